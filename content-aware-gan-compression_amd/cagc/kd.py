@@ -1,0 +1,113 @@
+"""The KD-retrain generator step — the measured unit (reference train.py:280-308 `G_Loss_BackProp`,
+:145-184 `KD_loss` in 'Output_Only' mode, :203-206 non-saturating loss, :226-237 style mixing), plus the
+synthetic workload of SURVEY.md §8-d.
+
+One process per GPU; the student may be wrapped in DistributedDataParallel (cagc/distributed.py) — its gradient
+all-reduce over RCCL is the path's only collective.  The content mask is supplied as a {0,1} tensor [B,1,H,W]
+(the reference derives it from BiSeNet, whose weights are not available offline) and
+LPIPS is off (`kd_lpips_lambda = 0`, weights unobtainable offline) — both stated in DESIGN.md."""
+import math
+import random
+
+import torch
+from torch.nn import functional as F
+
+from . import model as M
+from . import prune
+from .op import modconv as mc
+
+
+def requires_grad(model, flag=True):
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+def g_nonsaturating_loss(fake_pred):
+    return F.softplus(-fake_pred).mean()
+
+
+def index_aware_mixing_noise(batch, latent_dim, prob, n_latent, device, rng=random, generator=None):
+    """(list of 1 or 2 z, inject_index | None) — reference train.py:226-237."""
+    if prob > 0 and rng.random() < prob:
+        z = torch.randn(2, batch, latent_dim, device=device, generator=generator).unbind(0)
+        return list(z), rng.randint(1, n_latent - 1)
+    return [torch.randn(batch, latent_dim, device=device, generator=generator)], None
+
+
+def ellipse_mask(batch, size, device, coverage=0.6):
+    """Deterministic stand-in for the face-parsing mask: centred ellipse covering ~60 % of the pixels."""
+    yy, xx = torch.meshgrid(torch.arange(size, dtype=torch.float32), torch.arange(size, dtype=torch.float32),
+                            indexing="ij")
+    c = (size - 1) / 2
+    a = size * 0.5 * math.sqrt(coverage * 4 / math.pi) * 1.1
+    b = size * 0.5 * math.sqrt(coverage * 4 / math.pi) / 1.1
+    m = (((yy - c) / a) ** 2 + ((xx - c) / b) ** 2 <= 1.0).float()
+    return m.reshape(1, 1, size, size).repeat(batch, 1, 1, 1).to(device)
+
+
+class KDStep:
+    """student / teacher / discriminator + Adam, with `g_step` = one G_Loss_BackProp."""
+
+    def __init__(self, student, teacher, discriminator, lr=0.002, g_reg_every=4, kd_l1_lambda=3.0, mixing=0.9,
+                 latent=512, fused_adam=None):
+        self.student, self.teacher, self.disc = student, teacher, discriminator
+        self.kd_l1_lambda, self.mixing, self.latent = kd_l1_lambda, mixing, latent
+        self.teacher.eval()
+        requires_grad(self.teacher, False)
+        c = g_reg_every / (g_reg_every + 1)                      # lazy-regularisation correction, train.py:528-532
+        params = [p for p in student.parameters()]
+        dev = params[0].device
+        kw = {}
+        if fused_adam is None:
+            fused_adam = dev.type == "cuda"
+        if fused_adam:
+            kw["fused"] = True
+        self.optim = torch.optim.Adam(params, lr=lr * c, betas=(0.0 ** c, 0.99 ** c), **kw)
+        self.n_latent = (student.module if hasattr(student, "module") else student).n_latent
+
+    def g_losses(self, zs, inject_index, mask, student_noise=None, teacher_noise=None):
+        fake_list = self.student(zs, return_rgb_list=True, inject_index=inject_index, noise=student_noise)
+        fake_img = fake_list[-1]
+        g_loss = g_nonsaturating_loss(self.disc(fake_img))
+        with torch.no_grad():
+            teacher_img = self.teacher(zs, return_rgb_list=True, inject_index=inject_index, noise=teacher_noise)[-1]
+        kd_l1 = self.kd_l1_lambda * mc.masked_l1(fake_img, teacher_img, mask)
+        return g_loss, kd_l1, fake_img
+
+    def g_step(self, zs, inject_index, mask, student_noise=None, teacher_noise=None):
+        requires_grad(self.student, True)
+        requires_grad(self.disc, False)
+        g_loss, kd_l1, _ = self.g_losses(zs, inject_index, mask, student_noise, teacher_noise)
+        total = g_loss + kd_l1
+        self.optim.zero_grad(set_to_none=True)
+        total.backward()
+        self.optim.step()
+        return {"g": g_loss.detach(), "kd_l1_loss": kd_l1.detach()}
+
+    def sample_and_step(self, batch, mask, rng=random, generator=None):
+        dev = mask.device
+        zs, inj = index_aware_mixing_noise(batch, self.latent, self.mixing, self.n_latent, dev, rng, generator)
+        return self.g_step(zs, inj, mask)
+
+
+def build_synthetic_workload(size=256, device="cpu", seed=0, remove_ratio=0.7, style_dim=512, n_mlp=8,
+                             noise_weight=0.1):
+    """Teacher = seeded random-init full Generator with every noise weight set to 0.1 (init is 0 and would hide
+    the noise path); student = teacher sliced to the uniform 70 %-pruned shape with masks from seeded random
+    scores; D = seeded random-init Discriminator.  (SURVEY.md §8-d "Synthetic inputs".)"""
+    import numpy as np
+    torch.manual_seed(seed)
+    teacher = M.Generator(size, style_dim, n_mlp)
+    with torch.no_grad():
+        for n, p in teacher.named_parameters():
+            if n.endswith("noise.weight"):
+                p.fill_(noise_weight)
+    sd = teacher.state_dict()
+    shape = prune.network_shape(sd)
+    rng = np.random.RandomState(seed + 1)
+    masks = prune.masks_from_scores([rng.rand(c) for c in shape], shape, prune.uniform_remove_list(shape, remove_ratio))
+    ssd = prune.mask_generator_state_dict(sd, masks)
+    student = M.Generator(size, style_dim, n_mlp, generator_net_shape=prune.network_shape(ssd))
+    student.load_state_dict(ssd, strict=True)
+    disc = M.Discriminator(size)
+    return student.to(device), teacher.to(device), disc.to(device)

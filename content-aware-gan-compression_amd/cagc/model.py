@@ -1,0 +1,490 @@
+"""StyleGAN2 Generator / Discriminator with the reference's Python API surface and state-dict contract
+(reference model.py), running on the hand-written gfx950 kernels for GPU tensors.
+
+What is kept byte-for-byte: class names, constructor arguments and defaults, forward keyword arguments,
+attribute names read by the reference's callers (`.size`, `.n_latent`, `.style`, `.input`, `.conv1`, `.convs`,
+`.to_rgbs`, `.to_rgb1`, `.noises`, `module.conv.weight`, `.conv.modulation`, `.conv.scale`, `.conv.demodulate`,
+`.conv.out_channel`), parameter / buffer names and their registration order (Util/mask_util.py and
+Util/network_util.py parse `state_dict()` by substring and position).
+
+What is different underneath: StyledConv = ONE fused op (modulated conv on the fp32 MFMA with the
+modulation applied to the staged input tile, demodulation + noise + bias + LeakyReLU in the epilogue); the
+upsampling conv writes a phase-planar intermediate consumed by a fused blur+epilogue kernel; ToRGB is one
+streaming kernel including the skip upsample; nothing materialises per-sample weights [B,Cout,Cin,k,k].
+"""
+import math
+import random
+
+import torch
+from torch import autograd, nn
+from torch.nn import functional as F
+
+from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
+from .op import modconv as mc
+
+
+class PixelNorm(nn.Module):
+    """x * rsqrt(mean_c(x^2) + 1e-8) — reference model.py:14-24."""
+
+    def forward(self, input):
+        return mc.pixel_norm(input)
+
+
+def make_kernel(k):
+    """1-D taps -> normalised 2-D FIR — reference model.py:27-35."""
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+def _resample_pad(ktaps, factor, extra=0):
+    p = ktaps - factor + extra
+    return p
+
+
+class Upsample(nn.Module):
+    """reference model.py:38-56."""
+
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class Downsample(nn.Module):
+    """reference model.py:59-77."""
+
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=1, down=self.factor, pad=self.pad)
+
+
+class Blur(nn.Module):
+    """reference model.py:80-96."""
+
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        k = make_kernel(kernel)
+        if upsample_factor > 1:
+            k = k * (upsample_factor ** 2)
+        self.register_buffer("kernel", k)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class EqualConv2d(nn.Module):
+    """reference model.py:99-134 (discriminator convs; stock F.conv2d -> MIOpen on the GPU)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride = stride
+        self.padding = padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, input):
+        return F.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]}, {self.weight.shape[2]},"
+                f" stride={self.stride}, padding={self.padding})")
+
+
+class EqualLinear(nn.Module):
+    """reference model.py:137-171."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, input):
+        if self.activation:
+            out = F.linear(input, self.weight * self.scale)
+            return fused_leaky_relu(out, self.bias * self.lr_mul)
+        return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})"
+
+
+class ScaledLeakyReLU(nn.Module):
+    """reference model.py:174-183."""
+
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, input):
+        return F.leaky_relu(input, negative_slope=self.negative_slope) * math.sqrt(2)
+
+
+class ModulatedConv2d(nn.Module):
+    """reference model.py:186-289.  forward(input, style, return_style_scalars=False)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        self.downsample = downsample
+        if upsample:   # `blur` is registered before `weight`/`modulation`: state-dict order (App. C)
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2, p // 2))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+        self._packed = None  # (weight version, data_ptr, wp_fwd, wp_bwd, wsq) for frozen weights
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
+                f"upsample={self.upsample}, downsample={self.downsample})")
+
+    # -- HIP plumbing ----------------------------------------------------------------------------
+    def _hip_eligible(self, input):
+        return (mc.use_hip(input) and input.dtype == torch.float32 and not self.downsample
+                and self.kernel_size in (1, 3) and not (self.upsample and
+                                                        (self.kernel_size != 3 or tuple(self.blur.kernel.shape) != (4, 4)
+                                                         or self.blur.pad != (1, 1))))
+
+    def packed_weights(self):
+        """Packed GEMM operands of `weight` (csrc/conv_igemm.hip k_pack_weights).  Trainable weights are
+        re-packed every forward (they change every optimiser step); frozen weights (teacher, g_ema, D-side
+        use) are cached and re-validated against the tensor's version counter and storage."""
+        w = self.weight
+        need_bwd = torch.is_grad_enabled()
+        if w.requires_grad and need_bwd:
+            return mc.pack_weights(w, True)
+        key = (w._version, w.data_ptr(), w.device)
+        if self._packed is None or self._packed[0] != key or (need_bwd and self._packed[1][1] is None):
+            self._packed = (key, mc.pack_weights(w, need_bwd))
+        return self._packed[1]
+
+    def invalidate_packed(self):
+        self._packed = None
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def _demod(self, s, wsq):
+        return mc._Demod.apply(s, self.weight, wsq) if self.demodulate else None
+
+    def forward(self, input, style, return_style_scalars=False):
+        batch, in_channel = input.shape[0], input.shape[1]
+        s = self.modulation(style)                                        # [B, Cin]
+        if self._hip_eligible(input):
+            wp_fwd, wp_bwd, wsq = self.packed_weights()
+            d = self._demod(s, wsq)
+            out = mc._ModConv.apply(input, self.weight, s, d, None, None, None, wp_fwd, wp_bwd,
+                                    self.blur.kernel if self.upsample else None, False, self.upsample)
+        else:
+            out = mc.modconv_composed(input, self.weight, s, self.demodulate, self.upsample, self.downsample,
+                                      self.blur.kernel if (self.upsample or self.downsample) else None,
+                                      self.blur.pad if (self.upsample or self.downsample) else None)
+        if return_style_scalars:
+            return out, s.view(batch, 1, in_channel, 1, 1)
+        return out
+
+
+class NoiseInjection(nn.Module):
+    """reference model.py:292-303."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def forward(self, image, noise=None):
+        if noise is None:
+            batch, _, height, width = image.shape
+            noise = image.new_empty(batch, 1, height, width).normal_()
+        return image + self.weight * noise
+
+
+class ConstantInput(nn.Module):
+    """reference model.py:306-320."""
+
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, input):
+        return self.input.repeat(input.shape[0], 1, 1, 1)
+
+
+class StyledConv(nn.Module):
+    """reference model.py:323-367: ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU; one fused op on the GPU."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1],
+                 demodulate=True):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, return_style_scalars=False, noise=None):
+        conv = self.conv
+        fused = (conv._hip_eligible(input) and self.activate.bias is not None
+                 and self.activate.negative_slope == 0.2 and abs(self.activate.scale - 2 ** 0.5) < 1e-12)
+        if fused:
+            batch, cin, h, w = input.shape
+            s = conv.modulation(style)
+            wp_fwd, wp_bwd, wsq = conv.packed_weights()
+            d = conv._demod(s, wsq)
+            oh, ow = (2 * h, 2 * w) if conv.upsample else (h, w)
+            if noise is None:
+                noise = input.new_empty(batch, 1, oh, ow).normal_()
+            elif noise.shape[0] not in (1, batch) or tuple(noise.shape[1:]) != (1, oh, ow):
+                noise = noise.expand(batch, 1, oh, ow)
+            out = mc._ModConv.apply(input, conv.weight, s, d, noise, self.noise.weight, self.activate.bias, wp_fwd,
+                                    wp_bwd, conv.blur.kernel if conv.upsample else None, True, conv.upsample)
+            styles = s.view(batch, 1, cin, 1, 1)
+        else:
+            if return_style_scalars:
+                out, styles = conv(input, style, True)
+            else:
+                out, styles = conv(input, style), None
+            out = self.activate(self.noise(out, noise=noise))
+        if return_style_scalars:
+            return out, styles
+        return out
+
+
+class ToRGB(nn.Module):
+    """reference model.py:370-395."""
+
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, input, style, skip=None, return_style_scalars=False):
+        conv = self.conv
+        up = getattr(self, "upsample", None)
+        fused = (mc.use_hip(input) and input.dtype == torch.float32
+                 and (skip is None or (up is not None and up.factor == 2 and tuple(up.kernel.shape) == (4, 4)
+                                       and up.pad == (2, 1) and skip.shape[2] * 2 == input.shape[2])))
+        if fused:
+            s = conv.modulation(style)
+            out = mc._ToRGB.apply(input, conv.weight, s, self.bias, skip, up.kernel if skip is not None else None)
+            styles = s.view(input.shape[0], 1, input.shape[1], 1, 1)
+        else:
+            out, styles = conv(input, style, True)
+            out = out + self.bias
+            if skip is not None:
+                out = out + self.upsample(skip)
+        if return_style_scalars:
+            return out, styles
+        return out
+
+
+class Generator(nn.Module):
+    """reference model.py:398-666 — same constructor (incl. `generator_net_shape` for pruned students) and
+    forward keywords."""
+
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01,
+                 generator_net_shape=None):
+        super().__init__()
+        self.size = size
+        self.style_dim = style_dim
+        self.style = nn.Sequential(PixelNorm(), *[EqualLinear(style_dim, style_dim, lr_mul=lr_mlp,
+                                                              activation="fused_lrelu") for _ in range(n_mlp)])
+        self.channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier,
+                         128: 128 * channel_multiplier, 256: 64 * channel_multiplier, 512: 32 * channel_multiplier,
+                         1024: 16 * channel_multiplier}
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        if generator_net_shape is None:   # channel count entering every styled conv, plus the last output
+            res = [4] + [2 ** i for i in range(3, self.log_size + 1) for _ in range(2)]
+            shape = [self.channels[4]] + [self.channels[r] for r in res]
+        else:
+            shape = list(generator_net_shape)
+        self.input = ConstantInput(shape[0])
+        self.conv1 = StyledConv(shape[0], shape[1], 3, style_dim, blur_kernel=blur_kernel)
+        self.to_rgb1 = ToRGB(shape[1], style_dim, upsample=False)
+        self.convs = nn.ModuleList()
+        self.upsamples = nn.ModuleList()
+        self.to_rgbs = nn.ModuleList()
+        self.noises = nn.Module()
+        for layer_idx in range(self.num_layers):
+            r = (layer_idx + 5) // 2
+            self.noises.register_buffer(f"noise_{layer_idx}", torch.randn(1, 1, 2 ** r, 2 ** r))
+        n_blocks = (len(shape) // 2 - 1) if generator_net_shape is not None else (self.log_size - 2)
+        for i in range(1, n_blocks + 1):
+            self.convs.append(StyledConv(shape[2 * i - 1], shape[2 * i], 3, style_dim, upsample=True,
+                                         blur_kernel=blur_kernel))
+            self.convs.append(StyledConv(shape[2 * i], shape[2 * i + 1], 3, style_dim, blur_kernel=blur_kernel))
+            self.to_rgbs.append(ToRGB(shape[2 * i + 1], style_dim))
+        self.n_latent = self.log_size * 2 - 2
+
+    def make_noise(self):
+        device = self.input.input.device
+        noises = [torch.randn(1, 1, 4, 4, device=device)]
+        for i in range(3, self.log_size + 1):
+            noises += [torch.randn(1, 1, 2 ** i, 2 ** i, device=device) for _ in range(2)]
+        return noises
+
+    def mean_latent(self, n_latent):
+        latent_in = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
+        return self.style(latent_in).mean(0, keepdim=True)
+
+    def get_latent(self, input):
+        return self.style(input)
+
+    def forward(self, noise_z, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                latent_styles=None, input_is_latent=False, noise=None, randomize_noise=True, PPL_regularize=False,
+                return_rgb_list=False, return_style_scalars=False):
+        if PPL_regularize:   # double backward: composed, twice-differentiable ops
+            with mc.composed_autograd():
+                image, latent = self._synthesize(noise_z, inject_index, truncation, truncation_latent, latent_styles,
+                                                 input_is_latent, noise, randomize_noise, False, False, True)
+                pl_noise = torch.randn_like(image) / math.sqrt(image.shape[2] * image.shape[3])
+                grad, = autograd.grad(outputs=(image * pl_noise).sum(), inputs=latent, create_graph=True)
+            path_lengths = torch.sqrt(grad.pow(2).sum(2).mean(1))
+            return image, path_lengths
+        return self._synthesize(noise_z, inject_index, truncation, truncation_latent, latent_styles, input_is_latent,
+                                noise, randomize_noise, return_rgb_list, return_style_scalars, False)
+
+    def _synthesize(self, noise_z, inject_index, truncation, truncation_latent, latent_styles, input_is_latent, noise,
+                    randomize_noise, return_rgb_list, return_style_scalars, want_latent):
+        styles = latent_styles if input_is_latent else [self.style(z) for z in noise_z]
+        if noise is None:
+            noise = ([None] * self.num_layers if randomize_noise
+                     else [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)])
+        if truncation < 1:
+            styles = [truncation_latent + truncation * (w - truncation_latent) for w in styles]
+        if len(styles) < 2:
+            inject_index = self.n_latent
+            latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1) if styles[0].ndim < 3 else styles[0]
+        else:
+            if inject_index is None:
+                inject_index = random.randint(1, self.n_latent - 1)
+            latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                                styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+
+        rss = return_style_scalars
+        styles_list = []
+        out = self.input(latent)
+        out = self.conv1(out, latent[:, 0], rss, noise=noise[0])
+        if rss:
+            out, sc = out
+            styles_list.append(sc)
+        skip = self.to_rgb1(out, latent[:, 1])
+        rgb_img_list = [skip]
+        i = 1
+        for blk, to_rgb in enumerate(self.to_rgbs):
+            for j in (0, 1):
+                out = self.convs[2 * blk + j](out, latent[:, i + j], rss, noise=noise[2 * blk + 1 + j])
+                if rss:
+                    out, sc = out
+                    styles_list.append(sc)
+            if rss and (i + 3) == latent.shape[1]:   # only the last ToRGB reports its scalars (ref :637-639)
+                skip, sc = to_rgb(out, latent[:, i + 2], skip, True)
+                styles_list.append(sc)
+            else:
+                skip = to_rgb(out, latent[:, i + 2], skip)
+            rgb_img_list.append(skip)
+            i += 2
+        image = skip
+        if want_latent:
+            return image, latent
+        returns = rgb_img_list if return_rgb_list else image
+        if rss:
+            returns = returns, styles_list
+        return returns
+
+
+# ---------------------------------------------------------------------------------------------------
+# Discriminator (reference model.py:670-798).  Its convolutions are stock F.conv2d (MIOpen); every Blur and
+# FusedLeakyReLU inside goes through the HIP upfirdn2d / fused-bias-act kernels.
+# ---------------------------------------------------------------------------------------------------
+class ConvLayer(nn.Sequential):
+    def __init__(self, in_channel, out_channel, kernel_size, downsample=False, blur_kernel=[1, 3, 3, 1], bias=True,
+                 activate=True):
+        layers = []
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            layers.append(Blur(blur_kernel, pad=((p + 1) // 2, p // 2)))
+            stride, self.padding = 2, 0
+        else:
+            stride, self.padding = 1, kernel_size // 2
+        layers.append(EqualConv2d(in_channel, out_channel, kernel_size, padding=self.padding, stride=stride,
+                                  bias=bias and not activate))
+        if activate:
+            layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
+        super().__init__(*layers)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channel, out_channel, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        self.conv1 = ConvLayer(in_channel, in_channel, 3)
+        self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=True)
+        self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, activate=False, bias=False)
+
+    def forward(self, input):
+        return (self.conv2(self.conv1(input)) + self.skip(input)) / math.sqrt(2)
+
+
+class Discriminator(nn.Module):
+    def __init__(self, size, channel_multiplier=2, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier, 128: 128 * channel_multiplier,
+                    256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+        convs = [ConvLayer(3, channels[size], 1)]
+        log_size = int(math.log(size, 2))
+        in_channel = channels[size]
+        for i in range(log_size, 2, -1):
+            out_channel = channels[2 ** (i - 1)]
+            convs.append(ResBlock(in_channel, out_channel, blur_kernel))
+            in_channel = out_channel
+        self.convs = nn.Sequential(*convs)
+        self.stddev_group = 4
+        self.stddev_feat = 1
+        self.final_conv = ConvLayer(in_channel + 1, channels[4], 3)
+        self.final_linear = nn.Sequential(EqualLinear(channels[4] * 4 * 4, channels[4], activation="fused_lrelu"),
+                                          EqualLinear(channels[4], 1))
+
+    def forward(self, input):
+        out = self.convs(input)
+        batch, channel, height, width = out.shape
+        group = min(batch, self.stddev_group)
+        stddev = out.view(group, -1, self.stddev_feat, channel // self.stddev_feat, height, width)
+        stddev = torch.sqrt(stddev.var(0, unbiased=False) + 1e-8)
+        stddev = stddev.mean([2, 3, 4], keepdims=True).squeeze(2)
+        stddev = stddev.repeat(group, 1, height, width)
+        out = torch.cat([out, stddev], 1)
+        out = self.final_conv(out)
+        return self.final_linear(out.view(batch, -1))

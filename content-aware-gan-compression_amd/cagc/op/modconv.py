@@ -1,0 +1,318 @@
+"""Modulated convolution, styled-conv epilogue, ToRGB, PixelNorm, demodulation, masked-L1 — the autograd
+wrappers over the MFMA / streaming kernels of libcagc_hip (csrc/conv_igemm.hip, conv_wgrad.hip, torgb.hip,
+upfirdn2d.hip, elementwise.hip), plus the composed-PyTorch path used for CPU tensors (reference dispatch
+rule) and for second-order autograd (path-length regulariser).
+
+Formulation — identical mathematics to reference model.py:241-289, different association:
+    s = modulation(style)                      [B,Cin]
+    d = rsqrt(sum_i s^2 * wsq + 1e-8)          [B,Cout],  wsq[o,i] = scale^2 sum_k W[o,i,k]^2
+    y = d * conv(s * x, scale * W)             one shared-weight conv instead of B grouped convs
+"""
+import math
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn import functional as F
+
+from .. import _lib
+from .upfirdn2d import _launch as _upfirdn_launch
+from .upfirdn2d import upfirdn2d
+
+EPI_LINEAR, EPI_STYLED = 0, 1
+SQRT2 = 2 ** 0.5
+
+# ---------------------------------------------------------------------------------------------------
+# second-order switch: inside `composed_autograd()` GPU tensors also take the composed path, whose every op
+# (F.conv2d, upfirdn2d, fused_leaky_relu) is twice differentiable.  Generator.forward(PPL_regularize=True)
+# enters it; the KD step (first order) never does.
+# ---------------------------------------------------------------------------------------------------
+_composed_depth = 0
+
+
+class composed_autograd:
+    def __enter__(self):
+        global _composed_depth
+        _composed_depth += 1
+
+    def __exit__(self, *a):
+        global _composed_depth
+        _composed_depth -= 1
+
+
+def use_hip(t):
+    return t.is_cuda and _composed_depth == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# weight packing
+# ---------------------------------------------------------------------------------------------------
+def pack_weights(weight, need_bwd):
+    """weight [1,Cout,Cin,k,k] -> (wp_fwd, wp_bwd | None, wsq [Cout,Cin]) on weight's device."""
+    _, cout, cin, k, _ = weight.shape
+    scale = 1.0 / math.sqrt(cin * k * k)
+    w = weight.detach().contiguous()
+    dev = w.device
+    wp_fwd = torch.empty(_lib.query("cagc_modconv_packed_elems", cin, cout, k), dtype=torch.float32, device=dev)
+    wp_bwd = (torch.empty(_lib.query("cagc_modconv_packed_elems", cout, cin, k), dtype=torch.float32, device=dev)
+              if need_bwd else None)
+    wsq = torch.empty(cout, cin, dtype=torch.float32, device=dev)
+    with _lib.on_device(w):
+        _lib.call("cagc_modconv_prep", _lib.ptr(wp_fwd), _lib.ptr(wp_bwd), _lib.ptr(wsq), _lib.ptr(w), cout, cin, k, scale)
+    return wp_fwd, wp_bwd, wsq
+
+
+class _Demod(Function):
+    """d[b,o] = rsqrt(sum_i s[b,i]^2 wsq[o,i] + 1e-8) — wavefront-shuffle reduction (cagc_demod_fwd)."""
+
+    @staticmethod
+    def forward(ctx, s, weight, wsq):
+        s = s.contiguous()
+        B, cin = s.shape
+        cout = wsq.shape[0]
+        d = torch.empty(B, cout, dtype=s.dtype, device=s.device)
+        with _lib.on_device(s):
+            _lib.call("cagc_demod_fwd", _lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq), B, cin, cout)
+        ctx.save_for_backward(s, weight, wsq, d)
+        return d
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gd):
+        s, weight, wsq, d = ctx.saved_tensors
+        B, cin = s.shape
+        cout = wsq.shape[0]
+        gd = gd.contiguous()
+        gs = torch.zeros_like(s) if ctx.needs_input_grad[0] else None
+        gwsq = torch.empty_like(wsq) if ctx.needs_input_grad[1] else None
+        with _lib.on_device(s):
+            _lib.call("cagc_demod_bwd", _lib.ptr(gs), _lib.ptr(gwsq), _lib.ptr(gd), _lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq),
+                      B, cin, cout)
+        gweight = None
+        if gwsq is not None:
+            k = weight.shape[-1]
+            scale2 = 1.0 / (cin * k * k)
+            gweight = (2.0 * scale2) * gwsq[None, :, :, None, None] * weight
+        return gs, gweight, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# the modulated conv (+ optional fused noise / bias / LeakyReLU epilogue)
+# ---------------------------------------------------------------------------------------------------
+class _ModConv(Function):
+    """x, weight, s, d, noise, noise_w, bias -> out.  `styled` selects the fused StyledConv epilogue
+    (reference model.py:351-367); `upsample` the transposed-conv + blur variant (model.py:259-270)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, s, d, noise, noise_w, bias, wp_fwd, wp_bwd, fir, styled, upsample):
+        x = x.contiguous()
+        s = s.contiguous()
+        B, cin, H, W = x.shape
+        cout, k = weight.shape[1], weight.shape[-1]
+        dev = x.device
+        d_c = d.contiguous() if d is not None else None
+        nb = 0
+        if noise is not None:
+            noise = noise.contiguous()
+            nb = noise.shape[0]
+        with _lib.on_device(x):
+            if upsample:
+                t = torch.empty(B, cout, 4, H + 1, W + 1, dtype=x.dtype, device=dev)
+                _lib.call("cagc_modconv_up_fwd", _lib.ptr(t), _lib.ptr(x), _lib.ptr(wp_fwd), _lib.ptr(s), B, cin, cout, H, W)
+                out = torch.empty(B, cout, 2 * H, 2 * W, dtype=x.dtype, device=dev)
+                _lib.call("cagc_blur_up_fwd", _lib.ptr(out), _lib.ptr(t), _lib.ptr(fir), _lib.ptr(d_c),
+                          _lib.ptr(noise) if styled else None, nb, _lib.ptr(noise_w) if styled else None,
+                          _lib.ptr(bias) if styled else None, B, cout, H, W, 0.2, SQRT2)
+                del t
+            else:
+                out = torch.empty(B, cout, H, W, dtype=x.dtype, device=dev)
+                _lib.call("cagc_modconv_fwd", _lib.ptr(out), _lib.ptr(x), _lib.ptr(wp_fwd), _lib.ptr(s), B, cin, cout, H, W,
+                          k, EPI_STYLED if styled else EPI_LINEAR, _lib.ptr(d_c), _lib.ptr(noise) if styled else None, nb,
+                          _lib.ptr(noise_w) if styled else None, _lib.ptr(bias) if styled else None, 0.2, SQRT2)
+        ctx.styled, ctx.upsample, ctx.k = styled, upsample, k
+        ctx.save_for_backward(x, s, d_c, noise, noise_w, bias, out, wp_bwd, fir)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, s, d, noise, noise_w, bias, out, wp_bwd, fir = ctx.saved_tensors
+        styled, upsample, k = ctx.styled, ctx.upsample, ctx.k
+        if wp_bwd is None:
+            raise RuntimeError("modulated conv: backward requested but the weights were packed forward-only")
+        B, cin, H, W = x.shape
+        cout = out.shape[1]
+        Ho, Wo = out.shape[2], out.shape[3]
+        dev = x.device
+        gout = gout.contiguous()
+        need_x, need_w, need_s, need_d = ctx.needs_input_grad[0:4]
+        gd = g_nw = g_bias = None
+        with _lib.on_device(x):
+            if styled:
+                gz = torch.empty_like(gout)
+                red = torch.empty(3, B, cout, dtype=x.dtype, device=dev)
+                _lib.call("cagc_styled_act_bwd", _lib.ptr(gz), _lib.ptr(red), _lib.ptr(gout), _lib.ptr(out), _lib.ptr(d),
+                          _lib.ptr(noise), noise.shape[0] if noise is not None else 0, B, cout, Ho * Wo, 0.2, SQRT2)
+                r0, r1, r2 = red[0], red[1], red[2]
+                g_bias = r0.sum(0)
+                if noise is not None:
+                    g_nw = r1.sum().reshape(1)
+                if d is not None and need_d:
+                    # z = (pre - nw*noise - bias) / d  ->  gd = sum_p gpre * z
+                    gd = r2 - bias[None, :] * r0
+                    if noise is not None:
+                        gd = gd - noise_w * r1
+                    gd = gd / d
+            else:
+                if d is not None:
+                    if need_d:
+                        gd = (gout * out).sum([2, 3]) / d         # out = d*z  ->  sum_p gout*z = sum_p gout*out / d
+                    gz = gout * d[:, :, None, None]
+                else:
+                    gz = gout
+            if upsample:
+                g = torch.empty(B, cout, 4, H + 1, W + 1, dtype=x.dtype, device=dev)
+                _lib.call("cagc_blur_up_bwd", _lib.ptr(g), _lib.ptr(gz), _lib.ptr(fir), B, cout, H, W)
+            else:
+                g = gz
+            gx = gs = gweight = None
+            if need_x or need_s:
+                gx = torch.empty_like(x)
+                gs = torch.zeros_like(s) if need_s else None
+                if upsample:
+                    _lib.call("cagc_modconv_up_dgrad", _lib.ptr(gx), _lib.ptr(gs), _lib.ptr(g), _lib.ptr(wp_bwd), _lib.ptr(s),
+                              _lib.ptr(x), B, cin, cout, H, W)
+                else:
+                    _lib.call("cagc_modconv_dgrad", _lib.ptr(gx), _lib.ptr(gs), _lib.ptr(g), _lib.ptr(wp_bwd), _lib.ptr(s),
+                              _lib.ptr(x), B, cin, cout, H, W, k)
+            if need_w:
+                up = 1 if upsample else 0
+                n_ws = _lib.query("cagc_modconv_wgrad_workspace", B, cin, cout, H, W, k, up)
+                ws = torch.empty(n_ws, dtype=x.dtype, device=dev)
+                gweight = torch.empty(1, cout, cin, k, k, dtype=x.dtype, device=dev)
+                _lib.call("cagc_modconv_wgrad", _lib.ptr(gweight), _lib.ptr(ws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(s), B, cin,
+                          cout, H, W, k, up, 1.0 / math.sqrt(cin * k * k))
+        return (gx if need_x else None, gweight, gs, gd, None, g_nw, g_bias, None, None, None, None, None)
+
+
+def modconv_composed(x, weight, s, demodulate, upsample, downsample, blur_kernel, blur_pad):
+    """Same mathematics from stock differentiable ops (CPU tensors; second-order mode on GPU)."""
+    _, cout, cin, k, _ = weight.shape
+    w = weight[0] * (1.0 / math.sqrt(cin * k * k))
+    xs = x * s[:, :, None, None]
+    if upsample:
+        y = F.conv_transpose2d(xs, w.transpose(0, 1), stride=2, padding=0)
+        y = upfirdn2d(y, blur_kernel, pad=blur_pad)
+    elif downsample:
+        y = F.conv2d(upfirdn2d(xs, blur_kernel, pad=blur_pad), w, stride=2, padding=0)
+    else:
+        y = F.conv2d(xs, w, padding=k // 2)
+    if demodulate:
+        wsq = w.pow(2).sum([2, 3])
+        d = torch.rsqrt((s * s) @ wsq.t() + 1e-8)
+        y = y * d[:, :, None, None]
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------
+# ToRGB
+# ---------------------------------------------------------------------------------------------------
+class _ToRGB(Function):
+    @staticmethod
+    def forward(ctx, x, weight, s, bias, skip, fir):
+        x = x.contiguous()
+        s = s.contiguous()
+        B, C, H, W = x.shape
+        w2 = weight.detach().reshape(3, C).contiguous()
+        b1 = bias.detach().reshape(3).contiguous()
+        sk = skip.contiguous() if skip is not None else None
+        out = torch.empty(B, 3, H, W, dtype=x.dtype, device=x.device)
+        scale = 1.0 / math.sqrt(C)
+        with _lib.on_device(x):
+            _lib.call("cagc_torgb_fwd", _lib.ptr(out), _lib.ptr(x), _lib.ptr(w2), _lib.ptr(s), _lib.ptr(b1), _lib.ptr(sk),
+                      _lib.ptr(fir) if sk is not None else None, B, C, H, W, scale)
+        ctx.save_for_backward(x, w2, s, fir)
+        ctx.has_skip = skip is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, w2, s, fir = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = gout.contiguous()
+        scale = 1.0 / math.sqrt(C)
+        gx = torch.empty_like(x)
+        gws = torch.empty(B, 3, C, dtype=x.dtype, device=x.device)
+        with _lib.on_device(x):
+            _lib.call("cagc_torgb_bwd", _lib.ptr(gx), _lib.ptr(gws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(w2), _lib.ptr(s), B, C,
+                      H, W, scale)
+        gweight = (scale * torch.einsum("bc,boc->oc", s, gws)).reshape(1, 3, C, 1, 1)
+        gs = scale * torch.einsum("oc,boc->bc", w2, gws)
+        gbias = g.sum([0, 2, 3]).reshape(1, 3, 1, 1)
+        gskip = None
+        if ctx.has_skip:
+            # adjoint of upfirdn2d(up=2, pad=(2,1)): flipped FIR, down=2, pad=(1,1)  (reference op/upfirdn2d.py:111-116)
+            gskip = _upfirdn_launch(g, torch.flip(fir, [0, 1]).contiguous(), (1, 1), (2, 2), (1, 1, 1, 1), (H // 2, W // 2))
+        return gx, gweight, gs, gbias, gskip, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# PixelNorm, masked L1
+# ---------------------------------------------------------------------------------------------------
+class _PixelNorm(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        with _lib.on_device(x):
+            _lib.call("cagc_pixelnorm_fwd", _lib.ptr(y), _lib.ptr(x), x.shape[0], x.shape[1])
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        with _lib.on_device(x):
+            _lib.call("cagc_pixelnorm_bwd", _lib.ptr(gx), _lib.ptr(gy), _lib.ptr(x), x.shape[0], x.shape[1])
+        return gx
+
+
+def pixel_norm(x):
+    if x.ndim == 2 and use_hip(x) and x.dtype == torch.float32:
+        return _PixelNorm.apply(x)
+    return x * torch.rsqrt(torch.mean(x * x, dim=1, keepdim=True) + 1e-8)
+
+
+class _MaskedL1(Function):
+    """mean | mask*teacher - mask*student |, gradient to the student only (reference train.py:156-164 with the
+    {0,1} mask of Util/content_aware_pruning.py:102-115)."""
+
+    @staticmethod
+    def forward(ctx, student, teacher, mask):
+        s = student.contiguous()
+        t = teacher.contiguous()
+        m = mask.contiguous()
+        B, C, H, W = s.shape
+        acc = torch.zeros(1, dtype=s.dtype, device=s.device)
+        gs = torch.empty_like(s)
+        n = s.numel()
+        with _lib.on_device(s):
+            _lib.call("cagc_masked_l1", _lib.ptr(acc), _lib.ptr(gs), _lib.ptr(t), _lib.ptr(s), _lib.ptr(m), B, C, H * W, 1.0 / n)
+        ctx.save_for_backward(gs)
+        return (acc / n).reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (gs,) = ctx.saved_tensors
+        return gs * g, None, None
+
+
+def masked_l1(student, teacher, mask):
+    if use_hip(student) and student.dtype == torch.float32:
+        return _MaskedL1.apply(student, teacher.detach(), mask)
+    return torch.mean(torch.abs(teacher.detach() * mask - student * mask))

@@ -1,0 +1,265 @@
+// Weight gradient of the modulated convolution on the fp32 matrix cores (gfx950).
+//
+//   gW[o,i,t] = scale * sum_{b} sum_{p in HxW} A_t[b,o,p] * ( s[b,i] * x[b,i,p (+) t] )
+//
+// plain 3x3 / 1x1 conv :  A_t = gz[b,o,y,x]                          B_t = xs[b,i,y+ky-r,x+kx-r]
+// transposed (up) conv :  A_t = gt[b,o,plane(ky&1,kx&1),y+ky/2,x+kx/2] B_t = xs[b,i,y,x]
+// (gt is the phase-planar gradient of cagc.h.)  GEMM roles: M = o, N = i, K = pixels, one accumulator set
+// per tap.  A workgroup owns a 32(o) x 32(i) x all-taps tile and a strided subset of the pixel tiles
+// (split-K over batch x space); its 4 wavefronts split each pixel tile by rows, reduce through LDS at the
+// end and write one partial slab; k_wgrad_reduce sums the slabs (deterministic, no atomics), applies
+// `scale` and writes the [Cout,Cin,k,k] layout.
+#include "common.h"
+#include <string.h>
+
+namespace cagc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgTap { int a_off, b_off; };  // float offsets inside one channel's LDS plane
+struct WgArgs {
+  const float* ga;  // gz or gt
+  const float* x;
+  const float* s;
+  float* ws;
+  int B, Cin, Cout, H, W;        // H,W: the K-grid (pixels summed over)
+  int NPA, AHg, AWg;             // global dims of the A tensor planes
+  int TH, TW, tiles_x, tiles_y, ntiles, nsplit;
+  int AH, AW, AWp, ACS;          // LDS A tile rows/cols/padded row stride/channel stride
+  int BH, BW, BWp, BCS;
+  int a_y0, a_x0, b_y0, b_x0;    // global offset of LDS row/col 0 relative to the tile origin
+  int ntaps;
+  int Mp32, Np32;
+  WgTap taps[9];
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* a_lds = smem;
+  float* b_lds = smem + 32 * A.ACS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, g = lane >> 4;
+  const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 32, sp = blockIdx.z;
+
+  f32x4 acc[NT][2][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[t][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int rows_per_wave = A.TH / 4;  // TH is 4 or 8
+  const int steps = A.TW / 4;
+  const int a_rows = 32 * A.NPA * A.AH, b_rows = 32 * A.BH;
+  const float inv_AH = 1.0f / (float)A.AH, inv_NPA = 1.0f / (float)A.NPA, inv_BH = 1.0f / (float)A.BH;
+  const int rx = tid & 63, ry = tid >> 6;
+
+  for (int tile = sp; tile < A.ntiles; tile += A.nsplit) {
+    int q = tile;
+    const int txi = q % A.tiles_x; q /= A.tiles_x;
+    const int tyi = q % A.tiles_y;
+    const int b = q / A.tiles_y;
+    const int y0 = tyi * A.TH, x0 = txi * A.TW;
+    __syncthreads();
+    // ---- stage A: [32 o][NPA][AH][AW] ---------------------------------------------------------
+    for (int r = ry; r < a_rows; r += 4) {
+      const int q1 = (int)(((float)r + 0.5f) * inv_AH);
+      const int iy = r - q1 * A.AH;
+      const int oc = (int)(((float)q1 + 0.5f) * inv_NPA);
+      const int pl = q1 - oc * A.NPA;
+      const int gy = y0 + A.a_y0 + iy;
+      const int o = o0 + oc;
+      const bool rok = (o < A.Cout) && (gy >= 0) && (gy < A.AHg);
+      const float* src = A.ga + (((int64_t)(b * A.Cout + o) * A.NPA + pl) * A.AHg + gy) * A.AWg;
+      float* dst = a_lds + oc * A.ACS + (pl * A.AH + iy) * A.AWp;
+      for (int ix = rx; ix < A.AW; ix += 64) {
+        const int gx = x0 + A.a_x0 + ix;
+        float v = 0.f;
+        if (rok && gx >= 0 && gx < A.AWg) v = src[gx];
+        dst[ix] = v;
+      }
+    }
+    // ---- stage B: [32 i][BH][BW], scaled by s[b,i] ------------------------------------------------
+    for (int r = ry; r < b_rows; r += 4) {
+      const int ic = (int)(((float)r + 0.5f) * inv_BH);
+      const int iy = r - ic * A.BH;
+      const int gy = y0 + A.b_y0 + iy;
+      const int i = i0 + ic;
+      const bool rok = (i < A.Cin) && (gy >= 0) && (gy < A.H);
+      const float sc = (rok && A.s) ? A.s[b * A.Cin + i] : 1.f;
+      const float* src = A.x + ((int64_t)(b * A.Cin + i) * A.H + gy) * A.W;
+      float* dst = b_lds + ic * A.BCS + iy * A.BWp;
+      for (int ix = rx; ix < A.BW; ix += 64) {
+        const int gx = x0 + A.b_x0 + ix;
+        float v = 0.f;
+        if (rok && gx >= 0 && gx < A.W) v = src[gx] * sc;
+        dst[ix] = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: this wave's rows -----------------------------------------------------------------
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
+      const int row = wave * rows_per_wave + rr;
+      for (int s4 = 0; s4 < steps; ++s4) {
+        const int px = 4 * s4 + g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (t < A.ntaps) {
+            const int ao = A.taps[t].a_off + row * A.AWp + px;
+            const int bo = A.taps[t].b_off + row * A.BWp + px;
+            float av[2], bv[2];
+            av[0] = a_lds[lm * A.ACS + ao];
+            av[1] = a_lds[(16 + lm) * A.ACS + ao];
+            bv[0] = b_lds[lm * A.BCS + bo];
+            bv[1] = b_lds[(16 + lm) * A.BCS + bo];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb)
+                acc[t][a][bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[bb], acc[t][a][bb], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- cross-wave reduction through LDS: red[t][o 32][i 32] ---------------------------------------
+  float* red = smem;
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              // C layout: row (M = o) = 4g + r, col (N = i) = lm
+              const int idx = (t * 32 + a * 16 + 4 * g + r) * 32 + bb * 16 + lm;
+              if (w == 0) red[idx] = acc[t][a][bb][r];
+              else red[idx] += acc[t][a][bb][r];
+            }
+    }
+  }
+  __syncthreads();
+  // slab layout ws[sp][t][Mp32][Np32]
+  float* slab = A.ws + (int64_t)sp * A.ntaps * A.Mp32 * A.Np32;
+  for (int e = tid; e < A.ntaps * 1024; e += 256) {
+    const int t = e >> 10, o = (e >> 5) & 31, i = e & 31;
+    slab[((int64_t)t * A.Mp32 + o0 + o) * A.Np32 + i0 + i] = red[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(float* __restrict__ gw, const float* __restrict__ ws, int Cout,
+                                                      int Cin, int ntaps, int Mp32, int Np32, int nsplit, float scale) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [Cout][Cin][ntaps]
+  if (idx >= (int64_t)Cout * Cin * ntaps) return;
+  const int t = (int)(idx % ntaps);
+  const int64_t q = idx / ntaps;
+  const int i = (int)(q % Cin), o = (int)(q / Cin);
+  const int64_t slab = (int64_t)ntaps * Mp32 * Np32;
+  const float* p = ws + ((int64_t)t * Mp32 + o) * Np32 + i;
+  float a = 0.f;
+  for (int s = 0; s < nsplit; ++s) a += p[s * slab];
+  gw[idx] = a * scale;
+}
+
+static int wgrad_geometry(WgArgs& a, int B, int Cin, int Cout, int H, int W, int ksize, int up) {
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  int tw = 4;
+  while (tw < W && tw < 32) tw <<= 1;
+  a.TW = tw;
+  a.TH = up ? 4 : 8;
+  a.tiles_x = cdiv(W, a.TW);
+  a.tiles_y = cdiv(H, a.TH);
+  a.ntiles = B * a.tiles_x * a.tiles_y;
+  a.ntaps = ksize * ksize;
+  a.Mp32 = round_up(Cout, 32);
+  a.Np32 = round_up(Cin, 32);
+  if (up) {
+    a.NPA = 4; a.AHg = H + 1; a.AWg = W + 1;
+    a.AH = a.TH + 1; a.AW = a.TW + 1; a.a_y0 = 0; a.a_x0 = 0;
+    a.BH = a.TH; a.BW = a.TW; a.b_y0 = 0; a.b_x0 = 0;
+  } else {
+    const int r = ksize / 2;
+    a.NPA = 1; a.AHg = H; a.AWg = W;
+    a.AH = a.TH; a.AW = a.TW; a.a_y0 = 0; a.a_x0 = 0;
+    a.BH = a.TH + 2 * r; a.BW = a.TW + 2 * r; a.b_y0 = -r; a.b_x0 = -r;
+  }
+  a.AWp = a.AW; a.BWp = a.BW;
+  auto pad2 = [](int v) { return v + ((2 - (v % 32)) + 32) % 32; };  // == 2 (mod 32): lanes lm*CS + g hit distinct banks
+  a.ACS = pad2(a.NPA * a.AH * a.AWp);
+  a.BCS = pad2(a.BH * a.BWp);
+  for (int ky = 0; ky < ksize; ++ky)
+    for (int kx = 0; kx < ksize; ++kx) {
+      WgTap& t = a.taps[ky * ksize + kx];
+      if (up) {
+        t.a_off = (((ky & 1) * 2 + (kx & 1)) * a.AH + ky / 2) * a.AWp + kx / 2;
+        t.b_off = 0;
+      } else {
+        t.a_off = 0;
+        t.b_off = ky * a.BWp + kx;
+      }
+    }
+  // split-K: enough workgroups to fill 256 CUs a few times over, never more than there are pixel tiles
+  const int mn = (a.Mp32 / 32) * (a.Np32 / 32);
+  int ns = (2048 + mn - 1) / mn;
+  if (ns > a.ntiles) ns = a.ntiles;
+  if (ns < 1) ns = 1;
+  a.nsplit = ns;
+  return CAGC_OK;
+}
+
+}  // namespace cagc
+
+using namespace cagc;
+
+extern "C" int64_t cagc_modconv_wgrad_workspace(int B, int Cin, int Cout, int H, int W, int ksize, int up) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3)) return -1;
+  WgArgs a;
+  wgrad_geometry(a, B, Cin, Cout, H, W, ksize, up);
+  return (int64_t)a.nsplit * a.ntaps * a.Mp32 * a.Np32;
+}
+
+extern "C" int cagc_modconv_wgrad(float* gweight, float* workspace, const float* g, const float* x, const float* s,
+                                  int B, int Cin, int Cout, int H, int W, int ksize, int up, float scale,
+                                  cagc_stream_t stream) {
+  const char* what = "cagc_modconv_wgrad";
+  CAGC_REQUIRE(gweight && workspace && g && x, "%s: null tensor", what);
+  CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
+  CAGC_REQUIRE(ksize == 3 || (ksize == 1 && !up), "%s: unsupported ksize/up", what);
+  WgArgs a;
+  wgrad_geometry(a, B, Cin, Cout, H, W, ksize, up);
+  a.ga = g; a.x = x; a.s = s; a.ws = workspace;
+  size_t smem = sizeof(float) * (size_t)(32 * a.ACS + 32 * a.BCS);
+  const size_t red = sizeof(float) * (size_t)a.ntaps * 1024;
+  if (smem < red) smem = red;
+  CAGC_REQUIRE(smem <= 160 * 1024, "%s: LDS tile %zu B too large", what, smem);
+  hipStream_t st = as_stream(stream);
+  dim3 grid(a.Mp32 / 32, a.Np32 / 32, a.nsplit);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  static bool attr9[64] = {}, attr1[64] = {};
+  if (ksize == 3) {
+    if (dev >= 0 && dev < 64 && !attr9[dev]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr9[dev] = true;
+    }
+    hipLaunchKernelGGL((k_wgrad<9>), grid, dim3(256), smem, st, a);
+  } else {
+    if (dev >= 0 && dev < 64 && !attr1[dev]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr1[dev] = true;
+    }
+    hipLaunchKernelGGL((k_wgrad<1>), grid, dim3(256), smem, st, a);
+  }
+  int rc = check_launch(what);
+  if (rc) return rc;
+  const int64_t n = (int64_t)Cout * Cin * a.ntaps;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n, 256)), dim3(256), 0, st, gweight, workspace, Cout, Cin, a.ntaps, a.Mp32,
+                     a.Np32, a.nsplit, scale);
+  return check_launch("cagc_modconv_wgrad(reduce)");
+}

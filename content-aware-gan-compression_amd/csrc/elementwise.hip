@@ -1,0 +1,391 @@
+// HBM-bound elementwise / small-reduction kernels of the generator hot path (gfx950).
+//   fused bias + LeakyReLU fwd / bwd(+grad_bias) / double-bwd      
+//   styled-conv epilogue backward (act' * d, three per-(b,c) reductions)
+//   PixelNorm fwd/bwd (row 1), demodulation fwd/bwd (row 3), masked-L1 distillation loss (row 12/14)
+// Layout [outer, C, inner]; one workgroup owns a contiguous chunk of ONE (outer, c) plane, so the bias
+// index is a workgroup-uniform scalar (the reference kernel pays an integer div + mod per element,
+// op/fused_bias_act_kernel.cu:25-29) and every access is a coalesced 16-byte-per-lane stream.
+#include "common.h"
+
+namespace cagc {
+
+constexpr int EW_THREADS = 256;
+constexpr int EW_VEC = 4;
+constexpr int EW_ITERS = 4;
+constexpr int EW_CHUNK = EW_THREADS * EW_VEC * EW_ITERS;  // 4096 elements per workgroup
+
+__device__ __forceinline__ float lrelu_fwd(float v, float alpha, float scale) {
+  return (v > 0.f ? v : v * alpha) * scale;
+}
+__device__ __forceinline__ float lrelu_gate(float ref, float alpha, float scale) {
+  return (ref > 0.f ? 1.f : alpha) * scale;
+}
+
+// block-wide sum of one float -> valid on thread 0
+__device__ __forceinline__ float block_sum(float v, float* sm /*[4]*/) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// MODE 0: out = lrelu(a + bias)            (a = x)
+// MODE 1: out = a * gate(ref)  [+ channel sum -> gsum]      (a = gout, ref = out)
+// MODE 2: out = (a + bias) * gate(ref)     (a = ggx, bias = ggbias, ref = out)
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(EW_THREADS) void k_bias_act_plane(float* __restrict__ out, const float* __restrict__ a,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ ref, float* __restrict__ gsum,
+                                                               int C, int64_t inner, int nchunk, float alpha,
+                                                               float scale) {
+  __shared__ float sm[4];
+  const int plane = blockIdx.x / nchunk;
+  const int chunk = blockIdx.x - plane * nchunk;
+  const int c = plane % C;
+  const float b = bias ? bias[c] : 0.f;
+  const int64_t base = (int64_t)plane * inner;
+  const int64_t lo = (int64_t)chunk * EW_CHUNK;
+  float acc = 0.f;
+  if (VEC) {
+#pragma unroll
+    for (int it = 0; it < EW_ITERS; ++it) {
+      const int64_t i = lo + ((int64_t)it * EW_THREADS + threadIdx.x) * EW_VEC;
+      if (i < inner) {
+        const float4 va = *reinterpret_cast<const float4*>(a + base + i);
+        float4 vr = va;
+        if (MODE != 0) vr = *reinterpret_cast<const float4*>(ref + base + i);
+        float4 vo;
+        if (MODE == 0) {
+          vo.x = lrelu_fwd(va.x + b, alpha, scale); vo.y = lrelu_fwd(va.y + b, alpha, scale);
+          vo.z = lrelu_fwd(va.z + b, alpha, scale); vo.w = lrelu_fwd(va.w + b, alpha, scale);
+        } else {
+          vo.x = (va.x + b) * lrelu_gate(vr.x, alpha, scale); vo.y = (va.y + b) * lrelu_gate(vr.y, alpha, scale);
+          vo.z = (va.z + b) * lrelu_gate(vr.z, alpha, scale); vo.w = (va.w + b) * lrelu_gate(vr.w, alpha, scale);
+          if (MODE == 1) acc += (vo.x + vo.y) + (vo.z + vo.w);
+        }
+        *reinterpret_cast<float4*>(out + base + i) = vo;
+      }
+    }
+  } else {
+    for (int it = 0; it < EW_ITERS * EW_VEC; ++it) {
+      const int64_t i = lo + (int64_t)it * EW_THREADS + threadIdx.x;
+      if (i < inner) {
+        const float va = a[base + i];
+        float vo;
+        if (MODE == 0) vo = lrelu_fwd(va + b, alpha, scale);
+        else { vo = (va + b) * lrelu_gate(ref[base + i], alpha, scale); if (MODE == 1) acc += vo; }
+        out[base + i] = vo;
+      }
+    }
+  }
+  if (MODE == 1 && gsum) {
+    const float s = block_sum(acc, sm);
+    if (threadIdx.x == 0) atomicAdd(gsum + c, s);
+  }
+}
+
+// small-inner variant ([N, C] inputs of the mapping network / D's final linear): one thread per element
+template <int MODE>
+__global__ __launch_bounds__(EW_THREADS) void k_bias_act_flat(float* __restrict__ out, const float* __restrict__ a,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ ref, float* __restrict__ gsum,
+                                                              int64_t total, int C, int64_t inner, float alpha,
+                                                              float scale) {
+  const int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)((i / inner) % C);
+  const float b = bias ? bias[c] : 0.f;
+  const float va = a[i];
+  float vo;
+  if (MODE == 0) vo = lrelu_fwd(va + b, alpha, scale);
+  else vo = (va + b) * lrelu_gate(ref[i], alpha, scale);
+  out[i] = vo;
+  if (MODE == 1 && gsum) atomicAdd(gsum + c, vo);
+}
+
+template <int MODE>
+static int launch_bias_act(float* out, const float* a, const float* bias, const float* ref, float* gsum, int64_t outer,
+                           int64_t C, int64_t inner, float alpha, float scale, hipStream_t st, const char* what) {
+  CAGC_REQUIRE(out && a, "%s: null tensor", what);
+  CAGC_REQUIRE(outer >= 0 && C > 0 && inner > 0, "%s: bad shape outer=%lld C=%lld inner=%lld", what, (long long)outer,
+               (long long)C, (long long)inner);
+  const int64_t total = outer * C * inner;
+  if (total == 0) return CAGC_OK;
+  if (inner < 256) {
+    const int64_t nb = (total + EW_THREADS - 1) / EW_THREADS;
+    CAGC_REQUIRE(nb < (1ll << 31), "%s: too large", what);
+    hipLaunchKernelGGL((k_bias_act_flat<MODE>), dim3((unsigned)nb), dim3(EW_THREADS), 0, st, out, a, bias, ref, gsum, total,
+                       (int)C, inner, alpha, scale);
+  } else {
+    const int nchunk = cdiv(inner, EW_CHUNK);
+    const int64_t nb = outer * C * nchunk;
+    CAGC_REQUIRE(nb < (1ll << 31), "%s: too large", what);
+    const bool vec = (inner % 4 == 0) && (((uintptr_t)out | (uintptr_t)a | (uintptr_t)ref) % 16 == 0);
+    if (vec)
+      hipLaunchKernelGGL((k_bias_act_plane<MODE, true>), dim3((unsigned)nb), dim3(EW_THREADS), 0, st, out, a, bias, ref,
+                         gsum, (int)C, inner, nchunk, alpha, scale);
+    else
+      hipLaunchKernelGGL((k_bias_act_plane<MODE, false>), dim3((unsigned)nb), dim3(EW_THREADS), 0, st, out, a, bias, ref,
+                         gsum, (int)C, inner, nchunk, alpha, scale);
+  }
+  return check_launch(what);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// styled epilogue backward
+// ---------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(EW_THREADS) void k_styled_act_bwd(float* __restrict__ gz, float* __restrict__ red,
+                                                               const float* __restrict__ gout,
+                                                               const float* __restrict__ out,
+                                                               const float* __restrict__ d,
+                                                               const float* __restrict__ noise, int noise_bstride_on,
+                                                               int B, int C, int64_t HW, int nchunk, float alpha,
+                                                               float act_scale) {
+  __shared__ float sm[4];
+  const int plane = blockIdx.x / nchunk;  // b*C + c
+  const int chunk = blockIdx.x - plane * nchunk;
+  const int b = plane / C;
+  const float dv = d ? d[plane] : 1.f;
+  const float inv_pos = 1.f / act_scale, inv_neg = 1.f / (act_scale * alpha);
+  const int64_t base = (int64_t)plane * HW;
+  const float* nz = noise ? noise + (noise_bstride_on ? (int64_t)b * HW : 0) : nullptr;
+  const int64_t lo = (int64_t)chunk * EW_CHUNK;
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+  auto one = [&](float g, float o, float n) -> float {
+    const bool pos = o > 0.f;
+    const float gp = g * (pos ? act_scale : act_scale * alpha);
+    r0 += gp;
+    r1 += gp * n;
+    r2 += gp * (o * (pos ? inv_pos : inv_neg));
+    return gp * dv;
+  };
+  if (VEC) {
+#pragma unroll
+    for (int it = 0; it < EW_ITERS; ++it) {
+      const int64_t i = lo + ((int64_t)it * EW_THREADS + threadIdx.x) * EW_VEC;
+      if (i < HW) {
+        const float4 g = *reinterpret_cast<const float4*>(gout + base + i);
+        const float4 o = *reinterpret_cast<const float4*>(out + base + i);
+        float4 n = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nz) n = *reinterpret_cast<const float4*>(nz + i);
+        float4 r;
+        r.x = one(g.x, o.x, n.x); r.y = one(g.y, o.y, n.y); r.z = one(g.z, o.z, n.z); r.w = one(g.w, o.w, n.w);
+        *reinterpret_cast<float4*>(gz + base + i) = r;
+      }
+    }
+  } else {
+    for (int it = 0; it < EW_ITERS * EW_VEC; ++it) {
+      const int64_t i = lo + (int64_t)it * EW_THREADS + threadIdx.x;
+      if (i < HW) gz[base + i] = one(gout[base + i], out[base + i], nz ? nz[i] : 0.f);
+    }
+  }
+  const float s0 = block_sum(r0, sm);
+  const float s1 = block_sum(r1, sm);
+  const float s2 = block_sum(r2, sm);
+  if (threadIdx.x == 0) {
+    const int64_t BC = (int64_t)B * C;
+    atomicAdd(red + plane, s0);
+    atomicAdd(red + BC + plane, s1);
+    atomicAdd(red + 2 * BC + plane, s2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PixelNorm: one wavefront per row
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pixelnorm_fwd(float* __restrict__ y, const float* __restrict__ x, int64_t rows,
+                                                       int dim) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + row * dim;
+  float ss = 0.f;
+  for (int i = lane; i < dim; i += 64) { const float v = xr[i]; ss += v * v; }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)dim + 1e-8f);
+  for (int i = lane; i < dim; i += 64) y[row * dim + i] = xr[i] * r;
+}
+
+__global__ __launch_bounds__(256) void k_pixelnorm_bwd(float* __restrict__ gx, const float* __restrict__ gy,
+                                                       const float* __restrict__ x, int64_t rows, int dim) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + row * dim;
+  const float* gr = gy + row * dim;
+  float ss = 0.f, gx_dot = 0.f;
+  for (int i = lane; i < dim; i += 64) { const float v = xr[i]; ss += v * v; gx_dot += gr[i] * v; }
+  ss = wave_sum(ss);
+  gx_dot = wave_sum(gx_dot);
+  const float r = rsqrtf(ss / (float)dim + 1e-8f);
+  // y = x r ; dy/dx = r I - r^3 x x^T / dim
+  const float k = r * r * r * gx_dot / (float)dim;
+  for (int i = lane; i < dim; i += 64) gx[row * dim + i] = gr[i] * r - xr[i] * k;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// demodulation
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_demod_fwd(float* __restrict__ d, const float* __restrict__ s,
+                                                   const float* __restrict__ wsq, int B, int Cin, int Cout) {
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);  // b*Cout + o
+  if (idx >= B * Cout) return;
+  const int b = idx / Cout, o = idx - b * Cout;
+  const int lane = threadIdx.x & 63;
+  const float* sr = s + (int64_t)b * Cin;
+  const float* wr = wsq + (int64_t)o * Cin;
+  float acc = 0.f;
+  for (int i = lane; i < Cin; i += 64) { const float sv = sr[i]; acc += sv * sv * wr[i]; }
+  acc = wave_sum(acc);
+  if (lane == 0) d[idx] = rsqrtf(acc + 1e-8f);
+}
+
+// gs[b,i] += 2 s[b,i] sum_o t[b,o] wsq[o,i];  t = -0.5 gd d^3
+__global__ __launch_bounds__(256) void k_demod_bwd_s(float* __restrict__ gs, const float* __restrict__ gd,
+                                                     const float* __restrict__ d, const float* __restrict__ s,
+                                                     const float* __restrict__ wsq, int B, int Cin, int Cout) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= Cin) return;
+  float acc = 0.f;
+  for (int o = 0; o < Cout; ++o) {
+    const float dv = d[b * Cout + o];
+    const float t = -0.5f * gd[b * Cout + o] * dv * dv * dv;
+    acc += t * wsq[(int64_t)o * Cin + i];
+  }
+  gs[(int64_t)b * Cin + i] += 2.f * s[(int64_t)b * Cin + i] * acc;
+}
+__global__ __launch_bounds__(256) void k_demod_bwd_w(float* __restrict__ gwsq, const float* __restrict__ gd,
+                                                     const float* __restrict__ d, const float* __restrict__ s, int B,
+                                                     int Cin, int Cout) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int o = blockIdx.y;
+  if (i >= Cin) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float dv = d[b * Cout + o];
+    const float t = -0.5f * gd[b * Cout + o] * dv * dv * dv;
+    const float sv = s[(int64_t)b * Cin + i];
+    acc += t * sv * sv;
+  }
+  gwsq[(int64_t)o * Cin + i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// masked L1
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void k_masked_l1(float* __restrict__ loss_sum, float* __restrict__ gs,
+                                                          const float* __restrict__ t, const float* __restrict__ s,
+                                                          const float* __restrict__ mask, int C, int64_t HW, int nchunk,
+                                                          float coef) {
+  __shared__ float sm[4];
+  const int plane = blockIdx.x / nchunk;  // b*C + c
+  const int chunk = blockIdx.x - plane * nchunk;
+  const int b = plane / C;
+  const int64_t base = (int64_t)plane * HW, mbase = (int64_t)b * HW;
+  const int64_t lo = (int64_t)chunk * EW_CHUNK;
+  float acc = 0.f;
+  for (int it = 0; it < EW_ITERS * EW_VEC; ++it) {
+    const int64_t i = lo + (int64_t)it * EW_THREADS + threadIdx.x;
+    if (i < HW) {
+      const float m = mask[mbase + i];
+      const float diff = m * s[base + i] - m * t[base + i];
+      acc += fabsf(diff);
+      if (gs) gs[base + i] = diff > 0.f ? coef * m : (diff < 0.f ? -coef * m : 0.f);
+    }
+  }
+  const float tot = block_sum(acc, sm);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, tot);
+}
+
+}  // namespace cagc
+
+using namespace cagc;
+
+extern "C" int cagc_fused_bias_act_fwd(float* out, const float* x, const float* bias, int64_t outer, int64_t C,
+                                       int64_t inner, float alpha, float scale, cagc_stream_t stream) {
+  return launch_bias_act<0>(out, x, bias, nullptr, nullptr, outer, C, inner, alpha, scale, as_stream(stream),
+                            "cagc_fused_bias_act_fwd");
+}
+extern "C" int cagc_fused_bias_act_bwd(float* gx, float* gbias, const float* gout, const float* out, int64_t outer,
+                                       int64_t C, int64_t inner, float alpha, float scale, cagc_stream_t stream) {
+  CAGC_REQUIRE(out, "cagc_fused_bias_act_bwd: null out");
+  return launch_bias_act<1>(gx, gout, nullptr, out, gbias, outer, C, inner, alpha, scale, as_stream(stream),
+                            "cagc_fused_bias_act_bwd");
+}
+extern "C" int cagc_fused_bias_act_bwd2(float* ggout, const float* ggx, const float* ggbias, const float* out,
+                                        int64_t outer, int64_t C, int64_t inner, float alpha, float scale,
+                                        cagc_stream_t stream) {
+  CAGC_REQUIRE(out, "cagc_fused_bias_act_bwd2: null out");
+  return launch_bias_act<2>(ggout, ggx, ggbias, out, nullptr, outer, C, inner, alpha, scale, as_stream(stream),
+                            "cagc_fused_bias_act_bwd2");
+}
+
+extern "C" int cagc_styled_act_bwd(float* gz, float* red, const float* gout, const float* out, const float* d,
+                                   const float* noise, int noise_batch, int B, int C, int64_t HW, float alpha,
+                                   float act_scale, cagc_stream_t stream) {
+  CAGC_REQUIRE(gz && red && gout && out, "cagc_styled_act_bwd: null tensor");
+  CAGC_REQUIRE(B > 0 && C > 0 && HW > 0, "cagc_styled_act_bwd: bad shape");
+  CAGC_REQUIRE(!noise || noise_batch == 1 || noise_batch == B, "cagc_styled_act_bwd: noise batch %d not in {1,%d}",
+               noise_batch, B);
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(red, 0, sizeof(float) * 3 * (size_t)B * C, st) != hipSuccess) {
+    set_error("cagc_styled_act_bwd: memset failed");
+    return CAGC_ERR_LAUNCH;
+  }
+  const int nchunk = cdiv(HW, EW_CHUNK);
+  const int64_t nb = (int64_t)B * C * nchunk;
+  CAGC_REQUIRE(nb < (1ll << 31), "cagc_styled_act_bwd: too large");
+  const bool vec = (HW % 4 == 0) && (((uintptr_t)gz | (uintptr_t)gout | (uintptr_t)out | (uintptr_t)noise) % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL((k_styled_act_bwd<true>), dim3((unsigned)nb), dim3(EW_THREADS), 0, st, gz, red, gout, out, d,
+                       noise, noise_batch == B ? 1 : 0, B, C, HW, nchunk, alpha, act_scale);
+  else
+    hipLaunchKernelGGL((k_styled_act_bwd<false>), dim3((unsigned)nb), dim3(EW_THREADS), 0, st, gz, red, gout, out, d,
+                       noise, noise_batch == B ? 1 : 0, B, C, HW, nchunk, alpha, act_scale);
+  return check_launch("cagc_styled_act_bwd");
+}
+
+extern "C" int cagc_pixelnorm_fwd(float* y, const float* x, int64_t rows, int dim, cagc_stream_t stream) {
+  CAGC_REQUIRE(y && x && rows >= 0 && dim > 0, "cagc_pixelnorm_fwd: bad argument");
+  if (rows == 0) return CAGC_OK;
+  hipLaunchKernelGGL(k_pixelnorm_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), y, x, rows, dim);
+  return check_launch("cagc_pixelnorm_fwd");
+}
+extern "C" int cagc_pixelnorm_bwd(float* gx, const float* gy, const float* x, int64_t rows, int dim,
+                                  cagc_stream_t stream) {
+  CAGC_REQUIRE(gx && gy && x && rows >= 0 && dim > 0, "cagc_pixelnorm_bwd: bad argument");
+  if (rows == 0) return CAGC_OK;
+  hipLaunchKernelGGL(k_pixelnorm_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), gx, gy, x, rows, dim);
+  return check_launch("cagc_pixelnorm_bwd");
+}
+
+extern "C" int cagc_demod_fwd(float* d, const float* s, const float* wsq, int B, int Cin, int Cout,
+                              cagc_stream_t stream) {
+  CAGC_REQUIRE(d && s && wsq && B > 0 && Cin > 0 && Cout > 0, "cagc_demod_fwd: bad argument");
+  hipLaunchKernelGGL(k_demod_fwd, dim3(cdiv((int64_t)B * Cout, 4)), dim3(256), 0, as_stream(stream), d, s, wsq, B, Cin,
+                     Cout);
+  return check_launch("cagc_demod_fwd");
+}
+extern "C" int cagc_demod_bwd(float* gs, float* gwsq, const float* gd, const float* d, const float* s,
+                              const float* wsq, int B, int Cin, int Cout, cagc_stream_t stream) {
+  CAGC_REQUIRE(gd && d && s && wsq && B > 0 && Cin > 0 && Cout > 0, "cagc_demod_bwd: bad argument");
+  hipStream_t st = as_stream(stream);
+  if (gs) hipLaunchKernelGGL(k_demod_bwd_s, dim3(cdiv(Cin, 256), B), dim3(256), 0, st, gs, gd, d, s, wsq, B, Cin, Cout);
+  if (gwsq) hipLaunchKernelGGL(k_demod_bwd_w, dim3(cdiv(Cin, 256), Cout), dim3(256), 0, st, gwsq, gd, d, s, B, Cin, Cout);
+  return check_launch("cagc_demod_bwd");
+}
+
+extern "C" int cagc_masked_l1(float* loss_sum, float* gs, const float* t, const float* s, const float* mask, int B,
+                              int C, int64_t HW, float coef, cagc_stream_t stream) {
+  CAGC_REQUIRE(loss_sum && t && s && mask && B > 0 && C > 0 && HW > 0, "cagc_masked_l1: bad argument");
+  const int nchunk = cdiv(HW, EW_CHUNK);
+  const int64_t nb = (int64_t)B * C * nchunk;
+  CAGC_REQUIRE(nb < (1ll << 31), "cagc_masked_l1: too large");
+  hipLaunchKernelGGL(k_masked_l1, dim3((unsigned)nb), dim3(EW_THREADS), 0, as_stream(stream), loss_sum, gs, t, s, mask, C,
+                     HW, nchunk, coef);
+  return check_launch("cagc_masked_l1");
+}

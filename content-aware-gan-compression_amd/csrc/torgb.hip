@@ -1,0 +1,180 @@
+// ToRGB (reference model.py:370-395) as one HBM-bound pass (gfx950):
+//   out[b,o,p] = scale * sum_c w[o,c] s[b,c] x[b,c,p] + bias[o] + Upsample(skip)[b,o,p]
+// The activation x [B,C,H,W] — the only large operand — is streamed exactly once, 16 B per lane; the
+// 3 x C per-sample weights live in LDS; the skip branch's upfirdn2d(up=2, pad=(2,1), 4x4 FIR) is
+// evaluated in the epilogue from the 4x-smaller previous RGB (2x2 non-zero polyphase taps per output).
+// Backward: gx (one streamed write) and the per-sample weight gradient gws[b,o,c] = sum_p g x.
+#include "common.h"
+
+namespace cagc {
+
+constexpr int RGB_PIX = 1024;  // pixels per workgroup (256 threads x float4)
+
+__global__ __launch_bounds__(256) void k_torgb_fwd(float* __restrict__ out, const float* __restrict__ x,
+                                                   const float* __restrict__ w, const float* __restrict__ s,
+                                                   const float* __restrict__ bias, const float* __restrict__ skip,
+                                                   const float* __restrict__ fir, int C, int H, int W, int nstrip,
+                                                   float scale) {
+  extern __shared__ float wm[];  // [3][C]
+  __shared__ float kf[16];
+  const int b = blockIdx.x / nstrip, strip = blockIdx.x - b * nstrip;
+  const int64_t HW = (int64_t)H * W;
+  for (int e = threadIdx.x; e < 3 * C; e += 256) {
+    const int c = e % C;
+    wm[e] = scale * w[e] * s[(int64_t)b * C + c];
+  }
+  if (skip && threadIdx.x < 16) kf[threadIdx.x] = fir[15 - threadIdx.x];
+  __syncthreads();
+  const int64_t p0 = (int64_t)strip * RGB_PIX + threadIdx.x * 4;
+  if (p0 >= HW) return;
+  const bool vec = (HW % 4 == 0);
+  float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+  const float* xb = x + (int64_t)b * C * HW + p0;
+  if (vec) {
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)c * HW);
+      const float w0 = wm[c], w1 = wm[C + c], w2 = wm[2 * C + c];
+      a0[0] += w0 * v.x; a0[1] += w0 * v.y; a0[2] += w0 * v.z; a0[3] += w0 * v.w;
+      a1[0] += w1 * v.x; a1[1] += w1 * v.y; a1[2] += w1 * v.z; a1[3] += w1 * v.w;
+      a2[0] += w2 * v.x; a2[1] += w2 * v.y; a2[2] += w2 * v.z; a2[3] += w2 * v.w;
+    }
+  } else {
+    for (int c = 0; c < C; ++c) {
+      const float w0 = wm[c], w1 = wm[C + c], w2 = wm[2 * C + c];
+      for (int k = 0; k < 4; ++k)
+        if (p0 + k < HW) {
+          const float v = xb[(int64_t)c * HW + k];
+          a0[k] += w0 * v; a1[k] += w1 * v; a2[k] += w2 * v;
+        }
+    }
+  }
+  const int SH = H / 2, SW = W / 2;
+  for (int k = 0; k < 4; ++k) {
+    const int64_t p = p0 + k;
+    if (p >= HW) break;
+    float r[3] = {a0[k] + bias[0], a1[k] + bias[1], a2[k] + bias[2]};
+    if (skip) {
+      const int Y = (int)(p / W), X = (int)(p - (int64_t)Y * W);
+      // U[u] (zero-inserted, pad0 = 2): tap i reads u = Y + i - 2, non-zero iff even and 0 <= u/2 < SH
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int uy = Y + i - 2;
+        if (uy < 0 || (uy & 1)) continue;
+        const int sy = uy >> 1;
+        if (sy >= SH) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ux = X + j - 2;
+          if (ux < 0 || (ux & 1)) continue;
+          const int sx = ux >> 1;
+          if (sx >= SW) continue;
+          const float kv = kf[i * 4 + j];
+          const int64_t so = ((int64_t)b * 3 * SH + sy) * SW + sx;
+          r[0] += kv * skip[so];
+          r[1] += kv * skip[so + (int64_t)SH * SW];
+          r[2] += kv * skip[so + 2 * (int64_t)SH * SW];
+        }
+      }
+    }
+    out[((int64_t)b * 3 + 0) * HW + p] = r[0];
+    out[((int64_t)b * 3 + 1) * HW + p] = r[1];
+    out[((int64_t)b * 3 + 2) * HW + p] = r[2];
+  }
+}
+
+constexpr int RGB_CCH = 8;  // channels per workgroup in the backward
+
+__global__ __launch_bounds__(256) void k_torgb_bwd(float* __restrict__ gx, float* __restrict__ gws,
+                                                   const float* __restrict__ g, const float* __restrict__ x,
+                                                   const float* __restrict__ w, const float* __restrict__ s, int C,
+                                                   int64_t HW, int nchunk, int nsplit, float scale) {
+  __shared__ float red[4][3 * RGB_CCH];
+  int bid = blockIdx.x;
+  const int sp = bid % nsplit; bid /= nsplit;
+  const int ch = bid % nchunk;
+  const int b = bid / nchunk;
+  const int c0 = ch * RGB_CCH;
+  float wv[RGB_CCH][3];
+#pragma unroll
+  for (int k = 0; k < RGB_CCH; ++k) {
+    const int c = c0 + k;
+    const float sv = c < C ? scale * s[(int64_t)b * C + c] : 0.f;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) wv[k][o] = c < C ? sv * w[o * C + c] : 0.f;
+  }
+  float acc[RGB_CCH][3];
+#pragma unroll
+  for (int k = 0; k < RGB_CCH; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
+  const float* gb = g + (int64_t)b * 3 * HW;
+  for (int64_t p = (int64_t)sp * 256 + threadIdx.x; p < HW; p += (int64_t)nsplit * 256) {
+    const float g0 = gb[p], g1 = gb[HW + p], g2 = gb[2 * HW + p];
+#pragma unroll
+    for (int k = 0; k < RGB_CCH; ++k) {
+      const int c = c0 + k;
+      if (c < C) {
+        const int64_t off = ((int64_t)b * C + c) * HW + p;
+        const float xv = x[off];
+        acc[k][0] += g0 * xv; acc[k][1] += g1 * xv; acc[k][2] += g2 * xv;
+        gx[off] = wv[k][0] * g0 + wv[k][1] * g1 + wv[k][2] * g2;
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < RGB_CCH; ++k)
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const float v = wave_sum(acc[k][o]);
+      if (lane == 0) red[wave][k * 3 + o] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 3 * RGB_CCH) {
+    const int k = threadIdx.x / 3, o = threadIdx.x % 3;
+    const int c = c0 + k;
+    if (c < C) {
+      const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      atomicAdd(gws + ((int64_t)b * 3 + o) * C + c, v);
+    }
+  }
+}
+
+}  // namespace cagc
+
+using namespace cagc;
+
+extern "C" int cagc_torgb_fwd(float* out, const float* x, const float* w, const float* s, const float* bias,
+                              const float* skip, const float* fir, int B, int C, int H, int W, float scale,
+                              cagc_stream_t stream) {
+  const char* what = "cagc_torgb_fwd";
+  CAGC_REQUIRE(out && x && w && s && bias, "%s: null tensor", what);
+  CAGC_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "%s: bad shape", what);
+  CAGC_REQUIRE(!skip || (fir && H % 2 == 0 && W % 2 == 0), "%s: skip needs fir and even H,W", what);
+  CAGC_REQUIRE(3 * C * sizeof(float) <= 48 * 1024, "%s: C too large", what);
+  const int64_t HW = (int64_t)H * W;
+  const int nstrip = cdiv(HW, RGB_PIX);
+  hipLaunchKernelGGL(k_torgb_fwd, dim3((unsigned)(B * nstrip)), dim3(256), 3 * C * sizeof(float), as_stream(stream), out, x,
+                     w, s, bias, skip, fir, C, H, W, nstrip, scale);
+  return check_launch(what);
+}
+
+extern "C" int cagc_torgb_bwd(float* gx, float* gws, const float* g, const float* x, const float* w, const float* s,
+                              int B, int C, int H, int W, float scale, cagc_stream_t stream) {
+  const char* what = "cagc_torgb_bwd";
+  CAGC_REQUIRE(gx && gws && g && x && w && s, "%s: null tensor", what);
+  CAGC_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "%s: bad shape", what);
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(gws, 0, sizeof(float) * (size_t)B * 3 * C, st) != hipSuccess) {
+    set_error("%s: memset failed", what);
+    return CAGC_ERR_LAUNCH;
+  }
+  const int64_t HW = (int64_t)H * W;
+  const int nchunk = cdiv(C, RGB_CCH);
+  int nsplit = (2048 + B * nchunk - 1) / (B * nchunk);
+  const int maxsplit = cdiv(HW, 1024);
+  if (nsplit > maxsplit) nsplit = maxsplit;
+  if (nsplit < 1) nsplit = 1;
+  hipLaunchKernelGGL(k_torgb_bwd, dim3((unsigned)(B * nchunk * nsplit)), dim3(256), 0, st, gx, gws, g, x, w, s, C, HW,
+                     nchunk, nsplit, scale);
+  return check_launch(what);
+}

@@ -1,0 +1,258 @@
+// upfirdn2d family (gfx950): zero-insert upsample -> pad/crop -> 2-D FIR (true convolution) -> decimate.
+//   k_upfirdn2d_generic   any up/down/pad/kernel size; one thread per output (API completeness: the
+//                         reference's "large" path, op/upfirdn2d_kernel.cu:49-105, and the tiny 3-channel
+//                         ToRGB skip up/down sampling)
+//   k_fir_s1<KH,KW>       up = down = 1 (every Blur in G and D): 32x32 output tile, input halo tile
+//                         staged once in LDS, KH*KW FMAs per output from LDS
+//   k_blur_up_fwd/bwd     the 4x4 blur that follows the stride-2 transposed conv, reading / writing the
+//                         PHASE-PLANAR intermediate [B,C,4,H+1,W+1] (cagc.h), with the styled-conv
+//                         epilogue (demod scale, noise, bias, LeakyReLU) fused into the forward
+// All HBM-bound: each input element is fetched from HBM once per tile (+halo), outputs written once.
+#include "common.h"
+
+namespace cagc {
+
+__global__ __launch_bounds__(256) void k_upfirdn2d_generic(float* __restrict__ out, const float* __restrict__ x,
+                                                           const float* __restrict__ kern, int64_t total, int in_h,
+                                                           int in_w, int out_h, int out_w, int kh, int kw, int up_x,
+                                                           int up_y, int down_x, int down_y, int pad_x0, int pad_y0) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int ox = (int)(idx % out_w);
+  const int64_t r = idx / out_w;
+  const int oy = (int)(r % out_h);
+  const int64_t p = r / out_h;
+  const float* xp = x + p * (int64_t)in_h * in_w;
+  // position in the zero-inserted (un-padded) grid of the top-left tap
+  const int uy0 = oy * down_y - pad_y0;
+  const int ux0 = ox * down_x - pad_x0;
+  float acc = 0.f;
+  for (int i = 0; i < kh; ++i) {
+    const int uy = uy0 + i;
+    if (uy < 0 || uy % up_y != 0) continue;
+    const int iy = uy / up_y;
+    if (iy >= in_h) continue;
+    for (int j = 0; j < kw; ++j) {
+      const int ux = ux0 + j;
+      if (ux < 0 || ux % up_x != 0) continue;
+      const int ix = ux / up_x;
+      if (ix >= in_w) continue;
+      acc += xp[(int64_t)iy * in_w + ix] * kern[(kh - 1 - i) * kw + (kw - 1 - j)];
+    }
+  }
+  out[idx] = acc;
+}
+
+constexpr int FT = 32;  // output tile edge
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void k_fir_s1(float* __restrict__ out, const float* __restrict__ x,
+                                                const float* __restrict__ kern, int in_h, int in_w, int out_h,
+                                                int out_w, int pad_x0, int pad_y0, int tiles_x, int tiles_y) {
+  constexpr int IH = FT + KH - 1, IW = FT + KW - 1, LW = IW + 1;
+  __shared__ float tile[IH * LW];
+  __shared__ float kf[KH * KW];
+  int bid = blockIdx.x;
+  const int tx0 = (bid % tiles_x) * FT;
+  bid /= tiles_x;
+  const int ty0 = (bid % tiles_y) * FT;
+  const int64_t p = bid / tiles_y;
+  const float* xp = x + p * (int64_t)in_h * in_w;
+  if (threadIdx.x < KH * KW) {
+    const int i = threadIdx.x / KW, j = threadIdx.x % KW;
+    kf[threadIdx.x] = kern[(KH - 1 - i) * KW + (KW - 1 - j)];
+  }
+  for (int e = threadIdx.x; e < IH * IW; e += 256) {
+    const int r = e / IW, c = e - r * IW;
+    const int iy = ty0 + r - pad_y0, ix = tx0 + c - pad_x0;
+    float v = 0.f;
+    if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(int64_t)iy * in_w + ix];
+    tile[r * LW + c] = v;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  const int ox = tx0 + lx;
+  if (ox >= out_w) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int yy = ly + q * 8;
+    const int oy = ty0 + yy;
+    if (oy < out_h) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < KH; ++i)
+#pragma unroll
+        for (int j = 0; j < KW; ++j) acc += tile[(yy + i) * LW + lx + j] * kf[i * KW + j];
+      out[(p * out_h + oy) * (int64_t)out_w + ox] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// blur after the transposed conv, phase-planar input.  T_full[Y,X] = t[plane 2*(Y&1)+(X&1)][Y>>1][X>>1].
+// out[Y,X] = sum_{a,b} kf[a][b] * T_full[Y-1+a, X-1+b],  Y in [0,2H), kf = flipped fir.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur_up_fwd(float* __restrict__ out, const float* __restrict__ t,
+                                                     const float* __restrict__ fir, const float* __restrict__ d,
+                                                     const float* __restrict__ noise, int noise_bstride_on,
+                                                     const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                     int C, int H, int W, int tiles_x, int tiles_y, float alpha,
+                                                     float act_scale) {
+  constexpr int LR = FT + 4, LW = FT + 4 + 1;  // rows Y0-2 .. Y0+33 (36), same for cols
+  __shared__ float tile[LR * LW];
+  __shared__ float kf[16];
+  int bid = blockIdx.x;
+  const int X0 = (bid % tiles_x) * FT;
+  bid /= tiles_x;
+  const int Y0 = (bid % tiles_y) * FT;
+  const int plane = bid / tiles_y;  // b*C + c
+  const int b = plane / C, c = plane - b * C;
+  const int PH = H + 1, PW = W + 1;
+  const float* tp = t + (int64_t)plane * 4 * PH * PW;
+  if (threadIdx.x < 16) kf[threadIdx.x] = fir[15 - threadIdx.x];
+  // stage: LDS row r <-> Y = Y0 - 2 + r ; for each phase (py,px): m = (Y0-2)/2 + mr, mr in [0,18)
+  const int m0 = (Y0 - 2) / 2, n0 = (X0 - 2) / 2;  // Y0,X0 are multiples of 32 -> exact (may be -1)
+  constexpr int HR = LR / 2;                         // 18
+  for (int e = threadIdx.x; e < 4 * HR * HR; e += 256) {
+    const int nc = e % HR;
+    const int mr = (e / HR) % HR;
+    const int ph = e / (HR * HR);
+    const int m = m0 + mr, n = n0 + nc;
+    float v = 0.f;
+    if (m >= 0 && m < PH && n >= 0 && n < PW) v = tp[((int64_t)ph * PH + m) * PW + n];
+    tile[(2 * mr + (ph >> 1)) * LW + 2 * nc + (ph & 1)] = v;
+  }
+  __syncthreads();
+  const int OH = 2 * H, OW = 2 * W;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  const int X = X0 + lx;
+  if (X >= OW) return;
+  const float dv = d ? d[plane] : 1.f;
+  const float nw = noise ? noise_w[0] : 0.f;
+  const float bv = bias ? bias[c] : 0.f;
+  const bool act = (bias != nullptr);  // styled epilogue (noise + bias + LeakyReLU); otherwise blur * d only
+  const float* nz = noise ? noise + (noise_bstride_on ? (int64_t)b * OH * OW : 0) : nullptr;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int yy = ly + q * 8;
+    const int Y = Y0 + yy;
+    if (Y < OH) {
+      float acc = 0.f;
+      // T_full row Y-1+a  ->  LDS row (Y-1+a) - (Y0-2) = yy + 1 + a
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) acc += tile[(yy + 1 + a) * LW + lx + 1 + bb] * kf[a * 4 + bb];
+      float v = acc * dv;
+      if (act) {
+        v += bv;
+        if (nz) v += nw * nz[(int64_t)Y * OW + X];
+        v = (v > 0.f ? v : v * alpha) * act_scale;
+      }
+      out[((int64_t)plane * OH + Y) * OW + X] = v;
+    }
+  }
+}
+
+// gT_full[Yt,Xt] = sum_{a,b} kf[a][b] * gz[Yt+1-a, Xt+1-b]  for Yt in [0,2H], Xt in [0,2W]; the phase
+// planes' extra entries (Yt = 2H+1 or Xt = 2W+1) are written as zero.
+__global__ __launch_bounds__(256) void k_blur_up_bwd(float* __restrict__ gt, const float* __restrict__ gz,
+                                                     const float* __restrict__ fir, int H, int W, int tiles_x,
+                                                     int tiles_y) {
+  constexpr int LR = FT + 3, LW = FT + 3 + 1;  // gz rows Yt0-2 .. Yt0+32
+  __shared__ float tile[LR * LW];
+  __shared__ float kf[16];
+  int bid = blockIdx.x;
+  const int X0 = (bid % tiles_x) * FT;
+  bid /= tiles_x;
+  const int Y0 = (bid % tiles_y) * FT;
+  const int plane = bid / tiles_y;
+  const int OH = 2 * H, OW = 2 * W, PH = H + 1, PW = W + 1;
+  const float* gp = gz + (int64_t)plane * OH * OW;
+  float* tp = gt + (int64_t)plane * 4 * PH * PW;
+  if (threadIdx.x < 16) kf[threadIdx.x] = fir[15 - threadIdx.x];
+  for (int e = threadIdx.x; e < LR * LR; e += 256) {
+    const int r = e / LR, cc = e - r * LR;
+    const int y = Y0 - 2 + r, x = X0 - 2 + cc;
+    float v = 0.f;
+    if (y >= 0 && y < OH && x >= 0 && x < OW) v = gp[(int64_t)y * OW + x];
+    tile[r * LW + cc] = v;
+  }
+  __syncthreads();
+  // thread -> (phase, m-local, n-local): n fastest so each 16-lane group writes 64 contiguous bytes
+  for (int e = threadIdx.x; e < 4 * 16 * 16; e += 256) {
+    const int nl = e & 15, ml = (e >> 4) & 15, ph = e >> 8;
+    const int py = ph >> 1, px = ph & 1;
+    const int m = Y0 / 2 + ml, n = X0 / 2 + nl;
+    if (m >= PH || n >= PW) continue;
+    const int yl = 2 * ml + py, xl = 2 * nl + px;  // local T_full coords in the tile
+    const int Yt = Y0 + yl, Xt = X0 + xl;
+    float acc = 0.f;
+    if (Yt <= OH && Xt <= OW) {
+      // gz row Yt+1-a -> LDS row (Yt+1-a) - (Y0-2) = yl + 3 - a
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) acc += tile[(yl + 3 - a) * LW + xl + 3 - bb] * kf[a * 4 + bb];
+    }
+    tp[((int64_t)ph * PH + m) * PW + n] = acc;
+  }
+}
+
+}  // namespace cagc
+
+using namespace cagc;
+
+extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, int64_t planes, int in_h, int in_w,
+                              int out_h, int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                              int pad_x0, int pad_x1, int pad_y0, int pad_y1, cagc_stream_t stream) {
+  CAGC_REQUIRE(out && x && kernel, "cagc_upfirdn2d: null tensor");
+  CAGC_REQUIRE(planes >= 0 && in_h > 0 && in_w > 0 && kh > 0 && kw > 0, "cagc_upfirdn2d: bad shape");
+  CAGC_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, "cagc_upfirdn2d: up/down must be positive");
+  const int eh = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
+  const int ew = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+  CAGC_REQUIRE(in_h * up_y + pad_y0 + pad_y1 >= kh && in_w * up_x + pad_x0 + pad_x1 >= kw,
+               "cagc_upfirdn2d: kernel larger than padded input");
+  CAGC_REQUIRE(eh == out_h && ew == out_w, "cagc_upfirdn2d: out size %dx%d, expected %dx%d", out_h, out_w, eh, ew);
+  if (planes == 0) return CAGC_OK;
+  hipStream_t st = as_stream(stream);
+  if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4) {
+    const int tx = cdiv(out_w, FT), ty = cdiv(out_h, FT);
+    const int64_t nb = planes * tx * ty;
+    CAGC_REQUIRE(nb < (1ll << 31), "cagc_upfirdn2d: too large");
+    hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w,
+                       pad_x0, pad_y0, tx, ty);
+  } else {
+    const int64_t total = planes * out_h * out_w;
+    const int64_t nb = (total + 255) / 256;
+    CAGC_REQUIRE(nb < (1ll << 31), "cagc_upfirdn2d: too large");
+    hipLaunchKernelGGL(k_upfirdn2d_generic, dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, total, in_h, in_w, out_h,
+                       out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0);
+  }
+  return check_launch("cagc_upfirdn2d");
+}
+
+extern "C" int cagc_blur_up_fwd(float* out, const float* t, const float* fir, const float* d, const float* noise,
+                                int noise_batch, const float* noise_w, const float* bias, int B, int C, int H, int W,
+                                float alpha, float act_scale, cagc_stream_t stream) {
+  CAGC_REQUIRE(out && t && fir, "cagc_blur_up_fwd: null tensor");
+  CAGC_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cagc_blur_up_fwd: bad shape");
+  CAGC_REQUIRE(!noise || (bias && noise_w && (noise_batch == 1 || noise_batch == B)), "cagc_blur_up_fwd: bad noise arguments");
+  const int tx = cdiv(2 * W, FT), ty = cdiv(2 * H, FT);
+  const int64_t nb = (int64_t)B * C * tx * ty;
+  CAGC_REQUIRE(nb < (1ll << 31), "cagc_blur_up_fwd: too large");
+  hipLaunchKernelGGL(k_blur_up_fwd, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, t, fir, d, noise,
+                     noise_batch == B ? 1 : 0, noise_w, bias, C, H, W, tx, ty, alpha, act_scale);
+  return check_launch("cagc_blur_up_fwd");
+}
+
+extern "C" int cagc_blur_up_bwd(float* gt, const float* gz, const float* fir, int B, int C, int H, int W,
+                                cagc_stream_t stream) {
+  CAGC_REQUIRE(gt && gz && fir, "cagc_blur_up_bwd: null tensor");
+  CAGC_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cagc_blur_up_bwd: bad shape");
+  const int tx = cdiv(2 * W + 2, FT), ty = cdiv(2 * H + 2, FT);
+  const int64_t nb = (int64_t)B * C * tx * ty;
+  CAGC_REQUIRE(nb < (1ll << 31), "cagc_blur_up_bwd: too large");
+  hipLaunchKernelGGL(k_blur_up_bwd, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), gt, gz, fir, H, W, tx, ty);
+  return check_launch("cagc_blur_up_bwd");
+}

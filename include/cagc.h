@@ -1,0 +1,206 @@
+/*
+ * cagc.h — C ABI of libcagc_hip.so, the MI355X (gfx950) kernel library behind the StyleGAN2
+ * generator / KD-retrain hot path of lychenyoko/content-aware-gan-compression.
+ *
+ * This is the drop-in boundary.  The reference reaches its native code through two
+ * pybind11 modules JIT-built at import time:
+ *     fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)      op/fused_bias_act.cpp:11-21
+ *     upfirdn2d.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y, pads)    op/upfirdn2d.cpp:12-23
+ * and through PyTorch built-ins for the modulated convolution (model.py:241-289: F.conv2d /
+ * F.conv_transpose2d with groups=batch).  Each entry point below names the reference interface it
+ * replaces.
+ *
+ * Conventions
+ *   - plain C, no torch / ATen types: raw device pointers, sizes, a hipStream_t passed as void*.
+ *   - all tensors are fp32, contiguous, NCHW unless stated ("planes" = N*C flattened).
+ *   - OWNERSHIP: the caller allocates every output and workspace (PyTorch caching allocator) and
+ *     passes data_ptr(); the library never allocates, frees or retains a pointer.
+ *   - ERRORS: every function returns CAGC_OK (0) or a negative code; the message is available from
+ *     cagc_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - THREADING: re-entrant; no global mutable state except the thread-local error string.  The
+ *     device is the caller's current HIP device; kernels are enqueued on `stream` and not synchronised.
+ *   - nullable pointers are marked [nullable].
+ */
+#ifndef CAGC_H
+#define CAGC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAGC_OK 0
+#define CAGC_ERR_INVALID (-1)  /* bad argument (shape / null / unsupported combination) */
+#define CAGC_ERR_LAUNCH (-2)   /* hipGetLastError() after a launch */
+#define CAGC_ERR_UNSUPPORTED (-3)
+
+#define CAGC_ABI_VERSION 1
+
+typedef void* cagc_stream_t; /* hipStream_t */
+
+int cagc_abi_version(void);
+const char* cagc_last_error(void);
+/* "gfx950" — the only architecture the library is built for. */
+const char* cagc_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * fused bias + LeakyReLU            replaces fused.fused_bias_act (op/fused_bias_act.cpp:11-21,
+ *                                   kernel op/fused_bias_act_kernel.cu:18-49, act=3 only — the only
+ *                                   activation op/fused_act.py ever requests)
+ * x viewed as [outer, C, inner] (outer = N, inner = prod(dims[2:]); 2-D input: inner = 1).
+ * ---------------------------------------------------------------------------------------------- */
+/* forward (grad=0):  out = lrelu(x + bias[c], alpha) * scale.          bias [nullable] */
+int cagc_fused_bias_act_fwd(float* out, const float* x, const float* bias, int64_t outer, int64_t C,
+                            int64_t inner, float alpha, float scale, cagc_stream_t stream);
+/* backward (grad=1, op/fused_act.py:29-39): gx = gout * (out > 0 ? 1 : alpha) * scale and, fused,
+ * gbias[c] = sum over (outer, inner) of gx  (the reference does a separate grad_input.sum(dim)).
+ * gbias [nullable] must be zero-initialised by the caller (accumulated with atomics). */
+int cagc_fused_bias_act_bwd(float* gx, float* gbias, const float* gout, const float* out, int64_t outer,
+                            int64_t C, int64_t inner, float alpha, float scale, cagc_stream_t stream);
+/* double backward (op/fused_act.py:46-53): ggout = (ggx + ggbias[c]) * (out > 0 ? 1 : alpha) * scale.
+ * ggbias [nullable]. */
+int cagc_fused_bias_act_bwd2(float* ggout, const float* ggx, const float* ggbias, const float* out,
+                             int64_t outer, int64_t C, int64_t inner, float alpha, float scale,
+                             cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * upfirdn2d                         replaces upfirdn2d.upfirdn2d (op/upfirdn2d.cpp:12-23, kernels
+ *                                   op/upfirdn2d_kernel.cu:49-207).  x [planes, in_h, in_w] ->
+ *                                   out [planes, out_h, out_w]; kernel [kh, kw] device pointer,
+ *                                   correlated flipped (== true convolution), zero-insert up, pad /
+ *                                   crop (negative pads crop), decimate.  out_h/out_w are passed in and
+ *                                   checked against (in*up + pad0 + pad1 - k) / down + 1
+ *                                   (op/upfirdn2d.py:103-104).  The same entry point serves backward
+ *                                   (flipped kernel, up<->down swapped, op/upfirdn2d.py:29-43).
+ * ---------------------------------------------------------------------------------------------- */
+int cagc_upfirdn2d(float* out, const float* x, const float* kernel, int64_t planes, int in_h, int in_w,
+                   int out_h, int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                   int pad_x0, int pad_x1, int pad_y0, int pad_y1, cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PixelNorm                         replaces model.py:23-24 (4 composed torch kernels).
+ * x [rows, dim]: y = x * rsqrt(mean(x^2) + 1e-8).  One wavefront per row, shuffle reduction.
+ * backward: gx = r*(gy - y * mean(gy*y)),  r = rsqrt(mean(x^2)+eps).
+ * ---------------------------------------------------------------------------------------------- */
+int cagc_pixelnorm_fwd(float* y, const float* x, int64_t rows, int dim, cagc_stream_t stream);
+int cagc_pixelnorm_bwd(float* gx, const float* gy, const float* x, int64_t rows, int dim,
+                       cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Demodulation                      replaces model.py:249-253 (materialising Wm [B,Cout,Cin,k,k]).
+ * d[b,o] = rsqrt( sum_i s[b,i]^2 * wsq[o,i] + 1e-8 ),  wsq[o,i] = scale^2 * sum_k W[o,i,k]^2 is
+ * produced by cagc_modconv_prep.  One wavefront per (b,o), shuffle reduction over Cin.
+ * backward:  t[b,o] = -0.5 * gd[b,o] * d[b,o]^3;
+ *            gs[b,i]  += 2 s[b,i] * sum_o t[b,o] wsq[o,i]      (accumulates into gs)
+ *            gwsq[o,i] = sum_b t[b,o] s[b,i]^2
+ * ---------------------------------------------------------------------------------------------- */
+int cagc_demod_fwd(float* d, const float* s, const float* wsq, int B, int Cin, int Cout, cagc_stream_t stream);
+int cagc_demod_bwd(float* gs, float* gwsq, const float* gd, const float* d, const float* s, const float* wsq,
+                   int B, int Cin, int Cout, cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Modulated convolution             replaces model.py:241-289 — F.conv2d / F.conv_transpose2d with
+ *                                   groups=batch on per-sample weights [B*Cout,Cin,k,k].
+ *
+ * Formulation (mathematically identical):  with s = modulation(style) [B,Cin],
+ *   Wsc = scale * W,  xs[b,i] = s[b,i] * x[b,i],  z[b,o] = sum_{i,k} Wsc[o,i,k] * xs[b,i,.+k],
+ *   y[b,o] = d[b,o] * z[b,o]
+ * so the B grouped convolutions become ONE implicit GEMM (M = Cout, N = B*H*W, K = Cin*k*k) on the
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32), with s applied while staging the input tile into LDS and
+ * d / noise / bias / LeakyReLU applied in the MFMA epilogue.
+ *
+ * cagc_modconv_prep: repack W [Cout,Cin,k,k] (k = 1 or 3) into the two GEMM-A layouts
+ *   wp_fwd [k*k][Kp(Cin)][Mp(Cout)]  and  wp_bwd [k*k][Kp(Cout)][Mp(Cin)]   (Kp = round_up(.,4),
+ *   Mp = round_up(.,16), zero padded, multiplied by `scale`) and wsq [Cout,Cin] (see demod).
+ *   Any of the three outputs may be null.  Sizes: cagc_modconv_packed_elems().
+ * ---------------------------------------------------------------------------------------------- */
+int64_t cagc_modconv_packed_elems(int K, int M, int ksize); /* elements of a packed [k*k][Kp][Mp] tensor */
+int cagc_modconv_prep(float* wp_fwd, float* wp_bwd, float* wsq, const float* weight, int Cout, int Cin,
+                      int ksize, float scale, cagc_stream_t stream);
+
+/* epilogue selectors for cagc_modconv_fwd */
+#define CAGC_EPI_LINEAR 0 /* out = acc * (out_scale ? out_scale[b,o] : 1)                         */
+#define CAGC_EPI_STYLED 1 /* out = lrelu(acc*d[b,o] + noise_w[0]*noise[b?,y,x] + bias[o]) * act_scale
+                             == ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU (model.py:351-367) */
+
+/* Plain (stride-1, "same") modulated conv, k = 3 or 1.
+ *   x [B,Cin,H,W], wp = wp_fwd, s [B,Cin] [nullable = all ones], out [B,Cout,H,W].
+ *   epi = CAGC_EPI_LINEAR: out_scale [B,Cout] [nullable];  CAGC_EPI_STYLED: out_scale = d (required),
+ *   noise [noise_batch,1,H,W] with noise_batch in {1,B}, noise_w device scalar, bias [Cout].       */
+int cagc_modconv_fwd(float* out, const float* x, const float* wp, const float* s, int B, int Cin, int Cout,
+                     int H, int W, int ksize, int epi, const float* out_scale, const float* noise,
+                     int noise_batch, const float* noise_w, const float* bias, float alpha, float act_scale,
+                     cagc_stream_t stream);
+
+/* Upsampling modulated conv, first half (model.py:259-269): stride-2 transposed 3x3 conv, evaluated as
+ * its 4 output-parity phases.  Output is PHASE-PLANAR: t [B,Cout,4,H+1,W+1] with
+ *   t[b,o,2*py+px,m,n] = convT[b,o,2m+py,2n+px]   (zero where 2m+py > 2H or 2n+px > 2W)
+ * raw (no demod; d is applied by cagc_blur_up_fwd).                                                */
+int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, const float* s, int B, int Cin, int Cout,
+                        int H, int W, cagc_stream_t stream);
+/* Second half (model.py:270 Blur(pad=(1,1), 4x4 FIR x4) + :360-362 noise/bias/act), reading the
+ * phase-planar t:  out [B,C,2H,2W] = lrelu(d[b,c]*blur(t) + noise_w*noise + bias[c]) * act_scale.
+ * fir [4,4] device pointer (the registered `blur.kernel` buffer).  d/noise/bias [nullable] -> plain blur. */
+int cagc_blur_up_fwd(float* out, const float* t, const float* fir, const float* d, const float* noise,
+                     int noise_batch, const float* noise_w, const float* bias, int B, int C, int H, int W,
+                     float alpha, float act_scale, cagc_stream_t stream);
+/* Backward of the blur half: gz [B,C,2H,2W] -> gt phase-planar [B,C,4,H+1,W+1] (every element written). */
+int cagc_blur_up_bwd(float* gt, const float* gz, const float* fir, int B, int C, int H, int W,
+                     cagc_stream_t stream);
+
+/* Backward through noise/bias/act + demod scaling for a styled conv (both plain and up):
+ *   gpre = gout * (out > 0 ? 1 : alpha) * act_scale;     gz[b,c,.] = d[b,c] * gpre      (d [nullable]=1)
+ * and per-(b,c) reductions, written (not accumulated) to red [3,B,C]:
+ *   red[0] = sum gpre;  red[1] = sum gpre * noise;  red[2] = sum gpre * pre,
+ *   pre = out / (act_scale * (out>0 ? 1 : alpha))  (the pre-activation value, recovered from out).  */
+int cagc_styled_act_bwd(float* gz, float* red, const float* gout, const float* out, const float* d,
+                        const float* noise, int noise_batch, int B, int C, int64_t HW, float alpha,
+                        float act_scale, cagc_stream_t stream);
+
+/* dgrad of the plain conv: gx [B,Cin,H,W] = s[b,i] * sum_{o,k} Wsc[o,i,k] gz[b,o,.-k]  (wp = wp_bwd).
+ * If gs != null also accumulates gs[b,i] += sum_p (unscaled dgrad)[b,i,p] * x[b,i,p]  (the direct
+ * d loss / d s term); gs must be zero-initialised by the caller.  x [nullable iff gs null].       */
+int cagc_modconv_dgrad(float* gx, float* gs, const float* gz, const float* wp, const float* s, const float* x,
+                       int B, int Cin, int Cout, int H, int W, int ksize, cagc_stream_t stream);
+/* dgrad of the transposed conv from the phase-planar gradient gt [B,Cout,4,H+1,W+1] -> gx [B,Cin,H,W]. */
+int cagc_modconv_up_dgrad(float* gx, float* gs, const float* gt, const float* wp, const float* s,
+                          const float* x, int B, int Cin, int Cout, int H, int W, cagc_stream_t stream);
+
+/* wgrad: gweight [Cout,Cin,k,k] = scale * sum_{b,p} g[b,o,p(+k)] * s[b,i] x[b,i,p(+k)]   (the direct
+ * term; the demod term flows through cagc_demod_bwd).  `up` selects the transposed-conv geometry with
+ * g phase-planar.  workspace: cagc_modconv_wgrad_workspace() floats, caller-allocated.            */
+int64_t cagc_modconv_wgrad_workspace(int B, int Cin, int Cout, int H, int W, int ksize, int up);
+int cagc_modconv_wgrad(float* gweight, float* workspace, const float* g, const float* x, const float* s,
+                       int B, int Cin, int Cout, int H, int W, int ksize, int up, float scale,
+                       cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ToRGB                             replaces model.py:380-395 (1x1 modconv, no demod, + bias +
+ *                                   Upsample(skip) = upfirdn2d(up=2, pad=(2,1), 4x4 FIR x4)).
+ * x [B,C,H,W], w [3,C] (= conv.weight[0,:,:,0,0]), s [B,C], bias [3], skip [B,3,H/2,W/2] [nullable],
+ * fir [4,4] [nullable iff skip null] -> out [B,3,H,W].  HBM-bound: x is read exactly once.
+ * backward: gx [B,C,H,W] = s[b,c]*scale*sum_o w[o,c] g[b,o];   gws [B,3,C] = sum_p g[b,o,p] x[b,c,p]
+ *           (from which gw = scale*sum_b s*gws, gs = scale*sum_o w*gws);  the skip gradient is
+ *           cagc_upfirdn2d(down=2) on g, the bias gradient a plain sum — both on the caller's side.
+ * ---------------------------------------------------------------------------------------------- */
+int cagc_torgb_fwd(float* out, const float* x, const float* w, const float* s, const float* bias,
+                   const float* skip, const float* fir, int B, int C, int H, int W, float scale,
+                   cagc_stream_t stream);
+int cagc_torgb_bwd(float* gx, float* gws, const float* g, const float* x, const float* w, const float* s,
+                   int B, int C, int H, int W, float scale, cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Content-mask distillation loss    replaces Get_Masked_Tensor + mean|T-S| (train.py:156-164,
+ *                                   Util/content_aware_pruning.py:90-117) with one fused pass.
+ * loss_sum[0] += sum |mask*(t - s)|  (caller zero-inits, divides by numel, multiplies by lambda);
+ * gs [nullable] = coef * mask * sign(s - t)   (coef = lambda / numel * upstream).
+ * t,s [B,C,H,W]; mask [B,1,H,W].
+ * ---------------------------------------------------------------------------------------------- */
+int cagc_masked_l1(float* loss_sum, float* gs, const float* t, const float* s, const float* mask, int B,
+                   int C, int64_t HW, float coef, cagc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAGC_H */

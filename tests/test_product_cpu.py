@@ -1,0 +1,131 @@
+"""Host-side logic of the shipped package on CPU tensors: state-dict contract, API surface, and the composed
+(weight-stationary) formulation against the reference goldens.  No oracle involved here: goldens only."""
+import json
+import os
+
+import torch
+
+import cagc.model as M
+from cagc.op import fused_leaky_relu, upfirdn2d
+from _util import assert_close, load_json, load_npz, sub
+
+TOL = 2e-5   # same torch CPU kernels as the reference, different association (s on x, d on y)
+
+
+def _tiny_generator(sd, cfg):
+    g = M.Generator(cfg["size"], cfg["style_dim"], cfg["n_mlp"], generator_net_shape=cfg["shape"])
+    missing, unexpected = g.load_state_dict(sd, strict=True), None
+    return g
+
+
+def test_state_dict_contract_256_full_and_pruned():
+    c = load_json("contract_256")
+    g = M.Generator(256, 512, 8)
+    assert [[k, list(v.shape)] for k, v in g.state_dict().items()] == c["full_keys"]
+    assert sum(p.numel() for p in g.parameters()) == c["full_params"]
+    assert g.n_latent == c["n_latent"] and g.num_layers == c["num_layers"]
+    del g
+    p = M.Generator(256, 512, 8, generator_net_shape=c["pruned_shape"])
+    assert [[k, list(v.shape)] for k, v in p.state_dict().items()] == c["pruned_keys"]
+    assert sum(q.numel() for q in p.parameters()) == c["pruned_params"] == 5573364
+    del p
+    d = M.Discriminator(256)
+    assert [[k, list(v.shape)] for k, v in d.state_dict().items()] == c["d_keys"]
+    assert sum(q.numel() for q in d.parameters()) == c["d_params"]
+
+
+def test_ops_cpu_path_matches_reference_goldens():
+    g = load_npz("fused_act")
+    for k in ("2d_b", "4d_b", "2d_nb", "4d_nb"):
+        b = g.get(k + "_b")
+        assert_close(fused_leaky_relu(g[k + "_x"], b), g[k + "_y"], 1e-6, k)
+    u = load_npz("upfirdn2d")
+    for c in load_json("upfirdn2d_cases"):
+        n = c["name"]
+        assert_close(upfirdn2d(u[n + "_x"], u[n + "_k"], up=c["up"], down=c["down"], pad=tuple(c["pad"])), u[n + "_y"],
+                     1e-6, n)
+
+
+def test_modulated_conv_composed_matches_reference():
+    g = load_npz("modconv")
+    for c in load_json("modconv_cases"):
+        n = c["name"]
+        m = M.ModulatedConv2d(c["cin"], c["cout"], c["k"], c["style_dim"], demodulate=c.get("demodulate", True),
+                              upsample=c.get("upsample", False), downsample=c.get("downsample", False))
+        with torch.no_grad():
+            m.weight.copy_(g[n + "_weight"])
+            m.modulation.weight.copy_(g[n + "_mod_weight"])
+            m.modulation.bias.copy_(g[n + "_mod_bias"])
+        x = g[n + "_x"].clone().requires_grad_(True)
+        w = g[n + "_w"].clone().requires_grad_(True)
+        y, s = m(x, w, return_style_scalars=True)
+        assert_close(y, g[n + "_y"], TOL, n + " y")
+        assert_close(s, g[n + "_s"], TOL, n + " s")
+        grads = torch.autograd.grad(y, [x, w, m.weight, m.modulation.weight, m.modulation.bias], g[n + "_go"])
+        for name, gr in zip(("x", "w", "weight", "mod_weight", "mod_bias"), grads):
+            assert_close(gr, g[f"{n}_g{name}"], 5e-5, f"{n} g{name}")
+
+
+def test_tiny_generator_forward_variants_and_grads():
+    g = load_npz("generator_tiny")
+    meta = load_json("generator_tiny_keys")
+    net = _tiny_generator(sub(g, "sd/"), meta["config"])
+    assert [k for k, _ in meta["keys"]] == list(net.state_dict().keys())
+    rgbs, scal = net([g["z0"]], randomize_noise=False, return_rgb_list=True, return_style_scalars=True)
+    assert len(scal) == g["a_n_styles"]
+    for i, r in enumerate(rgbs):
+        assert_close(r, g[f"a_rgb{i}"], TOL, f"rgb{i}")
+    for i, s in enumerate(scal):
+        assert_close(s, g[f"a_style{i}"], TOL, f"style{i}")
+    assert_close(net([g["z0"], g["z1"]], inject_index=3, randomize_noise=False), g["c_img"], TOL, "mixing")
+    assert_close(net(None, latent_styles=[g["d_w0"]], input_is_latent=True, truncation=0.7,
+                     truncation_latent=g["d_mean_w"], randomize_noise=False), g["d_img"], TOL, "truncation")
+    noise = [g[f"e_noise{i}"] for i in range(meta["num_layers"])]
+    assert_close(net([g["z0"]], noise=noise), g["e_img"], TOL, "noise list")
+    net.zero_grad()
+    img = net([g["z0"]], randomize_noise=False)
+    img.abs().mean().backward()
+    for k, v in sub(g, "b_grad/").items():
+        p = dict(net.named_parameters())[k]
+        assert_close(p.grad if p.grad is not None else torch.zeros_like(p), v, 1e-4, "grad " + k)
+
+
+def test_tiny_generator_path_length_regulariser():
+    g = load_npz("generator_tiny")
+    meta = load_json("generator_tiny_keys")
+    net = _tiny_generator(sub(g, "sd/"), meta["config"])
+    from unittest import mock
+    with mock.patch.object(torch, "randn_like", lambda t: g["f_pl_noise"]):
+        img, pl = net([g["z0"]], PPL_regularize=True, randomize_noise=False)
+    assert_close(pl, g["f_path_lengths"], TOL, "path lengths")
+    (pl - 0.37).pow(2).mean().backward()
+    for k, v in sub(g, "f_grad/").items():
+        p = dict(net.named_parameters())[k]
+        assert_close(p.grad if p.grad is not None else torch.zeros_like(p), v, 2e-4, "pl grad " + k)
+
+
+def test_discriminator_matches_reference():
+    from oracle.ref_model import regenerate_state_dict   # only to rebuild the (29 MB) seeded D weights
+    g = load_npz("discriminator32")
+    d = M.Discriminator(32)
+    d.load_state_dict(regenerate_state_dict(load_json("discriminator32_keys"), g["seed"]), strict=True)
+    x = g["x"].clone().requires_grad_(True)
+    y = d(x)
+    assert_close(y, g["y"], TOL, "D out")
+    (gx,) = torch.autograd.grad(torch.nn.functional.softplus(-y).mean(), x)
+    assert_close(gx, g["gx"], 5e-5, "D input grad")
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    import re
+    from cagc import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "cagc.h")).read()
+    declared = set(re.findall(r"\b(cagc_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("cagc_stream_t")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/cagc.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.load().cagc_arch() == b"gfx950"
