@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — KD-retrain generator step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one G_Loss_BackProp-equivalent (reference train.py:280-308): student fwd (+ style mixing, fresh
+per-layer noise), frozen-D fwd, non-saturating GAN loss, teacher fwd, content-masked L1 distillation, backward
+into the student, Adam.  Workload = BASELINE.json configs[1]: 256 px, 70 %-pruned student [154x10,77,77,39,39] +
+full teacher, GLOBAL batch 16 (strong scaling: 16/N per GPU), fp32, synthetic seeded weights / latents / mask.
+LPIPS and BiSeNet are excluded (weights not obtainable offline) — DESIGN.md §6.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields + `roofline` (dominant hand-written kernel, HIP
+events on the launch stream) + `cpu_baseline` (the oracle — a port of the reference CPU path — on host cores)."""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "content-aware-gan-compression_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GLOBAL_BATCH = 16
+SIZE = 256
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def conv_flops(name, a):
+    """Algorithmic FLOPs (2 * MACs, the repo's own MAC convention of Util/Calculators.py) of one MFMA launch."""
+    if name == "cagc_modconv_fwd":       # (out,x,wp,s,B,Cin,Cout,H,W,k,...)
+        B, cin, cout, H, W, k = a[4:10]
+        return 2.0 * B * cin * cout * k * k * H * W
+    if name == "cagc_modconv_up_fwd":    # (t,x,wp,s,B,Cin,Cout,H,W): 9 MACs per input pixel
+        B, cin, cout, H, W = a[4:9]
+        return 2.0 * B * cin * cout * 9 * H * W
+    if name == "cagc_modconv_dgrad":     # (gx,gs,gz,wp,s,x,B,Cin,Cout,H,W,k)
+        B, cin, cout, H, W, k = a[6:12]
+        return 2.0 * B * cin * cout * k * k * H * W
+    if name == "cagc_modconv_up_dgrad":
+        B, cin, cout, H, W = a[6:11]
+        return 2.0 * B * cin * cout * 9 * H * W
+    if name == "cagc_modconv_wgrad":     # (gw,ws,g,x,s,B,Cin,Cout,H,W,k,up,scale)
+        B, cin, cout, H, W, k = a[5:11]
+        return 2.0 * B * cin * cout * k * k * H * W
+    return 0.0
+
+
+class KernelTimer:
+    """HIP-event timing of every libcagc entry point, on the stream the kernels are launched on."""
+
+    def __init__(self, lib_mod):
+        self.lib_mod = lib_mod
+        self.orig = lib_mod.call
+        self.records = []
+
+    def __enter__(self):
+        def timed(name, *args):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            st = torch.cuda.current_stream()
+            s.record(st)
+            self.orig(name, *args)
+            e.record(st)
+            self.records.append((name, s, e, conv_flops(name, args)))
+        self.lib_mod.call = timed
+        return self
+
+    def __exit__(self, *a):
+        self.lib_mod.call = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, s, e, fl in self.records:
+            d = agg.setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += s.elapsed_time(e)
+            d[2] += fl
+        return agg
+
+
+def cpu_baseline(sample_batch=4):
+    """The oracle (port of the reference CPU path: grouped convs on per-sample modulated weights, composed
+    upfirdn2d / leaky_relu) timed on the host cores on a bounded sample: ONE KD step at batch `sample_batch` of the
+    same 256 px workload (the reference's own CPU path took 57 s per bs-16 step on 8 cores)."""
+    from cagc import kd
+    from oracle import ref_kd
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    student, teacher, disc = kd.build_synthetic_workload(SIZE, "cpu", seed=0)
+    ssd = {k: v.detach() for k, v in student.state_dict().items()}
+    names = [n for n, _ in student.named_parameters()]
+    tsd, dsd = dict(teacher.state_dict()), dict(disc.state_dict())
+
+    def one(bs):
+        g = torch.Generator().manual_seed(99)
+        zs = [torch.randn(bs, 512, generator=g), torch.randn(bs, 512, generator=g)]
+        mask = kd.ellipse_mask(bs, SIZE, "cpu")
+        leaves = {k: ssd[k].clone().requires_grad_(True) for k in names}
+        sd = dict(ssd)
+        sd.update(leaves)
+        t0 = time.perf_counter()
+        g_loss, kd_l1, _ = ref_kd.kd_generator_losses_ref(sd, tsd, dsd, zs, 5, mask)
+        grads = torch.autograd.grad(g_loss + kd_l1, [leaves[k] for k in names], allow_unused=True)
+        ref_kd.adam_step_ref({k: ssd[k] for k in names},
+                             {k: (g if g is not None else torch.zeros_like(ssd[k])) for k, g in zip(names, grads)}, {},
+                             0.0016, (0.0, 0.99 ** 0.8))
+        return time.perf_counter() - t0
+    one(1)   # warm-up (oneDNN primitive creation)
+    t = one(sample_batch)
+    return {"value": round(sample_batch / t, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 KD generator step at batch {sample_batch} of the 256px bs16 workload ({t:.1f} s), after a batch-1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from cagc import _lib, distributed as cd, kd
+    rank, world, local = cd.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    _lib.load()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    # MIOpen exhaustive find for the discriminator's stock convs is opt-in (CAGC_MIOPEN_BENCHMARK=1)
+    torch.backends.cudnn.benchmark = os.environ.get("CAGC_MIOPEN_BENCHMARK", "0") == "1"
+    assert GLOBAL_BATCH % world == 0
+    bs = GLOBAL_BATCH // world
+
+    student, teacher, disc = kd.build_synthetic_workload(SIZE, dev, seed=0)
+    n_params = sum(p.numel() for p in student.parameters())
+    ddp_student = cd.wrap_student(student, dev)
+    step = kd.KDStep(ddp_student, teacher, disc)
+    mask = kd.ellipse_mask(bs, SIZE, dev)
+    rng = random.Random(rank)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    def run(n):
+        for _ in range(n):
+            step.sample_and_step(bs, mask, rng, gen)
+
+    run(args.warmup)
+    cd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    cd.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / args.steps * 1e3
+    value = GLOBAL_BATCH * args.steps / dt
+
+    roof = None
+    if not args.no_roofline:
+        with KernelTimer(_lib) as kt:
+            run(3)
+        agg = kt.summary()
+        if rank == 0:
+            mfma = {k: v for k, v in agg.items() if v[2] > 0}
+            name, (cnt, tot_ms, flops) = max(mfma.items(), key=lambda kv: kv[1][1])
+            ach = flops / (tot_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": name + " (k_conv_igemm, v_mfma_f32_16x16x4_f32)",
+                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": cnt // 3, "avg_launch_ms": round(tot_ms / cnt, 4),
+                    "flops_per_launch_avg": flops / cnt,
+                    "cagc_kernel_ms_per_step": {k: round(v[1] / 3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {"metric": "KD-retrain images/sec, 256px StyleGAN2 70%-pruned bs16", "value": round(value, 3),
+               "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "256px StyleGAN2 70%-pruned student [154x10,77,77,39,39] + full teacher KD generator step, "
+                                      "global bs16 (configs[1]); frozen D fwd+dgrad, masked-L1 KD, Adam; LPIPS/BiSeNet off",
+                          "global_batch": GLOBAL_BATCH, "per_gpu_batch": bs, "parallelism": f"dp{world}",
+                          "student_params": n_params},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

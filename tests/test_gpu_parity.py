@@ -1,0 +1,328 @@
+"""-m gpu: the HIP path (through the C ABI of libcagc_hip.so) against (1) the golden vectors captured from the
+reference CPU path and (2) the oracle (oracle/, torch-fp32 CPU restatement) on seeded inputs at sizes the oracle
+finishes in seconds.  Parity bar: max|a-b| / max|b| <= 1e-3 (BASELINE.json north_star), far
+tighter in practice because the MFMA path is an exact fp32 FMA chain."""
+import pytest
+import torch
+
+import cagc.model as M
+from cagc import _lib, kd
+from cagc.op import fused_leaky_relu, upfirdn2d
+from oracle import ref_kd, ref_model, ref_ops
+from _util import assert_close, load_json, load_npz, sub
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+TIGHT = 2e-5
+DEV = "cuda"
+
+
+def cu(t):
+    return t.to(DEV)
+
+
+def test_library_loaded_and_gfx950():
+    assert _lib.load().cagc_arch() == b"gfx950"
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+def test_fused_leaky_relu_golden_first_and_second_order():
+    g = load_npz("fused_act")
+    for k in ("2d_b", "4d_b", "2d_nb", "4d_nb"):
+        x = cu(g[k + "_x"]).requires_grad_(True)
+        b = cu(g[k + "_b"]).requires_grad_(True) if (k + "_b") in g else None
+        go = cu(g[k + "_go"]).requires_grad_(True)
+        y = fused_leaky_relu(x, b)
+        assert_close(y, g[k + "_y"], TIGHT, k + " y")
+        ins = [x] + ([b] if b is not None else [])
+        grads = torch.autograd.grad(y, ins, go, create_graph=True)
+        assert_close(grads[0], g[k + "_gx"], TIGHT, k + " gx")
+        if b is not None:
+            assert_close(grads[1], g[k + "_gb"], TIGHT, k + " gb")
+        (ggo,) = torch.autograd.grad(grads[0], go, cu(g[k + "_ggi"]))
+        assert_close(ggo, g[k + "_ggo"], TIGHT, k + " ggo")
+
+
+@pytest.mark.parametrize("shape", [(16, 39, 256, 256), (4, 154, 16, 16), (3, 7, 33, 17), (8, 512)])
+def test_fused_leaky_relu_large_vs_oracle(shape):
+    torch.manual_seed(1)
+    x = torch.randn(*shape)
+    b = torch.randn(shape[1])
+    go = torch.randn(*shape)
+    xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = ref_ops.fused_leaky_relu_ref(xr, br)
+    gr = torch.autograd.grad(yr, [xr, br], go)
+    xg, bg = cu(x).requires_grad_(True), cu(b).requires_grad_(True)
+    yg = fused_leaky_relu(xg, bg)
+    gg = torch.autograd.grad(yg, [xg, bg], cu(go))
+    assert torch.equal(yg.cpu(), yr.detach()), "elementwise op must be bit-exact"
+    assert_close(gg[0], gr[0], 1e-6, "grad_input")   # gout*(gate*scale) vs (gout*scale)*gate: 1-ulp association
+    assert_close(gg[1], gr[1], 1e-4, "grad_bias (reduction order differs)")
+
+
+def test_upfirdn2d_golden_all_configs_with_grad_and_gradgrad():
+    g = load_npz("upfirdn2d")
+    for c in load_json("upfirdn2d_cases"):
+        n = c["name"]
+        x = cu(g[n + "_x"]).requires_grad_(True)
+        k = cu(g[n + "_k"])
+        y = upfirdn2d(x, k, up=c["up"], down=c["down"], pad=tuple(c["pad"]))
+        assert_close(y, g[n + "_y"], TIGHT, n + " y")
+        go = cu(g[n + "_go"]).requires_grad_(True)
+        (gx,) = torch.autograd.grad(y, x, go, create_graph=True)
+        assert_close(gx, g[n + "_gx"], TIGHT, n + " gx")
+        # double backward: d(gx)/d(go) contracted with v == forward op applied to v (linear op)
+        v = torch.randn_like(gx)
+        (ggo,) = torch.autograd.grad(gx, go, v)
+        assert_close(ggo, ref_ops.upfirdn2d_ref(v.cpu(), g[n + "_k"], up=c["up"], down=c["down"], pad=tuple(c["pad"])), TIGHT,
+                     n + " gradgrad")
+
+
+@pytest.mark.parametrize("cfg", [((16, 128, 257, 257), 4.0, 1, 1, (1, 1)), ((4, 128, 128, 128), 1.0, 1, 1, (2, 2)),
+                                 ((16, 3, 128, 128), 4.0, 2, 1, (2, 1)), ((16, 3, 256, 256), 1.0, 1, 2, (1, 1)),
+                                 ((2, 5, 67, 41), 1.0, 1, 1, (1, 1))])
+def test_upfirdn2d_full_size_vs_oracle(cfg):
+    shape, gain, up, down, pad = cfg
+    torch.manual_seed(2)
+    x = torch.randn(*shape)
+    k = ref_ops.fir_kernel([1, 3, 3, 1], gain)
+    y = upfirdn2d(cu(x), cu(k), up=up, down=down, pad=pad)
+    assert_close(y, ref_ops.upfirdn2d_ref(x, k, up=up, down=down, pad=pad), TIGHT, str(cfg))
+
+
+def _modconv_module(c, g, n):
+    m = M.ModulatedConv2d(c["cin"], c["cout"], c["k"], c["style_dim"], demodulate=c.get("demodulate", True),
+                          upsample=c.get("upsample", False), downsample=c.get("downsample", False))
+    with torch.no_grad():
+        m.weight.copy_(g[n + "_weight"])
+        m.modulation.weight.copy_(g[n + "_mod_weight"])
+        m.modulation.bias.copy_(g[n + "_mod_bias"])
+    return m.to(DEV)
+
+
+def test_modulated_conv_golden_plain_up_rgb_all_grads():
+    g = load_npz("modconv")
+    for c in load_json("modconv_cases"):
+        n = c["name"]
+        m = _modconv_module(c, g, n)
+        x = cu(g[n + "_x"]).requires_grad_(True)
+        w = cu(g[n + "_w"]).requires_grad_(True)
+        y, s = m(x, w, return_style_scalars=True)
+        assert_close(y, g[n + "_y"], TOL, n + " y")
+        assert_close(s, g[n + "_s"], TIGHT, n + " s")
+        grads = torch.autograd.grad(y, [x, w, m.weight, m.modulation.weight, m.modulation.bias], cu(g[n + "_go"]))
+        for name, gr in zip(("x", "w", "weight", "mod_weight", "mod_bias"), grads):
+            assert_close(gr, g[f"{n}_g{name}"], TOL, f"{n} g{name}")
+
+
+@pytest.mark.parametrize("cfg", [  # (B, cin, cout, H, W, upsample)
+    (2, 154, 154, 16, 16, False), (2, 154, 77, 32, 32, True), (2, 77, 39, 64, 64, True), (2, 39, 39, 96, 64, False),
+    (1, 512, 512, 4, 4, False), (3, 512, 256, 8, 8, True), (2, 128, 128, 64, 64, False), (5, 20, 10, 12, 20, False),
+    (16, 154, 154, 4, 4, True)])
+def test_styled_conv_vs_oracle_forward_and_all_grads(cfg):
+    B, cin, cout, H, W, up = cfg
+    torch.manual_seed(3)
+    m = M.StyledConv(cin, cout, 3, 64, upsample=up)
+    with torch.no_grad():
+        m.noise.weight.fill_(0.3)
+        m.activate.bias.copy_(0.2 * torch.randn(cout))
+        m.conv.modulation.bias.add_(0.3 * torch.randn(cin))
+    sd = {"c." + k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(B, 64)
+    oh, ow = (2 * H, 2 * W) if up else (H, W)
+    noise = torch.randn(B, 1, oh, ow)
+    go = torch.randn(B, cout, oh, ow)
+    # oracle
+    names = ["c.conv.weight", "c.conv.modulation.weight", "c.conv.modulation.bias", "c.noise.weight", "c.activate.bias"]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr, _ = ref_model._styled_conv(sdr, "c", xr, wr, noise, up)
+    gr = torch.autograd.grad(yr, [xr, wr] + [leaves[k] for k in names], go)
+    # HIP
+    mg = m.to(DEV)
+    xg, wg = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
+    yg = mg(xg, wg, noise=cu(noise))
+    assert_close(yg, yr, TOL, "out")
+    params = dict(mg.named_parameters())
+    gg = torch.autograd.grad(yg, [xg, wg] + [params[k[2:]] for k in names], cu(go))
+    for nm, a, b in zip(["x", "style"] + names, gg, gr):
+        assert_close(a, b, TOL if b.numel() > 1 else 3e-3, f"{cfg} grad {nm}")
+
+
+@pytest.mark.parametrize("cfg", [(2, 39, 256, 256, True), (2, 154, 8, 8, True), (3, 154, 4, 4, False), (1, 7, 6, 10, False)])
+def test_torgb_vs_oracle_forward_and_all_grads(cfg):
+    B, C, H, W, has_skip = cfg
+    torch.manual_seed(4)
+    m = M.ToRGB(C, 64, upsample=has_skip)
+    with torch.no_grad():
+        m.bias.copy_(0.1 * torch.randn(1, 3, 1, 1))
+    sd = {"r." + k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, w = torch.randn(B, C, H, W), torch.randn(B, 64)
+    skip = torch.randn(B, 3, H // 2, W // 2) if has_skip else None
+    go = torch.randn(B, 3, H, W)
+    names = ["r.conv.weight", "r.conv.modulation.weight", "r.conv.modulation.bias", "r.bias"]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    sr = skip.clone().requires_grad_(True) if has_skip else None
+    yr, _ = ref_model._to_rgb(sdr, "r", xr, wr, sr)
+    ins_r = [xr, wr] + [leaves[k] for k in names] + ([sr] if has_skip else [])
+    gr = torch.autograd.grad(yr, ins_r, go)
+    mg = m.to(DEV)
+    xg, wg = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
+    sg = cu(skip).requires_grad_(True) if has_skip else None
+    yg = mg(xg, wg, sg)
+    assert_close(yg, yr, TOL, "rgb")
+    params = dict(mg.named_parameters())
+    ins_g = [xg, wg] + [params[k[2:]] for k in names] + ([sg] if has_skip else [])
+    gg = torch.autograd.grad(yg, ins_g, cu(go))
+    for nm, a, b in zip(["x", "style"] + names + ["skip"], gg, gr):
+        assert_close(a, b, TOL, f"{cfg} grad {nm}")
+
+
+def _tiny(g, meta):
+    net = M.Generator(meta["config"]["size"], meta["config"]["style_dim"], meta["config"]["n_mlp"],
+                      generator_net_shape=meta["config"]["shape"])
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    return net.to(DEV)
+
+
+def test_tiny_generator_golden_image_rgbs_styles_grads_pathlength():
+    g = load_npz("generator_tiny")
+    meta = load_json("generator_tiny_keys")
+    net = _tiny(g, meta)
+    rgbs, scal = net([cu(g["z0"])], randomize_noise=False, return_rgb_list=True, return_style_scalars=True)
+    for i, r in enumerate(rgbs):
+        assert_close(r, g[f"a_rgb{i}"], TOL, f"rgb{i}")
+    for i, s in enumerate(scal):
+        assert_close(s, g[f"a_style{i}"], TOL, f"style{i}")
+    assert_close(net([cu(g["z0"]), cu(g["z1"])], inject_index=3, randomize_noise=False), g["c_img"], TOL, "mixing")
+    assert_close(net(None, latent_styles=[cu(g["d_w0"])], input_is_latent=True, truncation=0.7,
+                     truncation_latent=cu(g["d_mean_w"]), randomize_noise=False), g["d_img"], TOL, "truncation")
+    noise = [cu(g[f"e_noise{i}"]) for i in range(meta["num_layers"])]
+    assert_close(net([cu(g["z0"])], noise=noise), g["e_img"], TOL, "noise list")
+    net.zero_grad()
+    img = net([cu(g["z0"])], randomize_noise=False)
+    assert_close(img, g["b_img"], TOL, "img")
+    img.abs().mean().backward()
+    params = dict(net.named_parameters())
+    for k, v in sub(g, "b_grad/").items():
+        gr = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
+        assert_close(gr, v, TOL if v.numel() > 1 else 5e-3, "grad " + k)
+    # second order (composed twice-differentiable ops on the GPU, HIP upfirdn2d / fused act double-backward)
+    from unittest import mock
+    net.zero_grad()
+    with mock.patch.object(torch, "randn_like", lambda t: cu(g["f_pl_noise"])):
+        _, pl = net([cu(g["z0"])], PPL_regularize=True, randomize_noise=False)
+    assert_close(pl, g["f_path_lengths"], TOL, "path lengths")
+    (pl - 0.37).pow(2).mean().backward()
+    for k, v in sub(g, "f_grad/").items():
+        gr = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
+        assert_close(gr, v, 2e-3 if v.numel() > 1 else 1e-2, "pl grad " + k)
+
+
+def test_discriminator_golden():
+    g = load_npz("discriminator32")
+    d = M.Discriminator(32)
+    d.load_state_dict(ref_model.regenerate_state_dict(load_json("discriminator32_keys"), g["seed"]), strict=True)
+    d = d.to(DEV)
+    x = cu(g["x"]).requires_grad_(True)
+    y = d(x)
+    assert_close(y, g["y"], TOL, "D out")
+    (gx,) = torch.autograd.grad(torch.nn.functional.softplus(-y).mean(), x)
+    assert_close(gx, g["gx"], TOL, "D input grad")
+
+
+def test_kd_step_golden_losses_grads_adam():
+    g = load_npz("kd_step_tiny")
+    meta = load_json("kd_step_tiny_meta")
+    student = M.Generator(32, 24, 2, generator_net_shape=meta["student_shape"])
+    student.load_state_dict(sub(g, "student_sd/"), strict=True)
+    teacher = M.Generator(32, 24, 2, generator_net_shape=meta["teacher_shape"])
+    teacher.load_state_dict(sub(g, "teacher_sd/"), strict=True)
+    disc = M.Discriminator(32)
+    disc.load_state_dict(ref_model.regenerate_state_dict(load_json("discriminator32_keys"), g["d_seed"]), strict=True)
+    student, teacher, disc = student.to(DEV), teacher.to(DEV), disc.to(DEV)
+    step = kd.KDStep(student, teacher, disc, latent=24)
+    for st in meta["steps"]:
+        p = f"step{st['step']}/"
+        nl = student.num_layers
+        zs = [cu(g[p + f"z{i}"]) for i in range(st["n_z"])]
+        losses = step.g_step(zs, st["inject_index"], cu(g["mask"]),
+                             student_noise=[cu(g[p + f"student_noise{i}"]) for i in range(nl)],
+                             teacher_noise=[cu(g[p + f"teacher_noise{i}"]) for i in range(nl)])
+        assert abs(losses["g"].item() - float(g[p + "g_loss"])) < 1e-3 * max(1.0, abs(float(g[p + "g_loss"])))
+        assert abs(losses["kd_l1_loss"].item() - float(g[p + "kd_l1_loss"])) < 1e-3 * max(1.0, abs(float(g[p + "kd_l1_loss"])))
+        params = dict(student.named_parameters())
+        for k, v in sub(g, p + "grad/").items():
+            assert_close(params[k].grad, v, TOL if v.numel() > 1 else 5e-3, f"step{st['step']} grad {k}")
+        with torch.no_grad():
+            for k, v in sub(g, p + "param_after/").items():
+                params[k].copy_(cu(v))
+
+
+def test_pruned_256_generator_vs_oracle_image_and_every_grad():
+    """The parity gate of SURVEY.md §8-d at the real student shape: fixed latents, fixed noise, bs 2."""
+    torch.manual_seed(5)
+    c = load_json("contract_256")
+    net = M.Generator(256, 512, 8, generator_net_shape=c["pruned_shape"])
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith("noise.weight"):
+                p.fill_(0.1)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    z = [torch.randn(2, 512), torch.randn(2, 512)]
+    names = [n for n, _ in net.named_parameters()]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    img_r = ref_model.generator_forward_ref(sdr, z, inject_index=5, randomize_noise=False)
+    gr = torch.autograd.grad(img_r.abs().mean(), [leaves[k] for k in names], allow_unused=True)
+    netg = net.to(DEV)
+    img_g = netg([cu(z[0]), cu(z[1])], inject_index=5, randomize_noise=False)
+    assert_close(img_g, img_r, TOL, "image")
+    img_g.abs().mean().backward()
+    params = dict(netg.named_parameters())
+    for k, b in zip(names, gr):
+        a = params[k].grad
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0
+            continue
+        assert_close(a, b, TOL if b.numel() > 1 else 5e-3, "grad " + k)
+
+
+def test_full_256_teacher_forward_vs_oracle():
+    torch.manual_seed(6)
+    net = M.Generator(256, 512, 8)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith("noise.weight"):
+                p.fill_(0.1)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    z = [torch.randn(1, 512)]
+    with torch.no_grad():
+        img_r = ref_model.generator_forward_ref(sd, z, randomize_noise=False, return_rgb_list=True)
+        img_g = net.to(DEV)([cu(z[0])], randomize_noise=False, return_rgb_list=True)
+    for i, (a, b) in enumerate(zip(img_g, img_r)):
+        assert_close(a, b, TOL, f"teacher rgb {i}")
+
+
+def test_size_independent_properties_at_full_size():
+    """bs 16 student shapes (too slow for the CPU oracle): linearity of the conv in x, batch independence."""
+    torch.manual_seed(7)
+    m = M.StyledConv(39, 39, 3, 512).to(DEV)
+    with torch.no_grad():
+        m.noise.weight.fill_(0.0)
+        m.activate.bias.zero_()
+    x = torch.randn(16, 39, 256, 256, device=DEV)
+    w = torch.randn(16, 512, device=DEV)
+    with torch.no_grad():
+        y = m(x, w)
+        # LeakyReLU is positively homogeneous and bias/noise are zero: f(2x) == 2 f(x)
+        assert_close(m(2 * x, w), 2 * y, 1e-5, "homogeneity")
+        # sample 3 alone == sample 3 within the batch
+        assert_close(m(x[3:4], w[3:4]), y[3:4], 1e-6, "batch independence")
