@@ -117,7 +117,7 @@ class _ModConv(Function):
             nb = noise.shape[0]
         with _lib.on_device(x):
             if upsample:
-                t = torch.empty(B, cout, 4, H + 1, W + 1, dtype=x.dtype, device=dev)
+                t = torch.empty(B, cout, 4, H + 1, _lib.query("cagc_phase_pitch", W), dtype=x.dtype, device=dev)
                 _lib.call("cagc_modconv_up_fwd", _lib.ptr(t), _lib.ptr(x), _lib.ptr(wp_fwd), _lib.ptr(s), B, cin, cout, H, W)
                 out = torch.empty(B, cout, 2 * H, 2 * W, dtype=x.dtype, device=dev)
                 _lib.call("cagc_blur_up_fwd", _lib.ptr(out), _lib.ptr(t), _lib.ptr(fir), _lib.ptr(d_c),
@@ -171,7 +171,7 @@ class _ModConv(Function):
                 else:
                     gz = gout
             if upsample:
-                g = torch.empty(B, cout, 4, H + 1, W + 1, dtype=x.dtype, device=dev)
+                g = torch.empty(B, cout, 4, H + 1, _lib.query("cagc_phase_pitch", W), dtype=x.dtype, device=dev)
                 _lib.call("cagc_blur_up_bwd", _lib.ptr(g), _lib.ptr(gz), _lib.ptr(fir), B, cout, H, W)
             else:
                 g = gz

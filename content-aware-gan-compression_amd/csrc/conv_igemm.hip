@@ -1,26 +1,34 @@
 // Modulated convolution as ONE implicit GEMM on the fp32 matrix cores of gfx950
-// (v_mfma_f32_16x16x4_f32: exact fp32 FMA chain, 32 cycles / instruction / SIMD).
+// (v_mfma_f32_16x16x4_f32: exact fp32 FMA chain, 32 cycles / instruction / SIMD, 157 TFLOP/s chip peak).
 //
 //   out[b, m, P(v)] = epilogue( sum_{taps t} sum_{c} Wp[t][c][m] * ( s[b,c] * in[b, c, plane_t, Q_t(v)] ) )
 //
-// A "virtual pixel" v = (vy, vx) on an Hv x Wv grid maps to the input pixel (vy*isy + dy_t, vx*isx + dx_t)
-// of input plane plane_t for tap t, and to the output pixel (vy, vx) of output plane `out_plane`.  With
-// this one formulation the kernel serves
-//   * the plain 3x3 / 1x1 modulated conv forward              (1 phase, 9 / 1 taps)
-//   * the stride-2 transposed conv forward, phase by phase    (4 phases with 4/2/2/1 taps, phase-planar out)
-//   * dgrad of the plain conv                                 (taps mirrored, Wp = wp_bwd)
-//   * dgrad of the transposed conv from phase-planar grads    (9 taps reading 4 input planes)
-// GEMM roles: M = output channels (A = packed weights [tap][K][M], shared by every sample: the per-sample
-// modulation s[b,c] is applied to the *input* tile while it is staged into LDS, the demodulation d[b,m]
-// in the epilogue), N = pixels, K = input channels x taps.
+// A "virtual pixel" v = (vy, vx) maps to the input pixel (vy*isy + dy_t, vx*isx + dx_t) of input plane plane_t
+// for tap t and to the output pixel (vy, vx) of output plane `out_plane`.  One kernel therefore serves
+//   * the plain 3x3 / 1x1 modulated conv forward              (1 work item, 9 / 1 taps)
+//   * the stride-2 transposed conv forward by output parity   (4 phases with 4/2/2/1 taps, phase-planar output;
+//                                                              each phase split into an exact H x W main region
+//                                                              plus a 1-pixel bottom row / right column so that
+//                                                              the odd (H+1) x (W+1) phase grid wastes no tiles)
+//   * dgrad of the plain conv                                  (mirrored taps, Wp = wp_bwd)
+//   * dgrad of the transposed conv from phase-planar grads     (9 taps reading 4 input planes)
+// GEMM roles: M = output channels (A = packed weights [tap][K][M], shared by all samples: the per-sample
+// modulation s[b,c] is applied to the *input* tile while it is staged into LDS, the demodulation d[b,m] in the
+// epilogue), N = pixels, K = input channels x taps.
 //
-// Workgroup = 256 threads = 4 wavefronts; tile = (MB*16 channels) x (N_T = 4*NBW*16 pixels).  Every
-// wavefront owns all MB channel blocks for its NBW pixel blocks -> MB*NBW accumulators of 4 VGPRs.
-// Per K-chunk of CK channels: input halo tile [CK][planes][imgs][IH][IW] and weight slab [taps][CK][M_T]
-// are staged in LDS (plane stride == 16 mod 32 and LDA == 16 mod 32 so that the two 16-lane groups of a
-// ds_read_b32 half hit disjoint banks), then taps x CK/4 MFMA steps run out of LDS.
+// Workgroup = 256 threads = 4 wavefronts; tile = (MB*16 channels) x (256 pixels); every wavefront owns all MB
+// channel blocks for its 4 pixel blocks -> MB*4 accumulators of 4 AGPRs.  K runs in chunks of CK = 8 channels:
+//   - the input halo tile [CK][planes][imgs][IH][IWp] and the weight slab [taps][CK][M_T] of chunk k+1 are
+//     fetched from HBM/L2 into REGISTERS (16-byte loads on 16-byte aligned row segments) while the MFMAs of
+//     chunk k run out of LDS, and written to LDS after the barrier (issue-early / write-late);
+//   - LDS strides are chosen so the two 16-lane groups of a ds_read_b32 half-wave hit disjoint banks
+//     (channel-plane stride == 16 mod 32, LDA == 16 mod 32);
+//   - tap tables live in SGPRs (uniform loads), the tap loop is fully unrolled.
+// Layers with too few pixel tiles to fill 256 CUs (4x4 .. 16x16) are split over K (channels) across
+// workgroups; partial sums are combined with fp32 atomics and the non-linear epilogue runs as a separate pass.
 #include "common.h"
 #include <string.h>
+#include <type_traits>
 
 namespace cagc {
 
@@ -28,15 +36,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CONV_CK = 8;
 constexpr int MAX_TAPS = 9;
-constexpr int MAX_ROWS = 4096;  // staged input rows per chunk (table in LDS)
+constexpr int MAX_ITEMS = 12;
+constexpr int NBW = 4;                 // pixel blocks (of 16) per wavefront
+constexpr int CONV_NT = 4 * NBW * 16;  // 256 pixels per workgroup tile
 
 struct ConvTap {
-  int lds_off;  // float offset inside one channel's LDS plane: plane*(IPB*IH*IWp) + (dy-min_dy)*IWp + (dx-min_dx)
+  int lds_off;  // float offset inside one channel's LDS plane
   int widx;     // tap index into the packed weights
 };
-struct ConvPhase {
-  int ntaps;
-  int out_plane;
+struct ConvItem {
+  int ntaps, out_plane;
+  int vy_base, vx_base, Hv, Wv;  // region of virtual pixels [vy_base, vy_base+Hv) x [vx_base, vx_base+Wv)
+  int TH, TW, IPB, tiles_x, tiles_y;
+  int IH, IWp, Q4, PS, rows;     // LDS tile: rows per (c,plane,img), padded row (floats), float4 per row,
+                                 // channel-plane stride, rows per chunk (= CK*NPin*IPB*IH)
+  int xoff;                      // LDS column of the tile's first needed input column (alignment slack)
+  int block_end;                 // cumulative workgroup count (exclusive) along grid.x
   ConvTap taps[MAX_TAPS];
 };
 struct ConvArgs {
@@ -49,72 +64,104 @@ struct ConvArgs {
   const float* noise_w;
   const float* bias;
   const float* aux_x;  // dgrad: x at the output positions, for the gs reduction
-  float* gs;           // [B,Cout-of-this-GEMM] accumulated
+  float* gs;           // [B,Cout-of-this-GEMM], accumulated
   int B, Cin, Kp, Cout, Mp;
-  int NPin, Hin, Win;
-  int Hv, Wv, isy, isx;
-  int NPout, Hout, Wout;
-  int TH, TW, IPB, tiles_x, tiles_y;
-  int IH, IW, IWp, PS, rows;  // rows = CK*NPin*IPB*IH
+  int NPin, Hin, Win, Wpitch;  // input planes per channel, valid plane dims, row pitch (floats)
+  int isy, isx;
+  int NPout, Hout, Wout, Wopitch;
   int min_dy, min_dx;
-  int nphase;
+  int nitems, ksplit, vec;     // vec: 16-byte staging loads are legal (Wpitch % 4 == 0)
   int epi, noise_bstride_on;
   float alpha, act_scale;
-  ConvPhase phase[4];
+  ConvItem items[MAX_ITEMS];
 };
 
-template <int MB, int NBW>
-__global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs A) {
+// NV = max float4 (vec) / float (scalar) input elements staged per thread per chunk
+template <int MB, int NV, bool VEC>
+__global__ __launch_bounds__(256, (NV <= 4 ? 2 : 1)) void k_conv_igemm(const ConvArgs A) {
   constexpr int CK = CONV_CK;
   constexpr int MT = MB * 16;
   constexpr int LDA = (MT % 32 == 0) ? MT + 16 : MT;
+  constexpr int Q4M = MT / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* a_lds = smem;                                    // [MAX_TAPS*CK][LDA]
-  float* b_lds = smem + MAX_TAPS * CK * LDA;              // [CK][PS]
-  int* tab = reinterpret_cast<int*>(b_lds + CK * A.PS);   // [rows][3]: goff, lds_off, meta
+  float* a_lds = smem;                        // [MAX_TAPS*CK][LDA]
+  float* b_lds = smem + MAX_TAPS * CK * LDA;  // [CK][PS]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
 
-  // ---- block -> tile -------------------------------------------------------------------------
-  int bid = blockIdx.x;
-  const int tx_i = bid % A.tiles_x;
-  bid /= A.tiles_x;
-  const int ty_i = bid % A.tiles_y;
-  const int ig = bid / A.tiles_y;
-  const int b0 = ig * A.IPB;
-  const int vx0 = tx_i * A.TW, vy0 = ty_i * A.TH;
+  // ---- workgroup -> (item, image group, tile) : uniform -------------------------------------------
+  int item = 0;
+  while (item < A.nitems - 1 && (int)blockIdx.x >= A.items[item].block_end) ++item;
+  const ConvItem& I = A.items[item];
+  int bid = blockIdx.x - (item ? A.items[item - 1].block_end : 0);
+  const int tx_i = bid % I.tiles_x;
+  bid /= I.tiles_x;
+  const int ty_i = bid % I.tiles_y;
+  const int b0 = (bid / I.tiles_y) * I.IPB;
+  const int TH = I.TH, TW = I.TW, IPB = I.IPB, IH = I.IH, IWp = I.IWp, PS = I.PS;
+  const int vx0 = I.vx_base + tx_i * TW, vy0 = I.vy_base + ty_i * TH;
+  const int vx_end = I.vx_base + I.Wv, vy_end = I.vy_base + I.Hv;
   const int m0 = blockIdx.y * MT;
-  const ConvPhase& P = A.phase[blockIdx.z];
-  const int ix0 = vx0 * A.isx + A.min_dx, iy0 = vy0 * A.isy + A.min_dy;
-  const int HWin = A.Hin * A.Win;
+  const int ntaps = I.ntaps;
+  int widx[MAX_TAPS];
+#pragma unroll
+  for (int t = 0; t < MAX_TAPS; ++t) widx[t] = I.taps[t].widx;
+  // first needed input column / row, and the 16-byte aligned column the LDS row starts at
+  const int gx_lo = vx0 * A.isx + A.min_dx;
+  const int gx_al = VEC ? (gx_lo - I.xoff) : gx_lo;
+  const int iy0 = vy0 * A.isy + A.min_dy;
+  const int HWp = A.Hin * A.Wpitch;
+  const int chan_stride = A.NPin * HWp;
 
-  // ---- per-block row table for the input staging ------------------------------------------------
-  for (int r = tid; r < A.rows; r += 256) {
-    int q = r;
-    const int iy = q % A.IH; q /= A.IH;
-    const int img = q % A.IPB; q /= A.IPB;
-    const int pl = q % A.NPin;
-    const int c = q / A.NPin;
-    const int gy = iy0 + iy;
-    const int b = b0 + img;
-    const bool ok = (gy >= 0) && (gy < A.Hin) && (b < A.B);
-    tab[3 * r + 0] = ((b * A.Cin + c) * A.NPin + pl) * HWin + gy * A.Win;
-    tab[3 * r + 1] = c * A.PS + ((pl * A.IPB + img) * A.IH + iy) * A.IWp;
-    tab[3 * r + 2] = (ok ? 1 : 0) | (c << 1) | (img << 8);
+  // ---- K range of this split --------------------------------------------------------------------------
+  const int nchunks = (A.Kp + CK - 1) / CK;
+  const int cps = (nchunks + A.ksplit - 1) / A.ksplit;
+  const int kc_lo = blockIdx.z * cps * CK;
+  int kc_hi = kc_lo + cps * CK;
+  if (kc_hi > nchunks * CK) kc_hi = nchunks * CK;
+
+  // ---- per-thread staging descriptors (computed once) -----------------------------------------------------
+  // element e = tid + 256*i  ->  (row r, column unit q);  row r -> (c, plane, img, iy)
+  int e_goff[NV], e_loff[NV], e_meta[NV];  // meta: bit0 valid, bits 1..7 c, bits 8.. img
+  {
+    const int upr = VEC ? I.Q4 : IWp;      // units per row
+    const int total = I.rows * upr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = tid + 256 * i;
+      int goff = 0, loff = 0, meta = 0;
+      if (e < total) {
+        const int r = e / upr, q = e - r * upr;
+        int t2 = r;
+        const int iy = t2 % IH; t2 /= IH;
+        const int img = t2 % IPB; t2 /= IPB;
+        const int pl = t2 % A.NPin;
+        const int c = t2 / A.NPin;
+        const int gy = iy0 + iy, b = b0 + img;
+        const int gx = gx_al + (VEC ? 4 * q : q);
+        bool ok = (gy >= 0) && (gy < A.Hin) && (b < A.B);
+        if (VEC) ok = ok && (gx >= 0) && (gx + 4 <= A.Wpitch);
+        else ok = ok && (gx >= 0) && (gx < A.Win);
+        goff = ((b * A.Cin + c) * A.NPin + pl) * HWp + gy * A.Wpitch + gx;
+        loff = c * PS + ((pl * IPB + img) * IH + iy) * IWp + (VEC ? 4 * q : q);
+        meta = (ok ? 1 : 0) | (c << 1) | (img << 8) | 0x40000000;  // bit30: element exists (must be written)
+      }
+      e_goff[i] = goff; e_loff[i] = loff; e_meta[i] = meta;
+    }
   }
 
-  // ---- per-lane pixel decode (one per owned n-block) ---------------------------------------------
+  // ---- per-lane pixel decode (one per owned n-block) ----------------------------------------------------
   int lb[NBW];
-  const int THW = A.TH * A.TW;
+  const int THW = TH * TW;
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
     const int n = (wave * NBW + j) * 16 + lm;
     const int img = n / THW;
     const int rem = n - img * THW;
-    const int ty = rem / A.TW, tx = rem - ty * A.TW;
-    lb[j] = (img * A.IH + ty * A.isy) * A.IWp + tx * A.isx;
+    const int ty = rem / TW, tx = rem - ty * TW;
+    lb[j] = (img * IH + ty * A.isy) * IWp + tx * A.isx + (VEC ? I.xoff : 0);
   }
 
   f32x4 acc[MB][NBW];
@@ -123,47 +170,70 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs A) {
 #pragma unroll
     for (int j = 0; j < NBW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // staging geometry
-  int RW = 1;
-  while (RW < A.IW && RW < 64) RW <<= 1;
-  const int rx = tid & (RW - 1), ry = tid / RW, rstep = 256 / RW;
-  const int chan_stride = A.NPin * HWin;
-  const int ntaps = P.ntaps;
+  // ---- register prefetch buffers -------------------------------------------------------------------------
+  typedef typename std::conditional<VEC, float4, float>::type in_t;
+  in_t rin[NV];
+  float rsc[NV];
+  float4 rw[MAX_TAPS];
+  const int wq = tid;  // one float4 of the weight slab per tap per thread (CK*Q4M <= 256 for MB <= 8)
+  const int wc = wq / Q4M, wcol = (wq - wc * Q4M) * 4;
+  const bool w_thread = (wq < CK * Q4M) && (m0 + wcol < A.Mp);
 
-  for (int kc = 0; kc < A.Kp; kc += CK) {
-    __syncthreads();  // previous chunk's MFMA reads done (also publishes `tab` on the first pass)
-    // ---- input tile -------------------------------------------------------------------------------
-    for (int r = ry; r < A.rows; r += rstep) {
-      const int goff = tab[3 * r + 0], loff = tab[3 * r + 1], meta = tab[3 * r + 2];
-      const int c = (meta >> 1) & 127, img = meta >> 8;
-      const bool rok = (meta & 1) && (kc + c < A.Cin);
-      float sc = 1.f;
-      if (rok && A.in_scale) sc = A.in_scale[(b0 + img) * A.Cin + kc + c];
-      const float* src = A.in + (int64_t)goff + (int64_t)kc * chan_stride;
-      for (int ix = rx; ix < A.IW; ix += RW) {
-        const int gx = ix0 + ix;
-        float v = 0.f;
-        if (rok && gx >= 0 && gx < A.Win) v = src[gx] * sc;
-        b_lds[loff + ix] = v;
+  auto prefetch = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int meta = e_meta[i];
+      const int c = (meta >> 1) & 127;
+      const bool ok = (meta & 1) && (kc + c < A.Cin);
+      if (VEC) rin[i] = in_t{};
+      else rin[i] = in_t{};
+      rsc[i] = 1.f;
+      if (ok) {
+        const float* src = A.in + (int64_t)e_goff[i] + (int64_t)kc * chan_stride;
+        if (VEC) rin[i] = *reinterpret_cast<const in_t*>(src);
+        else rin[i] = *reinterpret_cast<const in_t*>(src);
+        if (A.in_scale) rsc[i] = A.in_scale[(b0 + ((meta >> 8) & 0x3fffff)) * A.Cin + kc + c];
       }
     }
-    // ---- weight slab ------------------------------------------------------------------------------
-    {
-      constexpr int Q4 = MT / 4;
-      const int total = ntaps * CK * Q4;
-      for (int q = tid; q < total; q += 256) {
-        const int row = q / Q4, col = (q - row * Q4) * 4;
-        const int t = row / CK, c = row - t * CK;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kc + c < A.Kp && m0 + col < A.Mp)
-          v = *reinterpret_cast<const float4*>(A.wp + ((int64_t)P.taps[t].widx * A.Kp + kc + c) * A.Mp + m0 + col);
-        *reinterpret_cast<float4*>(a_lds + row * LDA + col) = v;
+#pragma unroll
+    for (int t = 0; t < MAX_TAPS; ++t) {
+      rw[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < ntaps && w_thread && kc + wc < A.Kp)
+        rw[t] = *reinterpret_cast<const float4*>(A.wp + ((int64_t)widx[t] * A.Kp + kc + wc) * A.Mp + m0 + wcol);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (e_meta[i] & 0x40000000) {
+        if constexpr (VEC) {
+          float4 v = rin[i];
+          const float s = rsc[i];
+          v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+          *reinterpret_cast<float4*>(b_lds + e_loff[i]) = v;
+        } else {
+          b_lds[e_loff[i]] = rin[i] * rsc[i];
+        }
       }
     }
+    if (wq < CK * Q4M) {
+#pragma unroll
+      for (int t = 0; t < MAX_TAPS; ++t)
+        if (t < ntaps) *reinterpret_cast<float4*>(a_lds + (t * CK + wc) * LDA + wcol) = rw[t];
+    }
+  };
+
+  if (kc_lo < kc_hi) prefetch(kc_lo);
+  for (int kc = kc_lo; kc < kc_hi; kc += CK) {
+    __syncthreads();  // MFMA reads of the previous chunk are done
+    commit();
     __syncthreads();
-    // ---- MFMA ---------------------------------------------------------------------------------------
+    if (kc + CK < kc_hi) prefetch(kc + CK);  // in flight during the MFMAs below
+    // runtime tap loop (the tap's LDS offset is a scalar kernarg load): keeps address VGPRs at 8 + MB instead
+    // of letting the compiler hoist one address per (tap, step, block) out of the K loop
+#pragma unroll 1
     for (int t = 0; t < ntaps; ++t) {
-      const int toff = P.taps[t].lds_off;
+      const int to = I.taps[t].lds_off;
 #pragma unroll
       for (int s = 0; s < CK / 4; ++s) {
         const int kk = 4 * s + g;
@@ -171,55 +241,77 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs A) {
 #pragma unroll
         for (int i = 0; i < MB; ++i) av[i] = a_lds[(t * CK + kk) * LDA + i * 16 + lm];
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) bv[j] = b_lds[kk * A.PS + lb[j] + toff];
+        for (int j = 0; j < NBW; ++j) bv[j] = b_lds[kk * PS + lb[j] + to];
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
-          for (int j = 0; j < NBW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NBW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
       }
     }
   }
 
-  // ---- epilogue: lane holds channels m0 + i*16 + 4g + r (r = 0..3) of pixel n ----------------------
-  const int HWout = A.Hout * A.Wout;
-  const float nw = (A.epi == CAGC_EPI_STYLED && A.noise) ? A.noise_w[0] : 0.f;
+  // ---- epilogue: lane holds channels m0 + i*16 + 4g + r (r = 0..3) of pixel n ------------------------------
+  const int HWo = A.Hout * A.Wopitch;
+  const bool styled = (A.epi == CAGC_EPI_STYLED) && (A.ksplit == 1);
+  const bool atomic_out = A.ksplit > 1;
+  const float nw = (styled && A.noise) ? A.noise_w[0] : 0.f;
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
     const int n = (wave * NBW + j) * 16 + lm;
     const int img = n / THW;
     const int rem = n - img * THW;
-    const int ty = rem / A.TW, tx = rem - ty * A.TW;
+    const int ty = rem / TW, tx = rem - ty * TW;
     const int vy = vy0 + ty, vx = vx0 + tx, b = b0 + img;
-    const bool pok = (vy < A.Hv) && (vx < A.Wv) && (b < A.B) && (img < A.IPB);
-    const int pix = vy * A.Wout + vx;
+    const bool pok = (vy < vy_end) && (vx < vx_end) && (b < A.B) && (img < IPB);
+    const int pix = vy * A.Wopitch + vx;
     float nz = 0.f;
-    if (A.epi == CAGC_EPI_STYLED && A.noise && pok) nz = nw * A.noise[(A.noise_bstride_on ? (int64_t)b * HWout : 0) + pix];
+    if (styled && A.noise && pok) nz = nw * A.noise[(A.noise_bstride_on ? (int64_t)b * A.Hout * A.Wout : 0) + vy * A.Wout + vx];
+    const int bl = __shfl(b, lane & 48, 64);  // (b, m) is shared by the 16 lanes of a group when THW >= 16
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
+      const f32x4 a4 = acc[i][j];
+      const float vals[4] = {a4[0], a4[1], a4[2], a4[3]};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + i * 16 + 4 * g + r;
         const bool ok = pok && (m < A.Cout);
-        float v = acc[i][j][r];
+        float v = vals[r];
+        const int64_t oidx = ((int64_t)(b * A.Cout + m) * A.NPout + I.out_plane) * HWo + pix;
         if (A.gs) {  // dgrad: reduce (unscaled dgrad) * x over this 16-pixel group
           float xv = 0.f;
-          if (ok) xv = A.aux_x[((int64_t)(b * A.Cout + m) * A.NPout + P.out_plane) * HWout + pix];
+          if (ok) xv = A.aux_x[oidx];
           const float part = group16_sum(ok ? v * xv : 0.f);
-          // all 16 lanes of the group share (b, m) when THW >= 16 (an n-block never straddles images)
-          const int bl = __shfl(b, lane & 48, 64);
           if (lm == 0 && m < A.Cout && bl < A.B && part != 0.f) atomicAdd(A.gs + (int64_t)bl * A.Cout + m, part);
         }
         if (ok) {
-          if (A.out_scale) v *= A.out_scale[b * A.Cout + m];
-          if (A.epi == CAGC_EPI_STYLED) {
+          if (A.out_scale && !(A.epi == CAGC_EPI_STYLED && atomic_out)) v *= A.out_scale[b * A.Cout + m];
+          if (styled) {
             v += nz + A.bias[m];
             v = (v > 0.f ? v : v * A.alpha) * A.act_scale;
           }
-          A.out[((int64_t)(b * A.Cout + m) * A.NPout + P.out_plane) * HWout + pix] = v;
+          if (atomic_out) atomicAdd(A.out + oidx, v);
+          else A.out[oidx] = v;
         }
       }
     }
   }
+}
+
+// deferred styled epilogue for the split-K path: out = lrelu(out*d + nw*noise + bias) * act_scale, in place
+__global__ __launch_bounds__(256) void k_styled_epilogue(float* __restrict__ out, const float* __restrict__ d,
+                                                         const float* __restrict__ noise, int noise_bstride_on,
+                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                         int C, int HW, int64_t total, float alpha, float act_scale) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int p = (int)(idx % HW);
+  const int64_t plane = idx / HW;
+  const int c = (int)(plane % C);
+  const int b = (int)(plane / C);
+  float v = out[idx] * d[plane] + bias[c];
+  if (noise) v += noise_w[0] * noise[(noise_bstride_on ? (int64_t)b * HW : 0) + p];
+  out[idx] = (v > 0.f ? v : v * alpha) * act_scale;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -227,8 +319,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs A) {
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_weights(float* __restrict__ wp, const float* __restrict__ w, int Cout,
                                                       int Cin, int kk, int Kp, int Mp, float scale, int transpose) {
-  // dest index = (t*Kp + k)*Mp + m
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // dest index = (t*Kp + k)*Mp + m
   const int64_t total = (int64_t)kk * Kp * Mp;
   if (idx >= total) return;
   const int m = (int)(idx % Mp);
@@ -253,30 +344,51 @@ __global__ __launch_bounds__(256) void k_wsq(float* __restrict__ wsq, const floa
 // host side
 // -------------------------------------------------------------------------------------------------
 static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static int floor4(int v) { return (v >= 0) ? (v & ~3) : -(((-v) + 3) & ~3); }
 
-template <int MB, int NBW>
-static int launch_conv(ConvArgs& a, hipStream_t st, const char* what) {
-  constexpr int MT = MB * 16;
-  constexpr int LDA = (MT % 32 == 0) ? MT + 16 : MT;
-  const size_t smem = sizeof(float) * ((size_t)MAX_TAPS * CONV_CK * LDA + (size_t)CONV_CK * a.PS) + sizeof(int) * 3 * a.rows;
-  CAGC_REQUIRE(smem <= 160 * 1024, "%s: LDS tile %zu B too large", what, smem);
+struct RawTap { int plane, dy, dx, widx; };
+struct RawItem { int ntaps; const RawTap* taps; int out_plane, vy_base, vx_base, Hv, Wv; };
+
+template <int MB, int NV, bool VEC>
+static int launch_conv(ConvArgs& a, size_t smem, dim3 grid, hipStream_t st, const char* what) {
   static bool attr_set[64] = {};  // per device (one process normally drives one GPU)
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<MB, NBW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<MB, NV, VEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = true;
   }
-  const int groups = cdiv(a.B, a.IPB);
-  const int64_t gx = (int64_t)groups * a.tiles_x * a.tiles_y;
-  CAGC_REQUIRE(gx < (1ll << 31), "%s: grid too large", what);
-  dim3 grid((unsigned)gx, cdiv(a.Mp, MT), a.nphase);
-  hipLaunchKernelGGL((k_conv_igemm<MB, NBW>), grid, dim3(256), smem, st, a);
+  hipLaunchKernelGGL((k_conv_igemm<MB, NV, VEC>), grid, dim3(256), smem, st, a);
   return check_launch(what);
 }
 
-static int dispatch_conv(ConvArgs& a, hipStream_t st, const char* what) {
+template <int MB>
+static int launch_conv_nv(ConvArgs& a, int nv, size_t smem, dim3 grid, hipStream_t st, const char* what) {
+  if (a.vec) {
+    if (nv <= 4) return launch_conv<MB, 4, true>(a, smem, grid, st, what);
+    if (nv <= 12) return launch_conv<MB, 12, true>(a, smem, grid, st, what);
+  } else {
+    if (nv <= 12) return launch_conv<MB, 12, false>(a, smem, grid, st, what);
+    if (nv <= 48) return launch_conv<MB, 48, false>(a, smem, grid, st, what);
+  }
+  set_error("%s: staging tile too large (%d elements per thread)", what, nv);
+  return CAGC_ERR_UNSUPPORTED;
+}
+
+// Fill tile geometry for every work item and launch.
+static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, const char* what) {
+  CAGC_REQUIRE(nitems <= MAX_ITEMS, "%s: too many work items", what);
+  int min_dy = 1 << 20, max_dy = -(1 << 20), min_dx = 1 << 20, max_dx = -(1 << 20);
+  for (int p = 0; p < nitems; ++p)
+    for (int t = 0; t < raw[p].ntaps; ++t) {
+      const RawTap& tp = raw[p].taps[t];
+      min_dy = tp.dy < min_dy ? tp.dy : min_dy; max_dy = tp.dy > max_dy ? tp.dy : max_dy;
+      min_dx = tp.dx < min_dx ? tp.dx : min_dx; max_dx = tp.dx > max_dx ? tp.dx : max_dx;
+    }
+  a.min_dy = min_dy; a.min_dx = min_dx;
+  a.nitems = nitems;
+  a.vec = (a.Wpitch % 4 == 0) && (((uintptr_t)a.in) % 16 == 0) ? 1 : 0;
   const int nblk = a.Mp / 16;
   int mb;
   if (nblk <= 5) mb = nblk;
@@ -285,63 +397,110 @@ static int dispatch_conv(ConvArgs& a, hipStream_t st, const char* what) {
   else if (nblk % 4 == 0) mb = 4;
   else if (nblk % 3 == 0) mb = 3;
   else mb = 4;
-  switch (mb) {
-    case 1: return launch_conv<1, 4>(a, st, what);
-    case 2: return launch_conv<2, 4>(a, st, what);
-    case 3: return launch_conv<3, 4>(a, st, what);
-    case 4: return launch_conv<4, 4>(a, st, what);
-    case 5: return launch_conv<5, 4>(a, st, what);
-    default: return launch_conv<8, 4>(a, st, what);
+  const int MT = mb * 16;
+  const int LDA = (MT % 32 == 0) ? MT + 16 : MT;
+  int max_ps = 0, max_units = 0, blocks = 0;
+  for (int p = 0; p < nitems; ++p) {
+    ConvItem& I = a.items[p];
+    const RawItem& R = raw[p];
+    I.ntaps = R.ntaps; I.out_plane = R.out_plane;
+    I.vy_base = R.vy_base; I.vx_base = R.vx_base; I.Hv = R.Hv; I.Wv = R.Wv;
+    I.TW = pow2ceil(R.Wv) < 32 ? pow2ceil(R.Wv) : 32;
+    if (I.TW < 4) I.TW = 4;  // 1-pixel-wide strips: keep the halo tile short (rows cost a 16-byte unit each)
+    int th = pow2ceil(R.Hv);
+    if (th > CONV_NT / I.TW) th = CONV_NT / I.TW;
+    I.TH = th;
+    I.IPB = CONV_NT / (I.TW * I.TH);
+    if (I.IPB > pow2ceil(a.B)) I.IPB = pow2ceil(a.B);
+    I.tiles_x = cdiv(R.Wv, I.TW);
+    I.tiles_y = cdiv(R.Hv, I.TH);
+    I.IH = (I.TH - 1) * a.isy + (max_dy - min_dy) + 1;
+    const int IW = (I.TW - 1) * a.isx + (max_dx - min_dx) + 1;
+    if (a.vec) {
+      // tile origins are multiples of TW*isx relative to vx_base; the slack to the 16-byte boundary is the same
+      // for every tile iff (TW*isx) % 4 == 0, else fall back to the worst case by forcing scalar staging
+      const int gx_lo0 = R.vx_base * a.isx + min_dx;
+      if ((I.TW * a.isx) % 4 != 0 && I.tiles_x > 1) a.vec = 0;
+      I.xoff = gx_lo0 - floor4(gx_lo0);
+      I.IWp = round_up(I.xoff + IW, 4);
+    }
   }
+  for (int p = 0; p < nitems; ++p) {  // second pass: a.vec is final now
+    ConvItem& I = a.items[p];
+    const RawItem& R = raw[p];
+    const int IW = (I.TW - 1) * a.isx + (max_dx - min_dx) + 1;
+    if (!a.vec) { I.xoff = 0; I.IWp = IW; }
+    I.Q4 = I.IWp / 4;
+    // multi-image tiles of multi-plane inputs can exceed the per-thread staging budget: take fewer images per
+    // tile (lanes of the dropped images are masked)
+    while (I.IPB > 1 && CONV_CK * a.NPin * I.IPB * I.IH * (a.vec ? I.Q4 : I.IWp) > (a.vec ? 12 : 48) * 256) I.IPB /= 2;
+    int ps = a.NPin * I.IPB * I.IH * I.IWp;
+    ps = ps + ((16 - (ps % 32)) + 32) % 32;  // == 16 (mod 32)
+    I.PS = ps;
+    I.rows = CONV_CK * a.NPin * I.IPB * I.IH;
+    const int units = I.rows * (a.vec ? I.Q4 : I.IWp);
+    max_ps = ps > max_ps ? ps : max_ps;
+    max_units = units > max_units ? units : max_units;
+    for (int t = 0; t < R.ntaps; ++t) {
+      I.taps[t].lds_off = R.taps[t].plane * (I.IPB * I.IH * I.IWp) + (R.taps[t].dy - min_dy) * I.IWp + (R.taps[t].dx - min_dx);
+      I.taps[t].widx = R.taps[t].widx;
+    }
+    blocks += cdiv(a.B, I.IPB) * I.tiles_x * I.tiles_y;
+    I.block_end = blocks;
+  }
+  const int64_t in_elems = (int64_t)a.B * a.Cin * a.NPin * a.Hin * a.Wpitch;
+  CAGC_REQUIRE(in_elems < (1ll << 31), "%s: input tensor too large for 32-bit offsets", what);
+  // split-K when the pixel/channel tiling cannot fill the chip
+  const int mtiles = cdiv(a.Mp, MT);
+  const int nchunks = cdiv(a.Kp, CONV_CK);
+  int ks = 1;
+  if (blocks * mtiles < 256 && nchunks >= 4) {
+    ks = cdiv(512, blocks * mtiles);
+    if (ks > nchunks / 2) ks = nchunks / 2;
+    if (ks < 1) ks = 1;
+  }
+  a.ksplit = ks;
+  const size_t smem = sizeof(float) * ((size_t)MAX_TAPS * CONV_CK * LDA + (size_t)CONV_CK * max_ps);
+  CAGC_REQUIRE(smem <= 160 * 1024, "%s: LDS tile %zu B too large", what, smem);
+  const int nv = cdiv(max_units, 256);
+  if (ks > 1) {
+    const size_t bytes = sizeof(float) * (size_t)a.B * a.Cout * a.NPout * a.Hout * a.Wopitch;
+    if (hipMemsetAsync(a.out, 0, bytes, st) != hipSuccess) { set_error("%s: memset failed", what); return CAGC_ERR_LAUNCH; }
+  }
+  dim3 grid((unsigned)blocks, mtiles, ks);
+  int rc;
+  switch (mb) {
+    case 1: rc = launch_conv_nv<1>(a, nv, smem, grid, st, what); break;
+    case 2: rc = launch_conv_nv<2>(a, nv, smem, grid, st, what); break;
+    case 3: rc = launch_conv_nv<3>(a, nv, smem, grid, st, what); break;
+    case 4: rc = launch_conv_nv<4>(a, nv, smem, grid, st, what); break;
+    case 5: rc = launch_conv_nv<5>(a, nv, smem, grid, st, what); break;
+    default: rc = launch_conv_nv<8>(a, nv, smem, grid, st, what); break;
+  }
+  if (rc) return rc;
+  if (ks > 1 && a.epi == CAGC_EPI_STYLED) {
+    const int HW = a.Hout * a.Wout;
+    const int64_t total = (int64_t)a.B * a.Cout * HW;
+    hipLaunchKernelGGL(k_styled_epilogue, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, a.out, a.out_scale, a.noise,
+                       a.noise_bstride_on, a.noise_w, a.bias, a.Cout, HW, total, a.alpha, a.act_scale);
+    rc = check_launch(what);
+  }
+  return rc;
 }
 
-// Fill tile geometry from the virtual grid, strides and the taps' (dy,dx) ranges.
-struct RawTap { int plane, dy, dx, widx; };
-static int finish_geometry(ConvArgs& a, const RawTap* taps[4], const int ntaps[4], const int out_plane[4], const char* what) {
-  constexpr int NT = 256;  // 4 waves * NBW(4) * 16
-  int min_dy = 1 << 20, max_dy = -(1 << 20), min_dx = 1 << 20, max_dx = -(1 << 20);
-  for (int p = 0; p < a.nphase; ++p)
-    for (int t = 0; t < ntaps[p]; ++t) {
-      min_dy = taps[p][t].dy < min_dy ? taps[p][t].dy : min_dy;
-      max_dy = taps[p][t].dy > max_dy ? taps[p][t].dy : max_dy;
-      min_dx = taps[p][t].dx < min_dx ? taps[p][t].dx : min_dx;
-      max_dx = taps[p][t].dx > max_dx ? taps[p][t].dx : max_dx;
-    }
-  a.min_dy = min_dy;
-  a.min_dx = min_dx;
-  a.TW = pow2ceil(a.Wv) < 32 ? pow2ceil(a.Wv) : 32;
-  int th = pow2ceil(a.Hv);
-  if (th > NT / a.TW) th = NT / a.TW;
-  a.TH = th;
-  a.IPB = NT / (a.TW * a.TH);
-  if (a.IPB > a.B) a.IPB = pow2ceil(a.B);  // never more images than exist (keeps the LDS tile small)
-  a.tiles_x = cdiv(a.Wv, a.TW);
-  a.tiles_y = cdiv(a.Hv, a.TH);
-  a.IH = (a.TH - 1) * a.isy + (max_dy - min_dy) + 1;
-  a.IW = (a.TW - 1) * a.isx + (max_dx - min_dx) + 1;
-  a.IWp = a.IW;
-  int ps = a.NPin * a.IPB * a.IH * a.IWp;
-  ps = ps + ((16 - (ps % 32)) + 32) % 32;  // == 16 (mod 32)
-  a.PS = ps;
-  a.rows = CONV_CK * a.NPin * a.IPB * a.IH;
-  CAGC_REQUIRE(a.rows <= MAX_ROWS, "%s: staging table too large (%d rows)", what, a.rows);
-  for (int p = 0; p < a.nphase; ++p) {
-    a.phase[p].ntaps = ntaps[p];
-    a.phase[p].out_plane = out_plane[p];
-    for (int t = 0; t < ntaps[p]; ++t) {
-      a.phase[p].taps[t].lds_off =
-          taps[p][t].plane * (a.IPB * a.IH * a.IWp) + (taps[p][t].dy - min_dy) * a.IWp + (taps[p][t].dx - min_dx);
-      a.phase[p].taps[t].widx = taps[p][t].widx;
-    }
-  }
-  const int64_t in_elems = (int64_t)a.B * a.Cin * a.NPin * a.Hin * a.Win;
-  CAGC_REQUIRE(in_elems < (1ll << 31), "%s: input tensor too large for 32-bit offsets", what);
-  return CAGC_OK;
+static void base_args(ConvArgs& a, float* out, const float* in, const float* wp, int B, int K, int M) {
+  memset(&a, 0, sizeof(a));
+  a.in = in; a.out = out; a.wp = wp;
+  a.B = B; a.Cin = K; a.Kp = round_up(K, 4); a.Cout = M; a.Mp = round_up(M, 16);
+  a.NPin = 1; a.NPout = 1; a.isy = 1; a.isx = 1;
+  a.alpha = 0.2f; a.act_scale = 1.f;
 }
 
 }  // namespace cagc
 
 using namespace cagc;
+
+extern "C" int cagc_phase_pitch(int W) { return round_up(W + 1, 4); }
 
 extern "C" int64_t cagc_modconv_packed_elems(int K, int M, int ksize) {
   return (int64_t)ksize * ksize * round_up(K, 4) * round_up(M, 16);
@@ -369,14 +528,6 @@ extern "C" int cagc_modconv_prep(float* wp_fwd, float* wp_bwd, float* wsq, const
   return check_launch("cagc_modconv_prep");
 }
 
-static void base_args(ConvArgs& a, float* out, const float* in, const float* wp, int B, int K, int M) {
-  memset(&a, 0, sizeof(a));
-  a.in = in; a.out = out; a.wp = wp;
-  a.B = B; a.Cin = K; a.Kp = round_up(K, 4); a.Cout = M; a.Mp = round_up(M, 16);
-  a.NPin = 1; a.NPout = 1; a.isy = 1; a.isx = 1; a.nphase = 1;
-  a.alpha = 0.2f; a.act_scale = 1.f;
-}
-
 extern "C" int cagc_modconv_fwd(float* out, const float* x, const float* wp, const float* s, int B, int Cin, int Cout,
                                 int H, int W, int ksize, int epi, const float* out_scale, const float* noise,
                                 int noise_batch, const float* noise_w, const float* bias, float alpha, float act_scale,
@@ -387,7 +538,7 @@ extern "C" int cagc_modconv_fwd(float* out, const float* x, const float* wp, con
   CAGC_REQUIRE(ksize == 1 || ksize == 3, "%s: ksize %d unsupported", what, ksize);
   CAGC_REQUIRE(epi == CAGC_EPI_LINEAR || epi == CAGC_EPI_STYLED, "%s: bad epilogue %d", what, epi);
   if (epi == CAGC_EPI_STYLED) {
-    CAGC_REQUIRE(bias, "%s: styled epilogue needs bias", what);
+    CAGC_REQUIRE(bias && out_scale, "%s: styled epilogue needs bias and d", what);
     CAGC_REQUIRE(!noise || (noise_w && (noise_batch == 1 || noise_batch == B)), "%s: bad noise arguments", what);
   }
   ConvArgs a;
@@ -395,17 +546,14 @@ extern "C" int cagc_modconv_fwd(float* out, const float* x, const float* wp, con
   a.in_scale = s; a.out_scale = out_scale; a.noise = noise; a.noise_w = noise_w; a.bias = bias;
   a.noise_bstride_on = (noise_batch == B) ? 1 : 0;
   a.epi = epi; a.alpha = alpha; a.act_scale = act_scale;
-  a.Hin = H; a.Win = W; a.Hv = H; a.Wv = W; a.Hout = H; a.Wout = W;
+  a.Hin = H; a.Win = W; a.Wpitch = W; a.Hout = H; a.Wout = W; a.Wopitch = W;
   RawTap taps[9];
   int n = 0;
   const int r = ksize / 2;
   for (int ky = 0; ky < ksize; ++ky)
     for (int kx = 0; kx < ksize; ++kx) taps[n++] = RawTap{0, ky - r, kx - r, ky * ksize + kx};
-  const RawTap* tp[4] = {taps, nullptr, nullptr, nullptr};
-  const int nt[4] = {n, 0, 0, 0}, op[4] = {0, 0, 0, 0};
-  int rc = finish_geometry(a, tp, nt, op, what);
-  if (rc) return rc;
-  return dispatch_conv(a, as_stream(stream), what);
+  RawItem it{n, taps, 0, 0, 0, H, W};
+  return run_conv(a, &it, 1, as_stream(stream), what);
 }
 
 extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, const float* s, int B, int Cin, int Cout,
@@ -416,24 +564,24 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   ConvArgs a;
   base_args(a, t, x, wp, B, Cin, Cout);
   a.in_scale = s;
-  a.Hin = H; a.Win = W; a.Hv = H + 1; a.Wv = W + 1; a.Hout = H + 1; a.Wout = W + 1; a.NPout = 4;
-  a.nphase = 4;
+  a.Hin = H; a.Win = W; a.Wpitch = W;
+  a.Hout = H + 1; a.Wout = W + 1; a.Wopitch = cagc_phase_pitch(W); a.NPout = 4;
   // convT[o, 2y+ky, 2x+kx] += Wsc[o,i,ky,kx] * xs[i,y,x]   (model.py:259-267)
   // phase (py,px), virtual (m,n): ky = py + 2jy, input row = m - jy
   RawTap taps[4][4];
-  int nt[4], op[4];
-  const RawTap* tp[4];
+  RawItem items[12];
+  int ni = 0;
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       const int ph = py * 2 + px;
       int n = 0;
       for (int jy = 0; jy < (py ? 1 : 2); ++jy)
         for (int jx = 0; jx < (px ? 1 : 2); ++jx) taps[ph][n++] = RawTap{0, -jy, -jx, (py + 2 * jy) * 3 + (px + 2 * jx)};
-      nt[ph] = n; op[ph] = ph; tp[ph] = taps[ph];
+      items[ni++] = RawItem{n, taps[ph], ph, 0, 0, H, W};      // exact H x W main region
+      items[ni++] = RawItem{n, taps[ph], ph, H, 0, 1, W + 1};  // bottom row m = H (incl. the corner)
+      items[ni++] = RawItem{n, taps[ph], ph, 0, W, H, 1};      // right column n = W
     }
-  int rc = finish_geometry(a, tp, nt, op, what);
-  if (rc) return rc;
-  return dispatch_conv(a, as_stream(stream), what);
+  return run_conv(a, items, ni, as_stream(stream), what);
 }
 
 extern "C" int cagc_modconv_dgrad(float* gx, float* gs, const float* gz, const float* wp, const float* s, const float* x,
@@ -446,18 +594,15 @@ extern "C" int cagc_modconv_dgrad(float* gx, float* gs, const float* gz, const f
   ConvArgs a;
   base_args(a, gx, gz, wp, B, /*K=*/Cout, /*M=*/Cin);
   a.out_scale = s; a.aux_x = x; a.gs = gs;
-  a.Hin = H; a.Win = W; a.Hv = H; a.Wv = W; a.Hout = H; a.Wout = W;
+  a.Hin = H; a.Win = W; a.Wpitch = W; a.Hout = H; a.Wout = W; a.Wopitch = W;
   // gx[i,y,x] = sum_{o,ky,kx} Wsc[o,i,ky,kx] gz[o, y-(ky-r), x-(kx-r)]
   RawTap taps[9];
   int n = 0;
   const int r = ksize / 2;
   for (int ky = 0; ky < ksize; ++ky)
     for (int kx = 0; kx < ksize; ++kx) taps[n++] = RawTap{0, r - ky, r - kx, ky * ksize + kx};
-  const RawTap* tp[4] = {taps, nullptr, nullptr, nullptr};
-  const int nt[4] = {n, 0, 0, 0}, op[4] = {0, 0, 0, 0};
-  int rc = finish_geometry(a, tp, nt, op, what);
-  if (rc) return rc;
-  return dispatch_conv(a, as_stream(stream), what);
+  RawItem it{n, taps, 0, 0, 0, H, W};
+  return run_conv(a, &it, 1, as_stream(stream), what);
 }
 
 extern "C" int cagc_modconv_up_dgrad(float* gx, float* gs, const float* gt, const float* wp, const float* s,
@@ -469,15 +614,13 @@ extern "C" int cagc_modconv_up_dgrad(float* gx, float* gs, const float* gt, cons
   ConvArgs a;
   base_args(a, gx, gt, wp, B, /*K=*/Cout, /*M=*/Cin);
   a.out_scale = s; a.aux_x = x; a.gs = gs;
-  a.NPin = 4; a.Hin = H + 1; a.Win = W + 1; a.Hv = H; a.Wv = W; a.Hout = H; a.Wout = W;
+  a.NPin = 4; a.Hin = H + 1; a.Win = W + 1; a.Wpitch = cagc_phase_pitch(W);
+  a.Hout = H; a.Wout = W; a.Wopitch = W;
   // gx[i,y,x] = sum_{o,ky,kx} Wsc[o,i,ky,kx] gT[o, 2y+ky, 2x+kx];  gT phase-planar: plane (ky&1, kx&1) at (y + ky/2, x + kx/2)
   RawTap taps[9];
   int n = 0;
   for (int ky = 0; ky < 3; ++ky)
     for (int kx = 0; kx < 3; ++kx) taps[n++] = RawTap{(ky & 1) * 2 + (kx & 1), ky / 2, kx / 2, ky * 3 + kx};
-  const RawTap* tp[4] = {taps, nullptr, nullptr, nullptr};
-  const int nt[4] = {n, 0, 0, 0}, op[4] = {0, 0, 0, 0};
-  int rc = finish_geometry(a, tp, nt, op, what);
-  if (rc) return rc;
-  return dispatch_conv(a, as_stream(stream), what);
+  RawItem it{n, taps, 0, 0, 0, H, W};
+  return run_conv(a, &it, 1, as_stream(stream), what);
 }

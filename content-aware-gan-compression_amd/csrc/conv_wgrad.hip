@@ -23,7 +23,7 @@ struct WgArgs {
   const float* s;
   float* ws;
   int B, Cin, Cout, H, W;        // H,W: the K-grid (pixels summed over)
-  int NPA, AHg, AWg;             // global dims of the A tensor planes
+  int NPA, AHg, AWg, APitch;     // global dims of the A tensor planes (valid width, row pitch)
   int TH, TW, tiles_x, tiles_y, ntiles, nsplit;
   int AH, AW, AWp, ACS;          // LDS A tile rows/cols/padded row stride/channel stride
   int BH, BW, BWp, BCS;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
       const int gy = y0 + A.a_y0 + iy;
       const int o = o0 + oc;
       const bool rok = (o < A.Cout) && (gy >= 0) && (gy < A.AHg);
-      const float* src = A.ga + (((int64_t)(b * A.Cout + o) * A.NPA + pl) * A.AHg + gy) * A.AWg;
+      const float* src = A.ga + (((int64_t)(b * A.Cout + o) * A.NPA + pl) * A.AHg + gy) * A.APitch;
       float* dst = a_lds + oc * A.ACS + (pl * A.AH + iy) * A.AWp;
       for (int ix = rx; ix < A.AW; ix += 64) {
         const int gx = x0 + A.a_x0 + ix;
@@ -180,12 +180,12 @@ static int wgrad_geometry(WgArgs& a, int B, int Cin, int Cout, int H, int W, int
   a.Mp32 = round_up(Cout, 32);
   a.Np32 = round_up(Cin, 32);
   if (up) {
-    a.NPA = 4; a.AHg = H + 1; a.AWg = W + 1;
+    a.NPA = 4; a.AHg = H + 1; a.AWg = W + 1; a.APitch = (W + 1 + 3) & ~3;
     a.AH = a.TH + 1; a.AW = a.TW + 1; a.a_y0 = 0; a.a_x0 = 0;
     a.BH = a.TH; a.BW = a.TW; a.b_y0 = 0; a.b_x0 = 0;
   } else {
     const int r = ksize / 2;
-    a.NPA = 1; a.AHg = H; a.AWg = W;
+    a.NPA = 1; a.AHg = H; a.AWg = W; a.APitch = W;
     a.AH = a.TH; a.AW = a.TW; a.a_y0 = 0; a.a_x0 = 0;
     a.BH = a.TH + 2 * r; a.BW = a.TW + 2 * r; a.b_y0 = -r; a.b_x0 = -r;
   }

@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void k_blur_up_fwd(float* __restrict__ out, co
   const int Y0 = (bid % tiles_y) * FT;
   const int plane = bid / tiles_y;  // b*C + c
   const int b = plane / C, c = plane - b * C;
-  const int PH = H + 1, PW = W + 1;
-  const float* tp = t + (int64_t)plane * 4 * PH * PW;
+  const int PH = H + 1, PW = W + 1, PWp = (W + 1 + 3) & ~3;  // valid width, row pitch (cagc_phase_pitch)
+  const float* tp = t + (int64_t)plane * 4 * PH * PWp;
   if (threadIdx.x < 16) kf[threadIdx.x] = fir[15 - threadIdx.x];
   // stage: LDS row r <-> Y = Y0 - 2 + r ; for each phase (py,px): m = (Y0-2)/2 + mr, mr in [0,18)
   const int m0 = (Y0 - 2) / 2, n0 = (X0 - 2) / 2;  // Y0,X0 are multiples of 32 -> exact (may be -1)
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_blur_up_fwd(float* __restrict__ out, co
     const int ph = e / (HR * HR);
     const int m = m0 + mr, n = n0 + nc;
     float v = 0.f;
-    if (m >= 0 && m < PH && n >= 0 && n < PW) v = tp[((int64_t)ph * PH + m) * PW + n];
+    if (m >= 0 && m < PH && n >= 0 && n < PW) v = tp[((int64_t)ph * PH + m) * PWp + n];
     tile[(2 * mr + (ph >> 1)) * LW + 2 * nc + (ph & 1)] = v;
   }
   __syncthreads();
@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void k_blur_up_bwd(float* __restrict__ gt, con
   bid /= tiles_x;
   const int Y0 = (bid % tiles_y) * FT;
   const int plane = bid / tiles_y;
-  const int OH = 2 * H, OW = 2 * W, PH = H + 1, PW = W + 1;
+  const int OH = 2 * H, OW = 2 * W, PH = H + 1, PWp = (W + 1 + 3) & ~3;
   const float* gp = gz + (int64_t)plane * OH * OW;
-  float* tp = gt + (int64_t)plane * 4 * PH * PW;
+  float* tp = gt + (int64_t)plane * 4 * PH * PWp;
   if (threadIdx.x < 16) kf[threadIdx.x] = fir[15 - threadIdx.x];
   for (int e = threadIdx.x; e < LR * LR; e += 256) {
     const int r = e / LR, cc = e - r * LR;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_blur_up_bwd(float* __restrict__ gt, con
     const int nl = e & 15, ml = (e >> 4) & 15, ph = e >> 8;
     const int py = ph >> 1, px = ph & 1;
     const int m = Y0 / 2 + ml, n = X0 / 2 + nl;
-    if (m >= PH || n >= PW) continue;
+    if (m >= PH || n >= PWp) continue;   // pad columns [W+1, pitch) are written as zero
     const int yl = 2 * ml + py, xl = 2 * nl + px;  // local T_full coords in the tile
     const int Yt = Y0 + yl, Xt = X0 + xl;
     float acc = 0.f;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_blur_up_bwd(float* __restrict__ gt, con
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) acc += tile[(yl + 3 - a) * LW + xl + 3 - bb] * kf[a * 4 + bb];
     }
-    tp[((int64_t)ph * PH + m) * PW + n] = acc;
+    tp[((int64_t)ph * PH + m) * PWp + n] = acc;
   }
 }
 

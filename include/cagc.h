@@ -133,8 +133,11 @@ int cagc_modconv_fwd(float* out, const float* x, const float* wp, const float* s
                      int noise_batch, const float* noise_w, const float* bias, float alpha, float act_scale,
                      cagc_stream_t stream);
 
+/* Row pitch P = round_up(W+1, 4) of the phase-planar tensors below (16-byte aligned rows; columns
+ * >= W+1 are padding). */
+int cagc_phase_pitch(int W);
 /* Upsampling modulated conv, first half (model.py:259-269): stride-2 transposed 3x3 conv, evaluated as
- * its 4 output-parity phases.  Output is PHASE-PLANAR: t [B,Cout,4,H+1,W+1] with
+ * its 4 output-parity phases.  Output is PHASE-PLANAR: t [B,Cout,4,H+1,P] with
  *   t[b,o,2*py+px,m,n] = convT[b,o,2m+py,2n+px]   (zero where 2m+py > 2H or 2n+px > 2W)
  * raw (no demod; d is applied by cagc_blur_up_fwd).                                                */
 int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, const float* s, int B, int Cin, int Cout,
@@ -145,7 +148,7 @@ int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, const float* 
 int cagc_blur_up_fwd(float* out, const float* t, const float* fir, const float* d, const float* noise,
                      int noise_batch, const float* noise_w, const float* bias, int B, int C, int H, int W,
                      float alpha, float act_scale, cagc_stream_t stream);
-/* Backward of the blur half: gz [B,C,2H,2W] -> gt phase-planar [B,C,4,H+1,W+1] (every element written). */
+/* Backward of the blur half: gz [B,C,2H,2W] -> gt phase-planar [B,C,4,H+1,P] (every element written). */
 int cagc_blur_up_bwd(float* gt, const float* gz, const float* fir, int B, int C, int H, int W,
                      cagc_stream_t stream);
 
@@ -163,7 +166,7 @@ int cagc_styled_act_bwd(float* gz, float* red, const float* gout, const float* o
  * d loss / d s term); gs must be zero-initialised by the caller.  x [nullable iff gs null].       */
 int cagc_modconv_dgrad(float* gx, float* gs, const float* gz, const float* wp, const float* s, const float* x,
                        int B, int Cin, int Cout, int H, int W, int ksize, cagc_stream_t stream);
-/* dgrad of the transposed conv from the phase-planar gradient gt [B,Cout,4,H+1,W+1] -> gx [B,Cin,H,W]. */
+/* dgrad of the transposed conv from the phase-planar gradient gt [B,Cout,4,H+1,P] -> gx [B,Cin,H,W]. */
 int cagc_modconv_up_dgrad(float* gx, float* gs, const float* gt, const float* wp, const float* s,
                           const float* x, int B, int Cin, int Cout, int H, int W, cagc_stream_t stream);
 
