@@ -166,6 +166,225 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(float* __restrict__ gw, co
   gw[idx] = a * scale;
 }
 
+
+// =====================================================================================================
+// v2 — aligned shapes (W % 4 == 0): taps x input-channel blocks are split over the 4 wavefronts, so no
+// cross-wave reduction and only ceil(9*NB/4)*MB accumulators per wave; 16-byte staging loads.
+//
+//   plain :  K grid = H x W        A = gz[b,o,y,x]                    B_t = xs[b,i,y+ky-1,x+kx-1]
+//   up    :  K grid = (H+1)x(W+1)  A_t = gt[b,o,plane(ky&1,kx&1),m,n] B_t = xs[b,i,m-ky/2,n-kx/2]
+// (substituting m = y + ky/2 in gW = sum gT[2y+ky,2x+kx] xs[y,x]; xs is zero outside H x W), i.e. in both
+// modes only B carries a halo and A differs between taps at most by its plane.
+// Pair p = (tap, nb) -> wavefront p % 4, accumulator slot p / 4.
+// =====================================================================================================
+struct Wg2Args {
+  const float* ga;
+  const float* x;
+  const float* s;
+  float* ws;
+  int B, Cin, Cout, H, W;      // x dims
+  int Hk, Wk;                  // K grid
+  int NPA, AHg, APitch;        // A planes per channel, plane rows, row pitch
+  int TH, TW, tiles_x, tiles_y, ntiles, nsplit;
+  int ACS, BCS, BH, BWp, QB;   // LDS channel strides; B tile rows / padded row / float4 per row
+  int b_y0;                    // B tile row 0 relative to the tile origin (-1)
+  int ntaps, Mp, Np;           // padded slab dims
+  int a_off[9], b_off[9];
+};
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256, 2) void k_wgrad2(const Wg2Args A) {
+  constexpr int MT = MB * 16, NT = NB * 16;
+  constexpr int PPW = (9 * NB + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* a_lds = smem;
+  float* b_lds = smem + MT * A.ACS;
+  const int tid = threadIdx.x, lane = tid & 63, lm = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int o0 = blockIdx.x * MT, i0 = blockIdx.y * NT, sp = blockIdx.z;
+  const int TH = A.TH, TW = A.TW, QA = TW >> 2;
+
+  // wave-uniform pair descriptors
+  int p_aoff[PPW], p_boff[PPW], p_tap[PPW], p_nb[PPW];
+  bool p_ok[PPW];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int p = wave + 4 * q;
+    p_ok[q] = p < A.ntaps * NB;
+    const int tap = p_ok[q] ? p / NB : 0;
+    const int nb = p_ok[q] ? p - tap * NB : 0;
+    p_tap[q] = tap; p_nb[q] = nb;
+    p_aoff[q] = A.a_off[tap];
+    p_boff[q] = A.b_off[tap] + nb * 16 * A.BCS;
+  }
+  f32x4 acc[PPW][MB];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q)
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int a_rows = MT * A.NPA * TH;          // rows of QA float4
+  const int b_rows = NT * A.BH;                // rows of QB float4 (<= 16)
+  const float inv_TH = 1.0f / (float)TH, inv_NPA = 1.0f / (float)A.NPA, inv_BH = 1.0f / (float)A.BH;
+  const int rpa = 256 / QA;                    // A rows per pass of the workgroup
+  const int aq = tid % QA, ar = tid / QA;
+  const int bq = tid & 15, br = tid >> 4;      // 16 rows per pass
+
+  for (int tile = sp; tile < A.ntiles; tile += A.nsplit) {
+    int t2 = tile;
+    const int txi = t2 % A.tiles_x; t2 /= A.tiles_x;
+    const int tyi = t2 % A.tiles_y;
+    const int b = t2 / A.tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;
+    __syncthreads();
+    // ---- stage A: [MT][NPA][TH][TW], no halo, 16-byte loads ------------------------------------------
+#pragma unroll 4
+    for (int r = ar; r < a_rows; r += rpa) {
+      const int q1 = (int)(((float)r + 0.5f) * inv_TH);
+      const int iy = r - q1 * TH;
+      const int oc = (int)(((float)q1 + 0.5f) * inv_NPA);
+      const int pl = q1 - oc * A.NPA;
+      const int gy = y0 + iy, gx = x0 + 4 * aq, o = o0 + oc;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o < A.Cout && gy < A.Hk && gx + 4 <= A.APitch)
+        v = *reinterpret_cast<const float4*>(A.ga + (((int64_t)(b * A.Cout + o) * A.NPA + pl) * A.AHg + gy) * A.APitch + gx);
+      if (gx + 3 >= A.Wk) {  // mask the pitch padding / tile overhang
+        if (gx + 0 >= A.Wk) v.x = 0.f;
+        if (gx + 1 >= A.Wk) v.y = 0.f;
+        if (gx + 2 >= A.Wk) v.z = 0.f;
+        v.w = 0.f;
+      }
+      float* dst = a_lds + oc * A.ACS + (pl * TH + iy) * TW + 4 * aq;
+      *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+      *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+    }
+    // ---- stage B: [NT][BH][BWp], halo, scaled by s[b,i]; LDS column 0 <-> global column x0 - 4 --------
+#pragma unroll 4
+    for (int r = br; r < b_rows; r += 16) {
+      const int ic = (int)(((float)r + 0.5f) * inv_BH);
+      const int iy = r - ic * A.BH;
+      const int gy = y0 + A.b_y0 + iy, gx = x0 - 4 + 4 * bq, i = i0 + ic;
+      if (bq < A.QB) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < A.Cin && gy >= 0 && gy < A.H && gx >= 0 && gx + 4 <= A.W) {
+          v = *reinterpret_cast<const float4*>(A.x + ((int64_t)(b * A.Cin + i) * A.H + gy) * A.W + gx);
+          const float sc = A.s ? A.s[b * A.Cin + i] : 1.f;
+          v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        }
+        float* dst = b_lds + ic * A.BCS + iy * A.BWp + 4 * bq;
+        *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over the tile's pixels -------------------------------------------------------------------
+    for (int row = 0; row < TH; ++row) {
+      for (int s4 = 0; s4 < QA; ++s4) {
+        const int px = 4 * s4 + g;
+        const int ao = row * TW + px, bo = row * A.BWp + px;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+          if (p_ok[q]) {
+            float av[MB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) av[i] = a_lds[(i * 16 + lm) * A.ACS + p_aoff[q] + ao];
+            const float bv = b_lds[lm * A.BCS + p_boff[q] + bo];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[q][i], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- each wave owns its (tap, nb) pairs: write the partial slab ws[sp][t][Mp][Np] ----------------------
+  float* slab = A.ws + (int64_t)sp * A.ntaps * A.Mp * A.Np;
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    if (p_ok[q]) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + i * 16 + 4 * g + r, ii = i0 + p_nb[q] * 16 + lm;
+          slab[((int64_t)p_tap[q] * A.Mp + o) * A.Np + ii] = acc[q][i][r];
+        }
+    }
+  }
+}
+
+struct Wg2Plan { int mb, nb; };
+static Wg2Plan wg2_plan(int Cout, int Cin) {
+  static const Wg2Plan cands[] = {{1, 1}, {2, 2}, {3, 3}, {5, 2}};
+  Wg2Plan best = cands[0];
+  long best_cost = -1;
+  for (const Wg2Plan& c : cands) {
+    const long cost = (long)cdiv(Cout, 16 * c.mb) * c.mb * cdiv(Cin, 16 * c.nb) * c.nb;
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && c.mb * c.nb > best.mb * best.nb)) { best = c; best_cost = cost; }
+  }
+  return best;
+}
+
+static void wgrad2_geometry(Wg2Args& a, Wg2Plan pl, int B, int Cin, int Cout, int H, int W, int ksize, int up) {
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.Hk = up ? H + 1 : H; a.Wk = up ? W + 1 : W;
+  a.NPA = up ? 4 : 1; a.AHg = a.Hk; a.APitch = up ? ((W + 1 + 3) & ~3) : W;
+  int tw = 4;
+  while (tw < a.Wk && tw < 32) tw <<= 1;
+  a.TW = tw;
+  a.TH = (up ? 64 : 128) / tw;
+  if (a.TH > 16) a.TH = 16;
+  a.tiles_x = cdiv(a.Wk, a.TW); a.tiles_y = cdiv(a.Hk, a.TH);
+  a.ntiles = B * a.tiles_x * a.tiles_y;
+  a.ntaps = ksize * ksize;
+  a.Mp = cdiv(Cout, 16 * pl.mb) * 16 * pl.mb;
+  a.Np = cdiv(Cin, 16 * pl.nb) * 16 * pl.nb;
+  const int r = ksize / 2;
+  a.BH = up ? a.TH + 1 : a.TH + 2 * r;
+  a.b_y0 = up ? -1 : -r;
+  a.BWp = up ? a.TW + 4 : a.TW + 8;          // LDS col 0 = global col x0 - 4
+  a.QB = a.BWp / 4;
+  auto pad2 = [](int v) { return v + ((2 - (v % 32)) + 32) % 32; };  // == 2 (mod 32), even -> 8-byte aligned rows
+  a.ACS = pad2(a.NPA * a.TH * a.TW);
+  a.BCS = pad2(a.BH * a.BWp);
+  for (int ky = 0; ky < ksize; ++ky)
+    for (int kx = 0; kx < ksize; ++kx) {
+      const int t = ky * ksize + kx;
+      if (up) {
+        a.a_off[t] = ((ky & 1) * 2 + (kx & 1)) * a.TH * a.TW;
+        a.b_off[t] = (1 - ky / 2) * a.BWp + 4 - kx / 2;          // xs[m - ky/2, n - kx/2]; LDS row 0 = m0 - 1
+      } else {
+        a.a_off[t] = 0;
+        a.b_off[t] = ky * a.BWp + 4 + kx - r;                    // xs[y + ky - r, x + kx - r]; LDS row 0 = y0 - r
+      }
+    }
+  const int mn = (a.Mp / (16 * pl.mb)) * (a.Np / (16 * pl.nb));
+  int ns = (1024 + mn - 1) / mn;
+  if (ns > a.ntiles) ns = a.ntiles;
+  if (ns < 1) ns = 1;
+  a.nsplit = ns;
+}
+
+template <int MB, int NB>
+static int launch_wgrad2(Wg2Args& a, hipStream_t st, const char* what) {
+  const size_t smem = sizeof(float) * ((size_t)MB * 16 * a.ACS + (size_t)NB * 16 * a.BCS);
+  CAGC_REQUIRE(smem <= 160 * 1024, "%s: LDS tile %zu B too large", what, smem);
+  static bool attr[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad2<MB, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr[dev] = true;
+  }
+  dim3 grid(a.Mp / (16 * MB), a.Np / (16 * NB), a.nsplit);
+  hipLaunchKernelGGL((k_wgrad2<MB, NB>), grid, dim3(256), smem, st, a);
+  return check_launch(what);
+}
+
+static bool wgrad_use_v2(int W, int ksize, const float* g, const float* x) {
+  return ksize == 3 && (W % 4 == 0) && (((uintptr_t)g | (uintptr_t)x) % 16 == 0);
+}
+
 static int wgrad_geometry(WgArgs& a, int B, int Cin, int Cout, int H, int W, int ksize, int up) {
   memset(&a, 0, sizeof(a));
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
@@ -221,7 +440,14 @@ extern "C" int64_t cagc_modconv_wgrad_workspace(int B, int Cin, int Cout, int H,
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3)) return -1;
   WgArgs a;
   wgrad_geometry(a, B, Cin, Cout, H, W, ksize, up);
-  return (int64_t)a.nsplit * a.ntaps * a.Mp32 * a.Np32;
+  int64_t n = (int64_t)a.nsplit * a.ntaps * a.Mp32 * a.Np32;
+  if (ksize == 3 && W % 4 == 0) {   // the caller's pointers decide v1/v2 at launch: size for the larger
+    Wg2Args b;
+    wgrad2_geometry(b, wg2_plan(Cout, Cin), B, Cin, Cout, H, W, ksize, up);
+    const int64_t n2 = (int64_t)b.nsplit * b.ntaps * b.Mp * b.Np;
+    if (n2 > n) n = n2;
+  }
+  return n;
 }
 
 extern "C" int cagc_modconv_wgrad(float* gweight, float* workspace, const float* g, const float* x, const float* s,
@@ -231,6 +457,23 @@ extern "C" int cagc_modconv_wgrad(float* gweight, float* workspace, const float*
   CAGC_REQUIRE(gweight && workspace && g && x, "%s: null tensor", what);
   CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
   CAGC_REQUIRE(ksize == 3 || (ksize == 1 && !up), "%s: unsupported ksize/up", what);
+  if (wgrad_use_v2(W, ksize, g, x)) {
+    hipStream_t st2 = as_stream(stream);
+    const Wg2Plan pl = wg2_plan(Cout, Cin);
+    Wg2Args b;
+    wgrad2_geometry(b, pl, B, Cin, Cout, H, W, ksize, up);
+    b.ga = g; b.x = x; b.s = s; b.ws = workspace;
+    int rc2;
+    if (pl.mb == 1) rc2 = launch_wgrad2<1, 1>(b, st2, what);
+    else if (pl.mb == 2) rc2 = launch_wgrad2<2, 2>(b, st2, what);
+    else if (pl.mb == 3) rc2 = launch_wgrad2<3, 3>(b, st2, what);
+    else rc2 = launch_wgrad2<5, 2>(b, st2, what);
+    if (rc2) return rc2;
+    const int64_t n2 = (int64_t)Cout * Cin * b.ntaps;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n2, 256)), dim3(256), 0, st2, gweight, workspace, Cout, Cin, b.ntaps, b.Mp,
+                       b.Np, b.nsplit, scale);
+    return check_launch("cagc_modconv_wgrad(reduce)");
+  }
   WgArgs a;
   wgrad_geometry(a, B, Cin, Cout, H, W, ksize, up);
   a.ga = g; a.x = x; a.s = s; a.ws = workspace;
