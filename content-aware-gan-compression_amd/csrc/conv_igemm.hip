@@ -77,8 +77,8 @@ struct ConvArgs {
 };
 
 // NV = max float4 (vec) / float (scalar) input elements staged per thread per chunk
-template <int MB, int NV, bool VEC>
-__global__ __launch_bounds__(256, (NV <= 4 ? 2 : 1)) void k_conv_igemm(const ConvArgs A) {
+template <int MB, int NV, bool VEC, bool GS>
+__global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8)) ? 2 : 1)) void k_conv_igemm(const ConvArgs A) {
   constexpr int CK = CONV_CK;
   constexpr int MT = MB * 16;
   constexpr int LDA = (MT % 32 == 0) ? MT + 16 : MT;
@@ -256,6 +256,12 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 2 : 1)) void k_conv_igemm(const Con
   const bool styled = (A.epi == CAGC_EPI_STYLED) && (A.ksplit == 1);
   const bool atomic_out = A.ksplit > 1;
   const float nw = (styled && A.noise) ? A.noise_w[0] : 0.f;
+  const bool gs_block = GS && (IPB == 1);   // whole tile in one image: reduce per workgroup
+  float gpart[GS ? MB : 1][4];
+#pragma unroll
+  for (int i = 0; i < (GS ? MB : 1); ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gpart[i][r] = 0.f;
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
     const int n = (wave * NBW + j) * 16 + lm;
@@ -278,11 +284,15 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 2 : 1)) void k_conv_igemm(const Con
         const bool ok = pok && (m < A.Cout);
         float v = vals[r];
         const int64_t oidx = ((int64_t)(b * A.Cout + m) * A.NPout + I.out_plane) * HWo + pix;
-        if (A.gs) {  // dgrad: reduce (unscaled dgrad) * x over this 16-pixel group
+        if constexpr (GS) {  // dgrad: sum (unscaled dgrad) * x over pixels -> gs[b, m]
           float xv = 0.f;
           if (ok) xv = A.aux_x[oidx];
-          const float part = group16_sum(ok ? v * xv : 0.f);
-          if (lm == 0 && m < A.Cout && bl < A.B && part != 0.f) atomicAdd(A.gs + (int64_t)bl * A.Cout + m, part);
+          if (gs_block) {
+            gpart[i][r] += ok ? v * xv : 0.f;
+          } else {
+            const float part = group16_sum(ok ? v * xv : 0.f);
+            if (lm == 0 && m < A.Cout && bl < A.B && part != 0.f) atomicAdd(A.gs + (int64_t)bl * A.Cout + m, part);
+          }
         }
         if (ok) {
           if (A.out_scale && !(A.epi == CAGC_EPI_STYLED && atomic_out)) v *= A.out_scale[b * A.Cout + m];
@@ -294,6 +304,22 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 2 : 1)) void k_conv_igemm(const Con
           else A.out[oidx] = v;
         }
       }
+    }
+  }
+  if constexpr (GS) if (gs_block) {   // lanes -> 16-lane groups -> 4 waves (through LDS) -> ONE atomic per (workgroup, channel)
+    __syncthreads();  // all MFMA reads of LDS are done; reuse it
+    float* red = smem;  // [4 waves][MT]
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = group16_sum(gpart[i][r]);
+        if (lm == 0) red[wave * MT + i * 16 + 4 * g + r] = p;
+      }
+    __syncthreads();
+    if (tid < MT && m0 + tid < A.Cout && b0 < A.B) {
+      const float p = red[tid] + red[MT + tid] + red[2 * MT + tid] + red[3 * MT + tid];
+      atomicAdd(A.gs + (int64_t)b0 * A.Cout + m0 + tid, p);
     }
   }
 }
@@ -349,35 +375,40 @@ static int floor4(int v) { return (v >= 0) ? (v & ~3) : -(((-v) + 3) & ~3); }
 struct RawTap { int plane, dy, dx, widx; };
 struct RawItem { int ntaps; const RawTap* taps; int out_plane, vy_base, vx_base, Hv, Wv; };
 
-template <int MB, int NV, bool VEC>
+template <int MB, int NV, bool VEC, bool GS>
 static int launch_conv(ConvArgs& a, size_t smem, dim3 grid, hipStream_t st, const char* what) {
   static bool attr_set[64] = {};  // per device (one process normally drives one GPU)
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<MB, NV, VEC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<MB, NV, VEC, GS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((k_conv_igemm<MB, NV, VEC>), grid, dim3(256), smem, st, a);
+  hipLaunchKernelGGL((k_conv_igemm<MB, NV, VEC, GS>), grid, dim3(256), smem, st, a);
   return check_launch(what);
 }
 
-template <int MB>
-static int launch_conv_nv(ConvArgs& a, int nv, size_t smem, dim3 grid, hipStream_t st, const char* what) {
+template <int MB, bool GS>
+static int launch_conv_nv2(ConvArgs& a, int nv, size_t smem, dim3 grid, hipStream_t st, const char* what) {
   if (a.vec) {
-    if (nv <= 4) return launch_conv<MB, 4, true>(a, smem, grid, st, what);
-    if (nv <= 12) return launch_conv<MB, 12, true>(a, smem, grid, st, what);
+    if (nv <= 4) return launch_conv<MB, 4, true, GS>(a, smem, grid, st, what);
+    if (nv <= 12) return launch_conv<MB, 12, true, GS>(a, smem, grid, st, what);
   } else {
-    if (nv <= 12) return launch_conv<MB, 12, false>(a, smem, grid, st, what);
-    if (nv <= 48) return launch_conv<MB, 48, false>(a, smem, grid, st, what);
+    if (nv <= 12) return launch_conv<MB, 12, false, GS>(a, smem, grid, st, what);
+    if (nv <= 48) return launch_conv<MB, 48, false, GS>(a, smem, grid, st, what);
   }
   set_error("%s: staging tile too large (%d elements per thread)", what, nv);
   return CAGC_ERR_UNSUPPORTED;
 }
+template <int MB>
+static int launch_conv_nv(ConvArgs& a, int nv, size_t smem, dim3 grid, hipStream_t st, const char* what) {
+  return a.gs ? launch_conv_nv2<MB, true>(a, nv, smem, grid, st, what) : launch_conv_nv2<MB, false>(a, nv, smem, grid, st, what);
+}
 
 // Fill tile geometry for every work item and launch.
-static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, const char* what) {
+static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, const char* what, bool zero_out = true,
+                    bool allow_split = true) {
   CAGC_REQUIRE(nitems <= MAX_ITEMS, "%s: too many work items", what);
   int min_dy = 1 << 20, max_dy = -(1 << 20), min_dx = 1 << 20, max_dx = -(1 << 20);
   for (int p = 0; p < nitems; ++p)
@@ -454,7 +485,7 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   const int mtiles = cdiv(a.Mp, MT);
   const int nchunks = cdiv(a.Kp, CONV_CK);
   int ks = 1;
-  if (blocks * mtiles < 256 && nchunks >= 4) {
+  if (allow_split && blocks * mtiles < 256 && nchunks >= 4) {
     ks = cdiv(512, blocks * mtiles);
     if (ks > nchunks / 2) ks = nchunks / 2;
     if (ks < 1) ks = 1;
@@ -463,7 +494,7 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   const size_t smem = sizeof(float) * ((size_t)MAX_TAPS * CONV_CK * LDA + (size_t)CONV_CK * max_ps);
   CAGC_REQUIRE(smem <= 160 * 1024, "%s: LDS tile %zu B too large", what, smem);
   const int nv = cdiv(max_units, 256);
-  if (ks > 1) {
+  if (ks > 1 && zero_out) {
     const size_t bytes = sizeof(float) * (size_t)a.B * a.Cout * a.NPout * a.Hout * a.Wopitch;
     if (hipMemsetAsync(a.out, 0, bytes, st) != hipSuccess) { set_error("%s: memset failed", what); return CAGC_ERR_LAUNCH; }
   }
@@ -570,18 +601,28 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   // phase (py,px), virtual (m,n): ky = py + 2jy, input row = m - jy
   RawTap taps[4][4];
   RawItem items[12];
-  int ni = 0;
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       const int ph = py * 2 + px;
       int n = 0;
       for (int jy = 0; jy < (py ? 1 : 2); ++jy)
         for (int jx = 0; jx < (px ? 1 : 2); ++jx) taps[ph][n++] = RawTap{0, -jy, -jx, (py + 2 * jy) * 3 + (px + 2 * jx)};
-      items[ni++] = RawItem{n, taps[ph], ph, 0, 0, H, W};      // exact H x W main region
-      items[ni++] = RawItem{n, taps[ph], ph, H, 0, 1, W + 1};  // bottom row m = H (incl. the corner)
-      items[ni++] = RawItem{n, taps[ph], ph, 0, W, H, 1};      // right column n = W
+      items[ph] = RawItem{n, taps[ph], ph, 0, 0, H, W};              // exact H x W main region
+      items[4 + 2 * ph] = RawItem{n, taps[ph], ph, H, 0, 1, W + 1};  // bottom row m = H (incl. the corner)
+      items[5 + 2 * ph] = RawItem{n, taps[ph], ph, 0, W, H, 1};      // right column n = W
     }
-  return run_conv(a, items, ni, as_stream(stream), what);
+  // Two launches: the main regions keep the small staging footprint (NV = 4 -> 2 waves / SIMD); the thin strips
+  // need longer halo tiles.  Split-K launches accumulate with atomics, so t is zeroed once up front.
+  hipStream_t st = as_stream(stream);
+  const bool small = (int64_t)B * H * W <= 32768;   // only small layers are ever split over K
+  if (small) {
+    const size_t bytes = sizeof(float) * (size_t)B * Cout * 4 * (H + 1) * a.Wopitch;
+    if (hipMemsetAsync(t, 0, bytes, st) != hipSuccess) { set_error("%s: memset failed", what); return CAGC_ERR_LAUNCH; }
+  }
+  ConvArgs a2 = a;
+  int rc = run_conv(a, items, 4, st, what, false, small);
+  if (rc) return rc;
+  return run_conv(a2, items + 4, 8, st, what, false, small);
 }
 
 extern "C" int cagc_modconv_dgrad(float* gx, float* gs, const float* gz, const float* wp, const float* s, const float* x,

@@ -193,7 +193,7 @@ struct Wg2Args {
 };
 
 template <int MB, int NB>
-__global__ __launch_bounds__(256, 2) void k_wgrad2(const Wg2Args A) {
+__global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)) void k_wgrad2(const Wg2Args A) {
   constexpr int MT = MB * 16, NT = NB * 16;
   constexpr int PPW = (9 * NB + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(const Wg2Args A) {
 
 struct Wg2Plan { int mb, nb; };
 static Wg2Plan wg2_plan(int Cout, int Cin) {
-  static const Wg2Plan cands[] = {{1, 1}, {2, 2}, {3, 3}, {5, 2}};
+  static const Wg2Plan cands[] = {{1, 1}, {2, 2}, {3, 3}, {5, 2}, {2, 5}, {3, 5}, {5, 3}};
   Wg2Plan best = cands[0];
   long best_cost = -1;
   for (const Wg2Plan& c : cands) {
@@ -464,10 +464,14 @@ extern "C" int cagc_modconv_wgrad(float* gweight, float* workspace, const float*
     wgrad2_geometry(b, pl, B, Cin, Cout, H, W, ksize, up);
     b.ga = g; b.x = x; b.s = s; b.ws = workspace;
     int rc2;
-    if (pl.mb == 1) rc2 = launch_wgrad2<1, 1>(b, st2, what);
-    else if (pl.mb == 2) rc2 = launch_wgrad2<2, 2>(b, st2, what);
-    else if (pl.mb == 3) rc2 = launch_wgrad2<3, 3>(b, st2, what);
-    else rc2 = launch_wgrad2<5, 2>(b, st2, what);
+    const int key = pl.mb * 10 + pl.nb;
+    if (key == 11) rc2 = launch_wgrad2<1, 1>(b, st2, what);
+    else if (key == 22) rc2 = launch_wgrad2<2, 2>(b, st2, what);
+    else if (key == 33) rc2 = launch_wgrad2<3, 3>(b, st2, what);
+    else if (key == 52) rc2 = launch_wgrad2<5, 2>(b, st2, what);
+    else if (key == 25) rc2 = launch_wgrad2<2, 5>(b, st2, what);
+    else if (key == 35) rc2 = launch_wgrad2<3, 5>(b, st2, what);
+    else rc2 = launch_wgrad2<5, 3>(b, st2, what);
     if (rc2) return rc2;
     const int64_t n2 = (int64_t)Cout * Cin * b.ntaps;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n2, 256)), dim3(256), 0, st2, gweight, workspace, Cout, Cin, b.ntaps, b.Mp,

@@ -102,7 +102,22 @@ __global__ __launch_bounds__(EW_THREADS) void k_bias_act_flat(float* __restrict_
   if (MODE == 0) vo = lrelu_fwd(va + b, alpha, scale);
   else vo = (va + b) * lrelu_gate(ref[i], alpha, scale);
   out[i] = vo;
-  if (MODE == 1 && gsum) atomicAdd(gsum + c, vo);
+}
+
+// gsum[c] += sum over (outer, inner) of v[outer, c, inner] for small `inner`: one wavefront per channel
+__global__ __launch_bounds__(256) void k_channel_sum_small(float* __restrict__ gsum, const float* __restrict__ v,
+                                                           int64_t outer, int C, int64_t inner) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t n = outer * inner;
+  float acc = 0.f;
+  for (int64_t e = lane; e < n; e += 64) {
+    const int64_t o = e / inner, i = e - o * inner;
+    acc += v[(o * C + c) * inner + i];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) gsum[c] += acc;
 }
 
 template <int MODE>
@@ -118,6 +133,8 @@ static int launch_bias_act(float* out, const float* a, const float* bias, const 
     CAGC_REQUIRE(nb < (1ll << 31), "%s: too large", what);
     hipLaunchKernelGGL((k_bias_act_flat<MODE>), dim3((unsigned)nb), dim3(EW_THREADS), 0, st, out, a, bias, ref, gsum, total,
                        (int)C, inner, alpha, scale);
+    if (MODE == 1 && gsum)   // per-channel reduction as its own small pass (no per-element atomics)
+      hipLaunchKernelGGL(k_channel_sum_small, dim3(cdiv(C, 4)), dim3(256), 0, st, gsum, out, outer, (int)C, inner);
   } else {
     const int nchunk = cdiv(inner, EW_CHUNK);
     const int64_t nb = outer * C * nchunk;

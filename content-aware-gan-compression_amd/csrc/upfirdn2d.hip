@@ -70,19 +70,26 @@ __global__ __launch_bounds__(256) void k_fir_s1(float* __restrict__ out, const f
     tile[r * LW + c] = v;
   }
   __syncthreads();
+  // each thread: 4 vertically adjacent outputs of one column -> a (KH+3) x KW register window, (KH+3)*KW LDS reads
+  // for 4 outputs (7 per output at 4x4 instead of 16); lanes run along x, so LDS reads are conflict-free and
+  // the stores coalesce for any (odd) output width
   const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
   const int ox = tx0 + lx;
   if (ox >= out_w) return;
+  float win[KH + 3][KW];
+#pragma unroll
+  for (int r = 0; r < KH + 3; ++r)
+#pragma unroll
+    for (int j = 0; j < KW; ++j) win[r][j] = tile[(4 * ly + r) * LW + lx + j];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int yy = ly + q * 8;
-    const int oy = ty0 + yy;
+    const int oy = ty0 + 4 * ly + q;
     if (oy < out_h) {
       float acc = 0.f;
 #pragma unroll
       for (int i = 0; i < KH; ++i)
 #pragma unroll
-        for (int j = 0; j < KW; ++j) acc += tile[(yy + i) * LW + lx + j] * kf[i * KW + j];
+        for (int j = 0; j < KW; ++j) acc += win[q + i][j] * kf[i * KW + j];
       out[(p * out_h + oy) * (int64_t)out_w + ox] = acc;
     }
   }
