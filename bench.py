@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches + DDP instead of HIP-graph replay")
     args = ap.parse_args()
 
     from cagc import _lib, distributed as cd, kd
@@ -143,11 +144,23 @@ def main():
 
     student, teacher, disc = kd.build_synthetic_workload(SIZE, dev, seed=0)
     n_params = sum(p.numel() for p in student.parameters())
-    ddp_student = cd.wrap_student(student, dev)
-    step = kd.KDStep(ddp_student, teacher, disc)
     mask = kd.ellipse_mask(bs, SIZE, dev)
     rng = random.Random(rank)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    torch.cuda.manual_seed(1234 + rank)
+    mode = "graph"
+    step = None
+    if not args.no_graph:
+        try:     # HIP-graph replay of the step; gradients all-reduced as one flat RCCL collective between graphs
+            step = kd.GraphedKDStep(student, teacher, disc, bs, mask, random_noise=True, world_size=world)
+        except Exception as e:  # noqa: BLE001 — capture is an optimisation, never a correctness requirement
+            print(f"[bench] HIP-graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            student, teacher, disc = kd.build_synthetic_workload(SIZE, dev, seed=0)
+    if step is None:
+        mode = "eager"
+        ddp_student = cd.wrap_student(student, dev)
+        step = kd.KDStep(ddp_student, teacher, disc)
 
     def run(n):
         for _ in range(n):
@@ -170,8 +183,13 @@ def main():
 
     roof = None
     if not args.no_roofline:
+        # per-kernel HIP-event timing needs individual launches: same models, eager launches (no graph), no DDP
+        prof_step = step if mode == "eager" else kd.KDStep(student, teacher, disc)
+        for _ in range(2):
+            prof_step.sample_and_step(bs, mask, rng, None)
         with KernelTimer(_lib) as kt:
-            run(3)
+            for _ in range(3):
+                prof_step.sample_and_step(bs, mask, rng, None)
         agg = kt.summary()
         if rank == 0:
             mfma = {k: v for k, v in agg.items() if v[2] > 0}
@@ -194,7 +212,7 @@ def main():
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "256px StyleGAN2 70%-pruned student [154x10,77,77,39,39] + full teacher KD generator step, "
                                       "global bs16 (configs[1]); frozen D fwd+dgrad, masked-L1 KD, Adam; LPIPS/BiSeNet off",
-                          "global_batch": GLOBAL_BATCH, "per_gpu_batch": bs, "parallelism": f"dp{world}",
+                          "global_batch": GLOBAL_BATCH, "per_gpu_batch": bs, "parallelism": f"dp{world}", "launch_mode": mode,
                           "student_params": n_params},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))

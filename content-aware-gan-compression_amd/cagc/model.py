@@ -387,6 +387,11 @@ class Generator(nn.Module):
         if len(styles) < 2:
             inject_index = self.n_latent
             latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1) if styles[0].ndim < 3 else styles[0]
+        elif torch.is_tensor(inject_index):
+            # device-side mixing index (static shapes: lets the whole step live in one HIP graph); value n_latent
+            # reproduces the no-mixing case, values 1..n_latent-1 the reference's cat of the two repeated styles
+            pos = torch.arange(self.n_latent, device=styles[0].device).view(1, -1, 1)
+            latent = torch.where(pos < inject_index.view(1, 1, 1), styles[0].unsqueeze(1), styles[1].unsqueeze(1))
         else:
             if inject_index is None:
                 inject_index = random.randint(1, self.n_latent - 1)

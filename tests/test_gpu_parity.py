@@ -326,3 +326,46 @@ def test_size_independent_properties_at_full_size():
         assert_close(m(2 * x, w), 2 * y, 1e-5, "homogeneity")
         # sample 3 alone == sample 3 within the batch
         assert_close(m(x[3:4], w[3:4]), y[3:4], 1e-6, "batch independence")
+
+
+def test_graphed_kd_step_matches_eager_step():
+    """HIP-graph replay of the step (cagc.kd.GraphedKDStep) == the eager step on the same inputs, two steps in a
+    row (the second checks that Adam state and the device-side mixing index advance correctly under replay)."""
+    g = load_npz("kd_step_tiny")
+    meta = load_json("kd_step_tiny_meta")
+
+    def build():
+        student = M.Generator(32, 24, 2, generator_net_shape=meta["student_shape"])
+        student.load_state_dict(sub(g, "student_sd/"), strict=True)
+        teacher = M.Generator(32, 24, 2, generator_net_shape=meta["teacher_shape"])
+        teacher.load_state_dict(sub(g, "teacher_sd/"), strict=True)
+        disc = M.Discriminator(32)
+        disc.load_state_dict(ref_model.regenerate_state_dict(load_json("discriminator32_keys"), g["d_seed"]), strict=True)
+        return student.to(DEV), teacher.to(DEV), disc.to(DEV)
+
+    se, te, de = build()
+    sg, tg, dg = build()
+    eager = kd.KDStep(se, te, de, latent=24)
+    B = g["mask"].shape[0]
+    graphed = kd.GraphedKDStep(sg, tg, dg, B, cu(g["mask"]), random_noise=False, latent=24)
+    with torch.no_grad():                                      # undo the capture warm-up steps
+        for k, v in sub(g, "student_sd/").items():
+            dict(sg.state_dict())[k].copy_(cu(v))
+        for st_ in graphed.optim.state.values():
+            for v in st_.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+    nl = se.num_layers
+    for st in meta["steps"]:
+        p = f"step{st['step']}/"
+        zs = [cu(g[p + f"z{i}"]) for i in range(st["n_z"])]
+        sn = [cu(g[p + f"student_noise{i}"]) for i in range(nl)]
+        tn = [cu(g[p + f"teacher_noise{i}"]) for i in range(nl)]
+        le = eager.g_step(zs, st["inject_index"], cu(g["mask"]), sn, tn)
+        lg = graphed.g_step(zs, st["inject_index"], cu(g["mask"]), sn, tn)
+        torch.cuda.synchronize()
+        assert abs(le["g"].item() - lg["g"].item()) < 1e-5 and abs(le["kd_l1_loss"].item() - lg["kd_l1_loss"].item()) < 1e-5
+        pe, pg = dict(se.named_parameters()), dict(sg.named_parameters())
+        for k in pe:
+            assert_close(pg[k].grad, pe[k].grad, 5e-4 if pe[k].numel() > 1 else 3e-3, f"graph grad {k}")  # atomics order differs run to run
+            assert_close(pg[k].detach(), pe[k].detach(), 1e-4, f"graph param {k}")
