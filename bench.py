@@ -87,13 +87,15 @@ class KernelTimer:
         return agg
 
 
-def cpu_baseline(sample_batch=4):
+def cpu_baseline(sample_batch=2):
     """The oracle (port of the reference CPU path: grouped convs on per-sample modulated weights, composed
     upfirdn2d / leaky_relu) timed on the host cores on a bounded sample: ONE KD step at batch `sample_batch` of the
     same 256 px workload (the reference's own CPU path took 57 s per bs-16 step on 8 cores)."""
     from cagc import kd
     from oracle import ref_kd
-    cores = os.cpu_count() or 1
+    # intra-op threads: all cores up to 32 (the grouped-conv CPU kernels stop scaling — and oversubscribe badly —
+    # beyond that; measured 5x slower with 256 threads on a 2x64-core host)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     student, teacher, disc = kd.build_synthetic_workload(SIZE, "cpu", seed=0)
     ssd = {k: v.detach() for k, v in student.state_dict().items()}
