@@ -37,6 +37,9 @@ _PROTOS = {
     "cagc_modconv_up_dgrad": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "cagc_modconv_wgrad_workspace": [_i, _i, _i, _i, _i, _i, _i],
     "cagc_modconv_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "cagc_fir4x4_pitched": [_p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "cagc_conv3x3s2_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "cagc_conv3x3s2_dgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "cagc_torgb_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "cagc_torgb_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "cagc_masked_l1": [_p, _p, _p, _p, _p, _i, _i, _i64, _f, _p],

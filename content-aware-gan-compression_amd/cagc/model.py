@@ -450,6 +450,36 @@ class ConvLayer(nn.Sequential):
         if activate:
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
+        self._fused_down = downsample and kernel_size == 3 and list(blur_kernel) == [1, 3, 3, 1]
+        self._packed = None
+
+    def _packed_weights(self, conv):
+        w = conv.weight
+        need_bwd = torch.is_grad_enabled()
+        if w.requires_grad and need_bwd:
+            return mc.pack_plain_weights(w, conv.scale, True)
+        key = (w._version, w.data_ptr(), w.device)
+        if self._packed is None or self._packed[0] != key or (need_bwd and self._packed[1][1] is None):
+            self._packed = (key, mc.pack_plain_weights(w, conv.scale, need_bwd))
+        return self._packed[1]
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, input):
+        # Blur -> 3x3 stride-2 conv as one op on the hand-written MFMA kernel (odd blurred size 2*Ho+1)
+        if (self._fused_down and mc.use_hip(input) and input.dtype == torch.float32
+                and (input.shape[2] + sum(self[0].pad) - 3) % 2 == 1 and (input.shape[3] + sum(self[0].pad) - 3) % 2 == 1):
+            blur, conv = self[0], self[1]
+            wp_fwd, wp_bwd = self._packed_weights(conv)
+            out = mc._BlurConvS2.apply(input, conv.weight, blur.kernel, wp_fwd, wp_bwd, tuple(blur.pad), conv.scale)
+            if conv.bias is not None:
+                out = out + conv.bias.view(1, -1, 1, 1)
+            for layer in list(self)[2:]:
+                out = layer(out)
+            return out
+        return super().forward(input)
 
 
 class ResBlock(nn.Module):

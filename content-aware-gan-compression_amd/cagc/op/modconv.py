@@ -215,6 +215,69 @@ def modconv_composed(x, weight, s, demodulate, upsample, downsample, blur_kernel
 
 
 # ---------------------------------------------------------------------------------------------------
+# discriminator down-sampling conv: Blur(pad=(2,2)) -> 3x3 stride-2 conv (reference model.py:683-706)
+# ---------------------------------------------------------------------------------------------------
+def pack_plain_weights(weight, scale, need_bwd):
+    """weight [Cout,Cin,3,3] * scale -> (wp_fwd, wp_bwd | None)."""
+    cout, cin, k, _ = weight.shape
+    w = weight.detach().contiguous()
+    wp_fwd = torch.empty(_lib.query("cagc_modconv_packed_elems", cin, cout, k), dtype=torch.float32, device=w.device)
+    wp_bwd = (torch.empty(_lib.query("cagc_modconv_packed_elems", cout, cin, k), dtype=torch.float32, device=w.device)
+              if need_bwd else None)
+    with _lib.on_device(w):
+        _lib.call("cagc_modconv_prep", _lib.ptr(wp_fwd), _lib.ptr(wp_bwd), None, _lib.ptr(w), cout, cin, k, float(scale))
+    return wp_fwd, wp_bwd
+
+
+class _BlurConvS2(Function):
+    """x [B,C,H,W] -> blur (4x4 FIR, pad (p0,p1)) -> 3x3 stride-2 conv.  The blurred (H+1)-wide intermediate lives
+    only inside this op, at a 16-byte row pitch, so the MFMA conv stages it with 16-byte loads."""
+
+    @staticmethod
+    def forward(ctx, x, weight, fir, wp_fwd, wp_bwd, pad, scale):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        cout = weight.shape[0]
+        hb, wb = H + pad[0] + pad[1] - 3, W + pad[0] + pad[1] - 3
+        pitch = (wb + 3) // 4 * 4
+        ho, wo = (hb - 3) // 2 + 1, (wb - 3) // 2 + 1
+        tmp = torch.empty(B, C, hb, pitch, dtype=x.dtype, device=x.device)
+        out = torch.empty(B, cout, ho, wo, dtype=x.dtype, device=x.device)
+        with _lib.on_device(x):
+            _lib.call("cagc_fir4x4_pitched", _lib.ptr(tmp), _lib.ptr(x), _lib.ptr(fir), B * C, H, W, W, hb, wb, pitch, pad[0], pad[0])
+            _lib.call("cagc_conv3x3s2_fwd", _lib.ptr(out), _lib.ptr(tmp), _lib.ptr(wp_fwd), B, C, cout, hb, wb, pitch)
+        ctx.cfg = (pad, scale, hb, wb, pitch)
+        ctx.save_for_backward(x if weight.requires_grad else x.new_empty(0), weight, fir, wp_bwd)
+        ctx.x_shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, weight, fir, wp_bwd = ctx.saved_tensors
+        pad, scale, hb, wb, pitch = ctx.cfg
+        B, C, H, W = ctx.x_shape
+        cout = weight.shape[0]
+        gout = gout.contiguous()
+        gx = gweight = None
+        with _lib.on_device(gout):
+            if ctx.needs_input_grad[0]:
+                if wp_bwd is None:
+                    raise RuntimeError("blur_conv_s2: backward requested but the weights were packed forward-only")
+                gtmp = torch.empty(B, C, hb, pitch, dtype=gout.dtype, device=gout.device)
+                _lib.call("cagc_conv3x3s2_dgrad", _lib.ptr(gtmp), _lib.ptr(gout), _lib.ptr(wp_bwd), B, C, cout, hb, wb, pitch)
+                gx = torch.empty(B, C, H, W, dtype=gout.dtype, device=gout.device)
+                gp = 4 - pad[0] - 1   # adjoint padding (reference op/upfirdn2d.py:111-116)
+                _lib.call("cagc_fir4x4_pitched", _lib.ptr(gx), _lib.ptr(gtmp), _lib.ptr(torch.flip(fir, [0, 1]).contiguous()),
+                          B * C, hb, wb, pitch, H, W, W, gp, gp)
+            if ctx.needs_input_grad[1]:
+                # weight gradient (discriminator training step — not on the KD generator step): stock kernel
+                xb = upfirdn2d(x, fir, pad=pad)
+                gweight = torch.nn.grad.conv2d_weight(xb, weight.shape, gout, stride=2) * scale
+        return gx, gweight, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
 # ToRGB
 # ---------------------------------------------------------------------------------------------------
 class _ToRGB(Function):

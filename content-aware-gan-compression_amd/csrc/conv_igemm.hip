@@ -27,6 +27,7 @@
 // Layers with too few pixel tiles to fill 256 CUs (4x4 .. 16x16) are split over K (channels) across
 // workgroups; partial sums are combined with fp32 atomics and the non-linear epilogue runs as a separate pass.
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -51,6 +52,10 @@ struct ConvItem {
   int IH, IWp, Q4, PS, rows;     // LDS tile: rows per (c,plane,img), padded row (floats), float4 per row,
                                  // channel-plane stride, rows per chunk (= CK*NPin*IPB*IH)
   int xoff;                      // LDS column of the tile's first needed input column (alignment slack)
+  int ooy, oox;                  // output pixel = (vy*osy + ooy, vx*osx + oox)
+  // multi-phase items (NPH = 4: all output parities of a stride-2 transposed conv in ONE workgroup, sharing the
+  // staged input tile): taps are ordered by phase, phase p owns ph_ntaps[p] consecutive taps
+  int ph_ntaps[4], ph_out_plane[4], ph_ooy[4], ph_oox[4];
   int block_end;                 // cumulative workgroup count (exclusive) along grid.x
   ConvTap taps[MAX_TAPS];
 };
@@ -69,6 +74,7 @@ struct ConvArgs {
   int NPin, Hin, Win, Wpitch;  // input planes per channel, valid plane dims, row pitch (floats)
   int isy, isx;
   int NPout, Hout, Wout, Wopitch;
+  int osy, osx;                // output stride (2 for the data gradient of a stride-2 conv, else 1)
   int min_dy, min_dx;
   int nitems, ksplit, vec;     // vec: 16-byte staging loads are legal (Wpitch % 4 == 0)
   int epi, noise_bstride_on;
@@ -77,8 +83,8 @@ struct ConvArgs {
 };
 
 // NV = max float4 (vec) / float (scalar) input elements staged per thread per chunk
-template <int MB, int NV, bool VEC, bool GS>
-__global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8)) ? 2 : 1)) void k_conv_igemm(const ConvArgs A) {
+template <int MB, int NV, bool VEC, bool GS, int NPH>
+__global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8) && NPH == 1) ? 2 : 1)) void k_conv_igemm(const ConvArgs A) {
   constexpr int CK = CONV_CK;
   constexpr int MT = MB * 16;
   constexpr int LDA = (MT % 32 == 0) ? MT + 16 : MT;
@@ -105,6 +111,11 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8)) ? 2 : 1)) void 
   const int vx_end = I.vx_base + I.Wv, vy_end = I.vy_base + I.Hv;
   const int m0 = blockIdx.y * MT;
   const int ntaps = I.ntaps;
+  const int ph_nt[4] = {I.ph_ntaps[0], I.ph_ntaps[1], I.ph_ntaps[2], I.ph_ntaps[3]};
+  const int ph_pl[4] = {I.ph_out_plane[0], I.ph_out_plane[1], I.ph_out_plane[2], I.ph_out_plane[3]};
+  const int ph_oy[4] = {I.ph_ooy[0], I.ph_ooy[1], I.ph_ooy[2], I.ph_ooy[3]};
+  const int ph_ox[4] = {I.ph_oox[0], I.ph_oox[1], I.ph_oox[2], I.ph_oox[3]};
+  const int i_plane = I.out_plane, i_ooy = I.ooy, i_oox = I.oox;
   int widx[MAX_TAPS];
 #pragma unroll
   for (int t = 0; t < MAX_TAPS; ++t) widx[t] = I.taps[t].widx;
@@ -164,11 +175,13 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8)) ? 2 : 1)) void 
     lb[j] = (img * IH + ty * A.isy) * IWp + tx * A.isx + (VEC ? I.xoff : 0);
   }
 
-  f32x4 acc[MB][NBW];
+  f32x4 acc[NPH][MB][NBW];
 #pragma unroll
-  for (int i = 0; i < MB; ++i)
+  for (int p = 0; p < NPH; ++p)
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) acc[p][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- register prefetch buffers -------------------------------------------------------------------------
   typedef typename std::conditional<VEC, float4, float>::type in_t;
@@ -231,24 +244,32 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8)) ? 2 : 1)) void 
     if (kc + CK < kc_hi) prefetch(kc + CK);  // in flight during the MFMAs below
     // runtime tap loop (the tap's LDS offset is a scalar kernarg load): keeps address VGPRs at 8 + MB instead
     // of letting the compiler hoist one address per (tap, step, block) out of the K loop
-#pragma unroll 1
-    for (int t = 0; t < ntaps; ++t) {
-      const int to = I.taps[t].lds_off;
-#pragma unroll
-      for (int s = 0; s < CK / 4; ++s) {
-        const int kk = 4 * s + g;
-        float av[MB], bv[NBW];
-#pragma unroll
-        for (int i = 0; i < MB; ++i) av[i] = a_lds[(t * CK + kk) * LDA + i * 16 + lm];
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) bv[j] = b_lds[kk * PS + lb[j] + to];
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-          for (int j = 0; j < NBW; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-      }
+    // one expansion per phase with a compile-time phase index -> static accumulator set (a rolled loop over phases
+    // would index acc[] dynamically and send it to scratch; a lambda would take the address of the kernarg struct)
+    int tbase = 0;
+#define CAGC_RUN_PHASE(P)                                                                                      \
+    {                                                                                                            \
+      const int np = (NPH == 1) ? ntaps : ph_nt[P];                                                              \
+      _Pragma("unroll 1") for (int tt = 0; tt < np; ++tt) {                                                      \
+        const int t = tbase + tt;                                                                                \
+        const int to = I.taps[t].lds_off;                                                                        \
+        _Pragma("unroll") for (int s = 0; s < CK / 4; ++s) {                                                     \
+          const int kk = 4 * s + g;                                                                              \
+          float av[MB], bv[NBW];                                                                                 \
+          _Pragma("unroll") for (int i = 0; i < MB; ++i) av[i] = a_lds[(t * CK + kk) * LDA + i * 16 + lm];       \
+          _Pragma("unroll") for (int j = 0; j < NBW; ++j) bv[j] = b_lds[kk * PS + lb[j] + to];                   \
+          _Pragma("unroll") for (int i = 0; i < MB; ++i)                                                         \
+            _Pragma("unroll") for (int j = 0; j < NBW; ++j)                                                      \
+              acc[P][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[P][i][j], 0, 0, 0);          \
+        }                                                                                                        \
+      }                                                                                                          \
+      tbase += np;                                                                                               \
     }
+    CAGC_RUN_PHASE(0)
+    if constexpr (NPH > 1) CAGC_RUN_PHASE(1)
+    if constexpr (NPH > 2) CAGC_RUN_PHASE(2)
+    if constexpr (NPH > 3) CAGC_RUN_PHASE(3)
+#undef CAGC_RUN_PHASE
   }
 
   // ---- epilogue: lane holds channels m0 + i*16 + 4g + r (r = 0..3) of pixel n ------------------------------
@@ -262,6 +283,40 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8)) ? 2 : 1)) void 
   for (int i = 0; i < (GS ? MB : 1); ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) gpart[i][r] = 0.f;
+  if constexpr (NPH > 1) {
+    // fused-phase epilogue: raw stores only (linear epilogue, no scales), one phase at a time so that at most one
+    // accumulator set is being drained to VGPRs
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) {
+        const int n = (wave * NBW + j) * 16 + lm;
+        const int img = n / THW;
+        const int rem = n - img * THW;
+        const int ty = rem / TW, tx = rem - ty * TW;
+        const int vy = vy0 + ty, vx = vx0 + tx, b = b0 + img;
+        const bool pok = (vy < vy_end) && (vx < vx_end) && (b < A.B) && (img < IPB);
+        const int pix = (vy * A.osy + ph_oy[ph]) * A.Wopitch + vx * A.osx + ph_ox[ph];
+        float* obase = A.out + ((int64_t)b * A.Cout * A.NPout + ph_pl[ph]) * HWo + pix;
+        const int64_t cstride = (int64_t)A.NPout * HWo;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const f32x4 a4 = acc[ph][i][j];
+          const int mb0 = m0 + i * 16 + 4 * g;
+          if (pok && mb0 + 0 < A.Cout) obase[(int64_t)(mb0 + 0) * cstride] = a4[0];
+          if (pok && mb0 + 1 < A.Cout) obase[(int64_t)(mb0 + 1) * cstride] = a4[1];
+          if (pok && mb0 + 2 < A.Cout) obase[(int64_t)(mb0 + 2) * cstride] = a4[2];
+          if (pok && mb0 + 3 < A.Cout) obase[(int64_t)(mb0 + 3) * cstride] = a4[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int ph = 0; ph < 1; ++ph) {
+  const int o_plane = (NPH == 1) ? i_plane : ph_pl[ph];
+  const int o_oy = (NPH == 1) ? i_ooy : ph_oy[ph], o_ox = (NPH == 1) ? i_oox : ph_ox[ph];
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
     const int n = (wave * NBW + j) * 16 + lm;
@@ -270,20 +325,20 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8)) ? 2 : 1)) void 
     const int ty = rem / TW, tx = rem - ty * TW;
     const int vy = vy0 + ty, vx = vx0 + tx, b = b0 + img;
     const bool pok = (vy < vy_end) && (vx < vx_end) && (b < A.B) && (img < IPB);
-    const int pix = vy * A.Wopitch + vx;
+    const int pix = (vy * A.osy + o_oy) * A.Wopitch + vx * A.osx + o_ox;
     float nz = 0.f;
     if (styled && A.noise && pok) nz = nw * A.noise[(A.noise_bstride_on ? (int64_t)b * A.Hout * A.Wout : 0) + vy * A.Wout + vx];
     const int bl = __shfl(b, lane & 48, 64);  // (b, m) is shared by the 16 lanes of a group when THW >= 16
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
-      const f32x4 a4 = acc[i][j];
+      const f32x4 a4 = acc[ph][i][j];
       const float vals[4] = {a4[0], a4[1], a4[2], a4[3]};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + i * 16 + 4 * g + r;
         const bool ok = pok && (m < A.Cout);
         float v = vals[r];
-        const int64_t oidx = ((int64_t)(b * A.Cout + m) * A.NPout + I.out_plane) * HWo + pix;
+        const int64_t oidx = ((int64_t)(b * A.Cout + m) * A.NPout + o_plane) * HWo + pix;
         if constexpr (GS) {  // dgrad: sum (unscaled dgrad) * x over pixels -> gs[b, m]
           float xv = 0.f;
           if (ok) xv = A.aux_x[oidx];
@@ -306,6 +361,7 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8)) ? 2 : 1)) void 
       }
     }
   }
+  }  // phases
   if constexpr (GS) if (gs_block) {   // lanes -> 16-lane groups -> 4 waves (through LDS) -> ONE atomic per (workgroup, channel)
     __syncthreads();  // all MFMA reads of LDS are done; reuse it
     float* red = smem;  // [4 waves][MT]
@@ -373,19 +429,23 @@ static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static int floor4(int v) { return (v >= 0) ? (v & ~3) : -(((-v) + 3) & ~3); }
 
 struct RawTap { int plane, dy, dx, widx; };
-struct RawItem { int ntaps; const RawTap* taps; int out_plane, vy_base, vx_base, Hv, Wv; };
+struct RawItem {
+  int ntaps; const RawTap* taps; int out_plane, vy_base, vx_base, Hv, Wv, ooy = 0, oox = 0;
+  int nph = 1;                                       // 4: fused-phase item, taps ordered by phase
+  int ph_ntaps[4] = {0, 0, 0, 0}, ph_out_plane[4] = {0, 0, 0, 0}, ph_ooy[4] = {0, 0, 0, 0}, ph_oox[4] = {0, 0, 0, 0};
+};
 
-template <int MB, int NV, bool VEC, bool GS>
+template <int MB, int NV, bool VEC, bool GS, int NPH = 1>
 static int launch_conv(ConvArgs& a, size_t smem, dim3 grid, hipStream_t st, const char* what) {
   static bool attr_set[64] = {};  // per device (one process normally drives one GPU)
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<MB, NV, VEC, GS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<MB, NV, VEC, GS, NPH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((k_conv_igemm<MB, NV, VEC, GS>), grid, dim3(256), smem, st, a);
+  hipLaunchKernelGGL((k_conv_igemm<MB, NV, VEC, GS, NPH>), grid, dim3(256), smem, st, a);
   return check_launch(what);
 }
 
@@ -420,9 +480,11 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   a.min_dy = min_dy; a.min_dx = min_dx;
   a.nitems = nitems;
   a.vec = (a.Wpitch % 4 == 0) && (((uintptr_t)a.in) % 16 == 0) ? 1 : 0;
+  const int nph = raw[0].nph;
   const int nblk = a.Mp / 16;
   int mb;
-  if (nblk <= 5) mb = nblk;
+  if (nph == 4) mb = (nblk <= 5) ? nblk : ((nblk % 5 == 0) ? 5 : (nblk % 4 == 0 ? 4 : (nblk % 3 == 0 ? 3 : 4)));
+  else if (nblk <= 5) mb = nblk;
   else if (nblk % 8 == 0) mb = 8;
   else if (nblk % 5 == 0) mb = 5;
   else if (nblk % 4 == 0) mb = 4;
@@ -434,7 +496,8 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   for (int p = 0; p < nitems; ++p) {
     ConvItem& I = a.items[p];
     const RawItem& R = raw[p];
-    I.ntaps = R.ntaps; I.out_plane = R.out_plane;
+    I.ntaps = R.ntaps; I.out_plane = R.out_plane; I.ooy = R.ooy; I.oox = R.oox;
+    for (int q = 0; q < 4; ++q) { I.ph_ntaps[q] = R.ph_ntaps[q]; I.ph_out_plane[q] = R.ph_out_plane[q]; I.ph_ooy[q] = R.ph_ooy[q]; I.ph_oox[q] = R.ph_oox[q]; }
     I.vy_base = R.vy_base; I.vx_base = R.vx_base; I.Hv = R.Hv; I.Wv = R.Wv;
     I.TW = pow2ceil(R.Wv) < 32 ? pow2ceil(R.Wv) : 32;
     if (I.TW < 4) I.TW = 4;  // 1-pixel-wide strips: keep the halo tile short (rows cost a 16-byte unit each)
@@ -500,6 +563,17 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   }
   dim3 grid((unsigned)blocks, mtiles, ks);
   int rc;
+  if (nph == 4) {
+    CAGC_REQUIRE(a.vec && nv <= 4 && !a.gs, "%s: fused-phase path needs the aligned small-tile configuration", what);
+    switch (mb) {
+      case 1: rc = launch_conv<1, 4, true, false, 4>(a, smem, grid, st, what); break;
+      case 2: rc = launch_conv<2, 4, true, false, 4>(a, smem, grid, st, what); break;
+      case 3: rc = launch_conv<3, 4, true, false, 4>(a, smem, grid, st, what); break;
+      case 4: rc = launch_conv<4, 4, true, false, 4>(a, smem, grid, st, what); break;
+      default: rc = launch_conv<5, 4, true, false, 4>(a, smem, grid, st, what); break;
+    }
+    return rc;
+  }
   switch (mb) {
     case 1: rc = launch_conv_nv<1>(a, nv, smem, grid, st, what); break;
     case 2: rc = launch_conv_nv<2>(a, nv, smem, grid, st, what); break;
@@ -519,11 +593,44 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   return rc;
 }
 
+
+// Fused-phase work item for a stride-2 transposed 3x3 conv over the exact H x W main region: taps ordered by phase
+// (py,px) = (0,0),(0,1),(1,0),(1,1) with 4/2/2/1 taps.
+static RawItem fused_phase_item(RawTap* taps9, int H, int W, bool planar_out) {
+  RawItem it{};
+  int n = 0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      const int ph = py * 2 + px;
+      int cnt = 0;
+      for (int jy = 0; jy < (py ? 1 : 2); ++jy)
+        for (int jx = 0; jx < (px ? 1 : 2); ++jx) { taps9[n++] = RawTap{0, -jy, -jx, (py + 2 * jy) * 3 + (px + 2 * jx)}; ++cnt; }
+      it.ph_ntaps[ph] = cnt;
+      it.ph_out_plane[ph] = planar_out ? ph : 0;
+      it.ph_ooy[ph] = planar_out ? 0 : py;
+      it.ph_oox[ph] = planar_out ? 0 : px;
+    }
+  it.ntaps = n; it.taps = taps9; it.out_plane = 0; it.vy_base = 0; it.vx_base = 0; it.Hv = H; it.Wv = W; it.nph = 4;
+  return it;
+}
+// The fused-phase kernel needs the 16-byte staging path with the small (NV = 4) tile: W % 4 == 0 and a 32-wide or
+// whole-row tile; tiny layers that would be split over K keep the per-phase path (atomics).
+static bool fused_phase_ok(int B, int H, int W, int Mp) {
+  // Measured on MI355X (bench_11 vs bench_10): the fused-phase variant needs 4 accumulator sets -> 1 wave / SIMD and
+  // 64-channel tiles, and loses to the per-phase launches at 2 waves / SIMD (up_fwd 7.6 vs 7.0 ms, s2 dgrad 7.5 vs
+  // 6.7 ms per step).  Kept selectable for tuning, off by default.
+  static const bool enabled = getenv("CAGC_FUSED_PHASES") != nullptr;
+  if (!enabled) return false;
+  if (W % 4 != 0 || W < 16) return false;
+  const int64_t tiles = (int64_t)B * cdiv(H, CONV_NT / (W < 32 ? W : 32)) * cdiv(W, 32);
+  return tiles * cdiv(Mp, 64) >= 256;
+}
+
 static void base_args(ConvArgs& a, float* out, const float* in, const float* wp, int B, int K, int M) {
   memset(&a, 0, sizeof(a));
   a.in = in; a.out = out; a.wp = wp;
   a.B = B; a.Cin = K; a.Kp = round_up(K, 4); a.Cout = M; a.Mp = round_up(M, 16);
-  a.NPin = 1; a.NPout = 1; a.isy = 1; a.isx = 1;
+  a.NPin = 1; a.NPout = 1; a.isy = 1; a.isx = 1; a.osy = 1; a.osx = 1;
   a.alpha = 0.2f; a.act_scale = 1.f;
 }
 
@@ -620,7 +727,14 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
     if (hipMemsetAsync(t, 0, bytes, st) != hipSuccess) { set_error("%s: memset failed", what); return CAGC_ERR_LAUNCH; }
   }
   ConvArgs a2 = a;
-  int rc = run_conv(a, items, 4, st, what, false, small);
+  int rc;
+  if (fused_phase_ok(B, H, W, a.Mp)) {
+    RawTap t9[9];
+    RawItem fi = fused_phase_item(t9, H, W, /*planar_out=*/true);
+    rc = run_conv(a, &fi, 1, st, what, false, false);
+  } else {
+    rc = run_conv(a, items, 4, st, what, false, small);
+  }
   if (rc) return rc;
   return run_conv(a2, items + 4, 8, st, what, false, small);
 }
@@ -664,4 +778,70 @@ extern "C" int cagc_modconv_up_dgrad(float* gx, float* gs, const float* gt, cons
     for (int kx = 0; kx < 3; ++kx) taps[n++] = RawTap{(ky & 1) * 2 + (kx & 1), ky / 2, kx / 2, ky * 3 + kx};
   RawItem it{n, taps, 0, 0, 0, H, W};
   return run_conv(a, &it, 1, as_stream(stream), what);
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// Plain (un-modulated) 3x3 stride-2 convolution, no padding — the discriminator's down-sampling conv
+// (reference model.py:683-706: Blur(pad=(2,2)) -> EqualConv2d(stride=2, padding=0)), forward and data gradient.
+// x [B,Cin,Hin,in_pitch] (Hin, Win odd = 2*Ho+1; rows padded to a 16-byte pitch by the fused blur that
+// produces it), out [B,Cout,Ho,Wo].  The data gradient is the stride-2 transposed conv evaluated by output
+// parity (same decomposition as cagc_modconv_up_fwd) and written straight into the strided positions of gx.
+// -------------------------------------------------------------------------------------------------
+extern "C" int cagc_conv3x3s2_fwd(float* out, const float* x, const float* wp, int B, int Cin, int Cout, int Hin, int Win,
+                                  int in_pitch, cagc_stream_t stream) {
+  const char* what = "cagc_conv3x3s2_fwd";
+  CAGC_REQUIRE(out && x && wp, "%s: null tensor", what);
+  CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin >= 3 && Win >= 3 && (Hin & 1) && (Win & 1) && in_pitch >= Win,
+               "%s: bad shape", what);
+  const int Ho = (Hin - 3) / 2 + 1, Wo = (Win - 3) / 2 + 1;
+  ConvArgs a;
+  base_args(a, out, x, wp, B, Cin, Cout);
+  a.isy = 2; a.isx = 2;
+  a.Hin = Hin; a.Win = Win; a.Wpitch = in_pitch; a.Hout = Ho; a.Wout = Wo; a.Wopitch = Wo;
+  RawTap taps[9];
+  int n = 0;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) taps[n++] = RawTap{0, ky, kx, ky * 3 + kx};
+  RawItem it{n, taps, 0, 0, 0, Ho, Wo};
+  return run_conv(a, &it, 1, as_stream(stream), what);
+}
+
+extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_bwd, int B, int Cin, int Cout, int Hin,
+                                    int Win, int out_pitch, cagc_stream_t stream) {
+  const char* what = "cagc_conv3x3s2_dgrad";
+  CAGC_REQUIRE(gx && g && wp_bwd, "%s: null tensor", what);
+  CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin >= 3 && Win >= 3 && (Hin & 1) && (Win & 1) && out_pitch >= Win,
+               "%s: bad shape", what);
+  const int Ho = (Hin - 3) / 2 + 1, Wo = (Win - 3) / 2 + 1;
+  ConvArgs a;
+  base_args(a, gx, g, wp_bwd, B, /*K=*/Cout, /*M=*/Cin);
+  a.Hin = Ho; a.Win = Wo; a.Wpitch = Wo;
+  a.Hout = Hin; a.Wout = Win; a.Wopitch = out_pitch; a.osy = 2; a.osx = 2;
+  // gx[i, 2m+py, 2n+px] = sum_o sum_{jy,jx} W[o,i,py+2jy,px+2jx] g[o, m-jy, n-jx]
+  RawTap taps[4][4];
+  RawItem main_items[4], strip_items[5];
+  int ns = 0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      const int ph = py * 2 + px;
+      int n = 0;
+      for (int jy = 0; jy < (py ? 1 : 2); ++jy)
+        for (int jx = 0; jx < (px ? 1 : 2); ++jx) taps[ph][n++] = RawTap{0, -jy, -jx, (py + 2 * jy) * 3 + (px + 2 * jx)};
+      main_items[ph] = RawItem{n, taps[ph], 0, 0, 0, Ho, Wo, py, px};
+      if (py == 0) strip_items[ns++] = RawItem{n, taps[ph], 0, Ho, 0, 1, px ? Wo : Wo + 1, py, px};  // row Y = 2*Ho
+      if (px == 0) strip_items[ns++] = RawItem{n, taps[ph], 0, 0, Wo, Ho, 1, py, px};                // col X = 2*Wo
+    }
+  hipStream_t st = as_stream(stream);
+  ConvArgs a2 = a;
+  int rc;
+  if (fused_phase_ok(B, Ho, Wo, a.Mp)) {
+    RawTap t9[9];
+    RawItem fi = fused_phase_item(t9, Ho, Wo, /*planar_out=*/false);
+    rc = run_conv(a, &fi, 1, st, what, false, false);
+  } else {
+    rc = run_conv(a, main_items, 4, st, what, false, false);
+  }
+  if (rc) return rc;
+  return run_conv(a2, strip_items, ns, st, what, false, false);
 }

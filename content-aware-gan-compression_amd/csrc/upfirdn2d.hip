@@ -47,8 +47,9 @@ constexpr int FT = 32;  // output tile edge
 
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void k_fir_s1(float* __restrict__ out, const float* __restrict__ x,
-                                                const float* __restrict__ kern, int in_h, int in_w, int out_h,
-                                                int out_w, int pad_x0, int pad_y0, int tiles_x, int tiles_y) {
+                                                const float* __restrict__ kern, int in_h, int in_w, int in_pitch,
+                                                int out_h, int out_w, int out_pitch, int pad_x0, int pad_y0,
+                                                int tiles_x, int tiles_y) {
   constexpr int IH = FT + KH - 1, IW = FT + KW - 1, LW = IW + 1;
   __shared__ float tile[IH * LW];
   __shared__ float kf[KH * KW];
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void k_fir_s1(float* __restrict__ out, const f
   bid /= tiles_x;
   const int ty0 = (bid % tiles_y) * FT;
   const int64_t p = bid / tiles_y;
-  const float* xp = x + p * (int64_t)in_h * in_w;
+  const float* xp = x + p * (int64_t)in_h * in_pitch;
   if (threadIdx.x < KH * KW) {
     const int i = threadIdx.x / KW, j = threadIdx.x % KW;
     kf[threadIdx.x] = kern[(KH - 1 - i) * KW + (KW - 1 - j)];
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void k_fir_s1(float* __restrict__ out, const f
     const int r = e / IW, c = e - r * IW;
     const int iy = ty0 + r - pad_y0, ix = tx0 + c - pad_x0;
     float v = 0.f;
-    if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(int64_t)iy * in_w + ix];
+    if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(int64_t)iy * in_pitch + ix];
     tile[r * LW + c] = v;
   }
   __syncthreads();
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_fir_s1(float* __restrict__ out, const f
   // the stores coalesce for any (odd) output width
   const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
   const int ox = tx0 + lx;
-  if (ox >= out_w) return;
+  if (ox >= out_pitch) return;
   float win[KH + 3][KW];
 #pragma unroll
   for (int r = 0; r < KH + 3; ++r)
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void k_fir_s1(float* __restrict__ out, const f
       for (int i = 0; i < KH; ++i)
 #pragma unroll
         for (int j = 0; j < KW; ++j) acc += win[q + i][j] * kf[i * KW + j];
-      out[(p * out_h + oy) * (int64_t)out_w + ox] = acc;
+      out[(p * out_h + oy) * (int64_t)out_pitch + ox] = ox < out_w ? acc : 0.f;   // pitch padding is written as zero
     }
   }
 }
@@ -227,8 +228,8 @@ extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, i
     const int tx = cdiv(out_w, FT), ty = cdiv(out_h, FT);
     const int64_t nb = planes * tx * ty;
     CAGC_REQUIRE(nb < (1ll << 31), "cagc_upfirdn2d: too large");
-    hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w,
-                       pad_x0, pad_y0, tx, ty);
+    hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w, out_h, out_w,
+                       out_w, pad_x0, pad_y0, tx, ty);
   } else {
     const int64_t total = planes * out_h * out_w;
     const int64_t nb = (total + 255) / 256;
@@ -262,4 +263,22 @@ extern "C" int cagc_blur_up_bwd(float* gt, const float* gz, const float* fir, in
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_blur_up_bwd: too large");
   hipLaunchKernelGGL(k_blur_up_bwd, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), gt, gz, fir, H, W, tx, ty);
   return check_launch("cagc_blur_up_bwd");
+}
+
+
+// 4x4 FIR (up = down = 1) between tensors whose rows are padded to a pitch: the blur in front of / behind the
+// hand-written stride-2 conv, whose 2H+1-wide operand is kept at a 16-byte row pitch.
+extern "C" int cagc_fir4x4_pitched(float* out, const float* x, const float* kernel, int64_t planes, int in_h, int in_w,
+                                   int in_pitch, int out_h, int out_w, int out_pitch, int pad_x0, int pad_y0,
+                                   cagc_stream_t stream) {
+  CAGC_REQUIRE(out && x && kernel, "cagc_fir4x4_pitched: null tensor");
+  CAGC_REQUIRE(planes >= 0 && in_h > 0 && in_w > 0 && in_pitch >= in_w && out_h > 0 && out_w > 0 && out_pitch >= out_w,
+               "cagc_fir4x4_pitched: bad shape");
+  if (planes == 0) return CAGC_OK;
+  const int tx = cdiv(out_pitch, FT), ty = cdiv(out_h, FT);
+  const int64_t nb = planes * tx * ty;
+  CAGC_REQUIRE(nb < (1ll << 31), "cagc_fir4x4_pitched: too large");
+  hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, x, kernel, in_h, in_w,
+                     in_pitch, out_h, out_w, out_pitch, pad_x0, pad_y0, tx, ty);
+  return check_launch("cagc_fir4x4_pitched");
 }

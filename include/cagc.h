@@ -179,6 +179,25 @@ int cagc_modconv_wgrad(float* gweight, float* workspace, const float* g, const f
                        cagc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Discriminator down-sampling conv  replaces the reference's Blur(pad=(2,2)) -> EqualConv2d(3x3, stride 2,
+ *                                   padding 0) pair (model.py:683-706; there: upfirdn2d + cuDNN) where it sits
+ *                                   on the KD step's path (D forward + data gradient, D frozen).
+ * cagc_fir4x4_pitched: 4x4 FIR, up = down = 1, between tensors with a row pitch (in floats): the blurred
+ *   2H+1-wide operand is kept at a 16-byte row pitch so the conv can stage it with 16-byte loads; columns
+ *   [out_w, out_pitch) are written as zero.
+ * cagc_conv3x3s2_fwd:   out [B,Cout,Ho,Wo] = conv3x3(x [B,Cin,Hin,in_pitch], stride 2, no padding), Hin/Win odd,
+ *   Ho = (Hin-3)/2+1; wp = wp_fwd of cagc_modconv_prep (weights pre-multiplied by the equalised-lr scale).
+ * cagc_conv3x3s2_dgrad: gx [B,Cin,Hin,out_pitch] (every valid element written) from g [B,Cout,Ho,Wo]; wp_bwd.
+ * ---------------------------------------------------------------------------------------------- */
+int cagc_fir4x4_pitched(float* out, const float* x, const float* kernel, int64_t planes, int in_h, int in_w,
+                        int in_pitch, int out_h, int out_w, int out_pitch, int pad_x0, int pad_y0,
+                        cagc_stream_t stream);
+int cagc_conv3x3s2_fwd(float* out, const float* x, const float* wp, int B, int Cin, int Cout, int Hin, int Win,
+                       int in_pitch, cagc_stream_t stream);
+int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_bwd, int B, int Cin, int Cout, int Hin,
+                         int Win, int out_pitch, cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * ToRGB                             replaces model.py:380-395 (1x1 modconv, no demod, + bias +
  *                                   Upsample(skip) = upfirdn2d(up=2, pad=(2,1), 4x4 FIR x4)).
  * x [B,C,H,W], w [3,C] (= conv.weight[0,:,:,0,0]), s [B,C], bias [3], skip [B,3,H/2,W/2] [nullable],

@@ -369,3 +369,41 @@ def test_graphed_kd_step_matches_eager_step():
         for k in pe:
             assert_close(pg[k].grad, pe[k].grad, 5e-4 if pe[k].numel() > 1 else 3e-3, f"graph grad {k}")  # atomics order differs run to run
             assert_close(pg[k].detach(), pe[k].detach(), 1e-4, f"graph param {k}")
+
+
+@pytest.mark.parametrize("cfg", [(2, 128, 256, 64, 64), (3, 20, 36, 18, 18), (1, 512, 512, 8, 8), (16, 128, 256, 256, 256)])
+def test_discriminator_downsample_conv_vs_oracle(cfg):
+    """Blur(pad 2,2) -> 3x3 stride-2 EqualConv2d -> FusedLeakyReLU on the hand-written MFMA path vs the oracle
+    (forward + input gradient + weight gradient through the stock fallback)."""
+    B, cin, cout, H, W = cfg
+    torch.manual_seed(8)
+    layer = M.ConvLayer(cin, cout, 3, downsample=True)
+    with torch.no_grad():
+        layer[2].bias.copy_(0.1 * torch.randn(cout))
+    sd = {"l." + k: v.detach().clone() for k, v in layer.state_dict().items()}
+    x = torch.randn(B, cin, H, W)
+    big = B * cin * H * W > 50_000_000
+    lg = layer.to(DEV)
+    xg = cu(x).requires_grad_(True)
+    yg = lg(xg)
+    go = torch.randn(yg.shape)
+    if big:   # CPU oracle too slow at bs 16 x 256^2: linearity of the (conv o blur) in x instead, on the raw conv
+        for p in lg.parameters():
+            p.requires_grad_(False)
+        with torch.no_grad():
+            lg[2].bias.zero_()
+            y1 = lg(cu(x))
+            y2 = lg(2 * cu(x))
+        assert_close(y2, 2 * y1, 1e-5, "homogeneity")
+        return
+    xr = x.clone().requires_grad_(True)
+    yr = ref_model._conv_layer(sd, "l", xr, 3, downsample=True)
+    (gxr,) = torch.autograd.grad(yr, xr, go)
+    assert_close(yg, yr, TOL, "out")
+    gxg, gwg = torch.autograd.grad(yg, [xg, lg[1].weight], cu(go))
+    assert_close(gxg, gxr, TOL, "grad x")
+    wr = sd["l.1.weight"].clone().requires_grad_(True)
+    sd2 = dict(sd)
+    sd2["l.1.weight"] = wr
+    (gwr,) = torch.autograd.grad(ref_model._conv_layer(sd2, "l", x, 3, downsample=True), wr, go)
+    assert_close(gwg, gwr, TOL, "grad weight")
