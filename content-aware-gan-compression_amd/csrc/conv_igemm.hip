@@ -380,6 +380,20 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8) && NPH == 1) ? 2
   }
 }
 
+// zero one row and one column of every plane [planes][H][pitch] (the strip regions of the transposed-conv outputs,
+// so that the strip launches may split K and accumulate with atomics)
+__global__ __launch_bounds__(256) void k_zero_rowcol(float* __restrict__ out, int64_t planes, int H, int W, int pitch,
+                                                     int row, int col) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per = H + W;
+  if (idx >= planes * per) return;
+  const int64_t p = idx / per;
+  const int e = (int)(idx - p * per);
+  float* base = out + p * (int64_t)H * pitch;
+  if (e < W) base[(int64_t)row * pitch + e] = 0.f;
+  else base[(int64_t)(e - W) * pitch + col] = 0.f;
+}
+
 // deferred styled epilogue for the split-K path: out = lrelu(out*d + nw*noise + bias) * act_scale, in place
 __global__ __launch_bounds__(256) void k_styled_epilogue(float* __restrict__ out, const float* __restrict__ d,
                                                          const float* __restrict__ noise, int noise_bstride_on,
@@ -559,7 +573,7 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   const int nv = cdiv(max_units, 256);
   if (ks > 1 && zero_out) {
     const size_t bytes = sizeof(float) * (size_t)a.B * a.Cout * a.NPout * a.Hout * a.Wopitch;
-    if (hipMemsetAsync(a.out, 0, bytes, st) != hipSuccess) { set_error("%s: memset failed", what); return CAGC_ERR_LAUNCH; }
+    { int zrc = zero_fill(a.out, bytes, st); if (zrc) return zrc; }
   }
   dim3 grid((unsigned)blocks, mtiles, ks);
   int rc;
@@ -724,7 +738,7 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   const bool small = (int64_t)B * H * W <= 32768;   // only small layers are ever split over K
   if (small) {
     const size_t bytes = sizeof(float) * (size_t)B * Cout * 4 * (H + 1) * a.Wopitch;
-    if (hipMemsetAsync(t, 0, bytes, st) != hipSuccess) { set_error("%s: memset failed", what); return CAGC_ERR_LAUNCH; }
+    { int zrc = zero_fill(t, bytes, st); if (zrc) return zrc; }
   }
   ConvArgs a2 = a;
   int rc;
@@ -736,7 +750,12 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
     rc = run_conv(a, items, 4, st, what, false, small);
   }
   if (rc) return rc;
-  return run_conv(a2, items + 4, 8, st, what, false, small);
+  if (!small) {   // strips: few workgroups with long K loops -> split K; zero just the strip regions first
+    const int64_t planes = (int64_t)B * Cout * 4;
+    hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (H + 1 + W + 1), 256)), dim3(256), 0, st, t, planes, H + 1,
+                       W + 1, a.Wopitch, H, W);
+  }
+  return run_conv(a2, items + 4, 8, st, what, false, true);
 }
 
 extern "C" int cagc_modconv_dgrad(float* gx, float* gs, const float* gz, const float* wp, const float* s, const float* x,
@@ -843,5 +862,10 @@ extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_b
     rc = run_conv(a, main_items, 4, st, what, false, false);
   }
   if (rc) return rc;
-  return run_conv(a2, strip_items, ns, st, what, false, false);
+  {
+    const int64_t planes = (int64_t)B * Cin;
+    hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (Hin + Win), 256)), dim3(256), 0, st, gx, planes, Hin, Win,
+                       out_pitch, Hin - 1, Win - 1);
+  }
+  return run_conv(a2, strip_items, ns, st, what, false, true);
 }

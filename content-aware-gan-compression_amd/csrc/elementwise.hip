@@ -349,10 +349,7 @@ extern "C" int cagc_styled_act_bwd(float* gz, float* red, const float* gout, con
   CAGC_REQUIRE(!noise || noise_batch == 1 || noise_batch == B, "cagc_styled_act_bwd: noise batch %d not in {1,%d}",
                noise_batch, B);
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(red, 0, sizeof(float) * 3 * (size_t)B * C, st) != hipSuccess) {
-    set_error("cagc_styled_act_bwd: memset failed");
-    return CAGC_ERR_LAUNCH;
-  }
+  { int zrc = zero_fill(red, sizeof(float) * 3 * (size_t)B * C, st); if (zrc) return zrc; }
   const int nchunk = cdiv(HW, EW_CHUNK);
   const int64_t nb = (int64_t)B * C * nchunk;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_styled_act_bwd: too large");

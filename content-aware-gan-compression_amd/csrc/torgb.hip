@@ -164,10 +164,7 @@ extern "C" int cagc_torgb_bwd(float* gx, float* gws, const float* g, const float
   CAGC_REQUIRE(gx && gws && g && x && w && s, "%s: null tensor", what);
   CAGC_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "%s: bad shape", what);
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(gws, 0, sizeof(float) * (size_t)B * 3 * C, st) != hipSuccess) {
-    set_error("%s: memset failed", what);
-    return CAGC_ERR_LAUNCH;
-  }
+  { int zrc = zero_fill(gws, sizeof(float) * (size_t)B * 3 * C, st); if (zrc) return zrc; }
   const int64_t HW = (int64_t)H * W;
   const int nchunk = cdiv(C, RGB_CCH);
   int nsplit = (2048 + B * nchunk - 1) / (B * nchunk);
