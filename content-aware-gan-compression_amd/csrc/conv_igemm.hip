@@ -53,6 +53,7 @@ struct ConvItem {
                                  // channel-plane stride, rows per chunk (= CK*NPin*IPB*IH)
   int xoff;                      // LDS column of the tile's first needed input column (alignment slack)
   int ooy, oox;                  // output pixel = (vy*osy + ooy, vx*osx + oox)
+  int ks;                        // K split of this item: ks workgroups per tile, partial sums combined with atomics
   // multi-phase items (NPH = 4: all output parities of a stride-2 transposed conv in ONE workgroup, sharing the
   // staged input tile): taps are ordered by phase, phase p owns ph_ntaps[p] consecutive taps
   int ph_ntaps[4], ph_out_plane[4], ph_ooy[4], ph_oox[4];
@@ -102,6 +103,9 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8) && NPH == 1) ? 2
   while (item < A.nitems - 1 && (int)blockIdx.x >= A.items[item].block_end) ++item;
   const ConvItem& I = A.items[item];
   int bid = blockIdx.x - (item ? A.items[item - 1].block_end : 0);
+  const int ksplit = I.ks;
+  const int ksi = bid % ksplit;
+  bid /= ksplit;
   const int tx_i = bid % I.tiles_x;
   bid /= I.tiles_x;
   const int ty_i = bid % I.tiles_y;
@@ -128,8 +132,8 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8) && NPH == 1) ? 2
 
   // ---- K range of this split --------------------------------------------------------------------------
   const int nchunks = (A.Kp + CK - 1) / CK;
-  const int cps = (nchunks + A.ksplit - 1) / A.ksplit;
-  const int kc_lo = blockIdx.z * cps * CK;
+  const int cps = (nchunks + ksplit - 1) / ksplit;
+  const int kc_lo = ksi * cps * CK;
   int kc_hi = kc_lo + cps * CK;
   if (kc_hi > nchunks * CK) kc_hi = nchunks * CK;
 
@@ -274,8 +278,8 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8) && NPH == 1) ? 2
 
   // ---- epilogue: lane holds channels m0 + i*16 + 4g + r (r = 0..3) of pixel n ------------------------------
   const int HWo = A.Hout * A.Wopitch;
-  const bool styled = (A.epi == CAGC_EPI_STYLED) && (A.ksplit == 1);
-  const bool atomic_out = A.ksplit > 1;
+  const bool styled = (A.epi == CAGC_EPI_STYLED) && (ksplit == 1);
+  const bool atomic_out = ksplit > 1;
   const float nw = (styled && A.noise) ? A.noise_w[0] : 0.f;
   const bool gs_block = GS && (IPB == 1);   // whole tile in one image: reduce per workgroup
   float gpart[GS ? MB : 1][4];
@@ -446,6 +450,7 @@ struct RawTap { int plane, dy, dx, widx; };
 struct RawItem {
   int ntaps; const RawTap* taps; int out_plane, vy_base, vx_base, Hv, Wv, ooy = 0, oox = 0;
   int nph = 1;                                       // 4: fused-phase item, taps ordered by phase
+  int strip = 0;                                     // thin edge strip: own K split (caller zeroes the region)
   int ph_ntaps[4] = {0, 0, 0, 0}, ph_out_plane[4] = {0, 0, 0, 0}, ph_ooy[4] = {0, 0, 0, 0}, ph_oox[4] = {0, 0, 0, 0};
 };
 
@@ -553,21 +558,33 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
       I.taps[t].lds_off = R.taps[t].plane * (I.IPB * I.IH * I.IWp) + (R.taps[t].dy - min_dy) * I.IWp + (R.taps[t].dx - min_dx);
       I.taps[t].widx = R.taps[t].widx;
     }
-    blocks += cdiv(a.B, I.IPB) * I.tiles_x * I.tiles_y;
-    I.block_end = blocks;
+    I.ks = 1;
+  }
+  // K split: a launch that cannot fill the chip (4x4 .. 16x16 layers, edge strips) is split uniformly.  (Splitting
+  // the strips further, up to 16 ways, measured slower: bench_15 vs bench_13.)
+  const int nchunks = cdiv(a.Kp, CONV_CK);
+  {
+    const int mt = cdiv(a.Mp, MT);
+    int tiles_all = 0;
+    for (int p = 0; p < nitems; ++p) tiles_all += cdiv(a.B, a.items[p].IPB) * a.items[p].tiles_x * a.items[p].tiles_y;
+    int ks = 1;
+    if (allow_split && tiles_all * mt < 256 && nchunks >= 4) {
+      ks = cdiv(512, tiles_all * mt);
+      if (ks > nchunks / 2) ks = nchunks / 2;
+      if (ks < 1) ks = 1;
+    }
+    a.ksplit = ks;
+    for (int p = 0; p < nitems; ++p) {
+      ConvItem& I = a.items[p];
+      I.ks = ks;
+      blocks += cdiv(a.B, I.IPB) * I.tiles_x * I.tiles_y * I.ks;
+      I.block_end = blocks;
+    }
   }
   const int64_t in_elems = (int64_t)a.B * a.Cin * a.NPin * a.Hin * a.Wpitch;
   CAGC_REQUIRE(in_elems < (1ll << 31), "%s: input tensor too large for 32-bit offsets", what);
-  // split-K when the pixel/channel tiling cannot fill the chip
   const int mtiles = cdiv(a.Mp, MT);
-  const int nchunks = cdiv(a.Kp, CONV_CK);
-  int ks = 1;
-  if (allow_split && blocks * mtiles < 256 && nchunks >= 4) {
-    ks = cdiv(512, blocks * mtiles);
-    if (ks > nchunks / 2) ks = nchunks / 2;
-    if (ks < 1) ks = 1;
-  }
-  a.ksplit = ks;
+  const int ks = a.ksplit;
   const size_t smem = sizeof(float) * ((size_t)MAX_TAPS * CONV_CK * LDA + (size_t)CONV_CK * max_ps);
   CAGC_REQUIRE(smem <= 160 * 1024, "%s: LDS tile %zu B too large", what, smem);
   const int nv = cdiv(max_units, 256);
@@ -575,7 +592,7 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
     const size_t bytes = sizeof(float) * (size_t)a.B * a.Cout * a.NPout * a.Hout * a.Wopitch;
     { int zrc = zero_fill(a.out, bytes, st); if (zrc) return zrc; }
   }
-  dim3 grid((unsigned)blocks, mtiles, ks);
+  dim3 grid((unsigned)blocks, mtiles, 1);
   int rc;
   if (nph == 4) {
     CAGC_REQUIRE(a.vec && nv <= 4 && !a.gs, "%s: fused-phase path needs the aligned small-tile configuration", what);
@@ -755,6 +772,7 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
     hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (H + 1 + W + 1), 256)), dim3(256), 0, st, t, planes, H + 1,
                        W + 1, a.Wopitch, H, W);
   }
+  for (int q = 4; q < 12; ++q) items[q].strip = 1;
   return run_conv(a2, items + 4, 8, st, what, false, true);
 }
 
@@ -867,5 +885,6 @@ extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_b
     hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (Hin + Win), 256)), dim3(256), 0, st, gx, planes, Hin, Win,
                        out_pitch, Hin - 1, Win - 1);
   }
+  for (int q = 0; q < ns; ++q) strip_items[q].strip = 1;
   return run_conv(a2, strip_items, ns, st, what, false, true);
 }
