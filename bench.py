@@ -53,6 +53,28 @@ def conv_flops(name, a):
     return 0.0
 
 
+def pmc_traffic(symbol):
+    """HBM-side bytes per launch of `symbol` from the committed rocprofv3 PMC passes (profiles/r01_pmc_*.md; separate
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same bench, counters in KB).  gfx950 correction
+    (MI355X_MICROARCH.md §HBM, re-calibrated here on the bias+act stream kernel whose byte count is known exactly:
+    FETCH_SIZE reads 0.50x, WRITE_SIZE 1.00x of the true bytes): bytes = 2*FETCH + WRITE."""
+    vals = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(ROOT, "profiles", f"r01_pmc_{c}.md")
+        if not os.path.exists(path):
+            return None, "no committed PMC summary"
+        for line in open(path):
+            cols = [x.strip() for x in line.split("|")]
+            if len(cols) > 6 and symbol in cols[1] and cols[2] == c:
+                vals[c] = float(cols[4]) * 1024.0 / float(cols[3])
+    if len(vals) != 2:
+        return None, "kernel not found in PMC summary"
+    return int(2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]), (
+        f"avg bytes/launch of {symbol} (the MFMA kernel behind cagc_modconv_fwd/up_fwd/conv3x3s2) from rocprofv3 --pmc "
+        f"passes: 2x FETCH_SIZE + WRITE_SIZE; MFMA-bound kernel, re-reads of the input halo tile by the 4 channel tiles "
+        f"are served by L2/MALL")
+
+
 class KernelTimer:
     """HIP-event timing of every libcagc entry point, on the stream the kernels are launched on."""
 
@@ -197,9 +219,10 @@ def main():
             mfma = {k: v for k, v in agg.items() if v[2] > 0}
             name, (cnt, tot_ms, flops) = max(mfma.items(), key=lambda kv: kv[1][1])
             ach = flops / (tot_ms * 1e-3) / 1e12
+            traffic, traffic_note = pmc_traffic("k_conv_igemm<8, 4, true, false, 1>")
             roof = {"bound": "mfma", "kernel": name + " (k_conv_igemm, v_mfma_f32_16x16x4_f32)",
                     "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "launches_per_step": cnt // 3, "avg_launch_ms": round(tot_ms / cnt, 4),
                     "flops_per_launch_avg": flops / cnt,
                     "cagc_kernel_ms_per_step": {k: round(v[1] / 3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}

@@ -78,6 +78,7 @@ struct ConvArgs {
   int osy, osx;                // output stride (2 for the data gradient of a stride-2 conv, else 1)
   int min_dy, min_dx;
   int nitems, ksplit, vec;     // vec: 16-byte staging loads are legal (Wpitch % 4 == 0)
+  int nblocks, mtiles;         // pixel-tile workgroups (incl. K splits) and channel tiles; grid = nblocks * mtiles
   int epi, noise_bstride_on;
   float alpha, act_scale;
   ConvItem items[MAX_ITEMS];
@@ -98,11 +99,24 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8) && NPH == 1) ? 2
   const int lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
 
-  // ---- workgroup -> (item, image group, tile) : uniform -------------------------------------------
+  // ---- workgroup -> (pixel tile, channel tile) : XCD-aware -----------------------------------------------
+  // Workgroup id w runs on XCD w % 8 (observed dispatch order; used for speed only).  The `mtiles` channel tiles of
+  // one pixel tile read the same input halo tile: give them consecutive slots of ONE XCD so the tile is fetched
+  // from HBM/MALL once and re-read from that XCD's L2.
+  int pix_id, mtile;
+  {
+    const int w = blockIdx.x, nx = A.nblocks, mt = A.mtiles;
+    const int full = (nx / 8) * 8;                  // pixel tiles that take part in the 8-way interleave
+    const int s = w / 8, xcd = w - s * 8;
+    const int p = (s / mt) * 8 + xcd;
+    if (w < full * mt && p < full) { pix_id = p; mtile = s % mt; }
+    else { const int r = w - full * mt; pix_id = full + r / mt; mtile = r % mt; }   // tail: plain order
+  }
+  // ---- pixel tile -> (item, image group, tile) : uniform -------------------------------------------
   int item = 0;
-  while (item < A.nitems - 1 && (int)blockIdx.x >= A.items[item].block_end) ++item;
+  while (item < A.nitems - 1 && pix_id >= A.items[item].block_end) ++item;
   const ConvItem& I = A.items[item];
-  int bid = blockIdx.x - (item ? A.items[item - 1].block_end : 0);
+  int bid = pix_id - (item ? A.items[item - 1].block_end : 0);
   const int ksplit = I.ks;
   const int ksi = bid % ksplit;
   bid /= ksplit;
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8) && NPH == 1) ? 2
   const int TH = I.TH, TW = I.TW, IPB = I.IPB, IH = I.IH, IWp = I.IWp, PS = I.PS;
   const int vx0 = I.vx_base + tx_i * TW, vy0 = I.vy_base + ty_i * TH;
   const int vx_end = I.vx_base + I.Wv, vy_end = I.vy_base + I.Hv;
-  const int m0 = blockIdx.y * MT;
+  const int m0 = mtile * MT;
   const int ntaps = I.ntaps;
   const int ph_nt[4] = {I.ph_ntaps[0], I.ph_ntaps[1], I.ph_ntaps[2], I.ph_ntaps[3]};
   const int ph_pl[4] = {I.ph_out_plane[0], I.ph_out_plane[1], I.ph_out_plane[2], I.ph_out_plane[3]};
@@ -592,7 +606,9 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
     const size_t bytes = sizeof(float) * (size_t)a.B * a.Cout * a.NPout * a.Hout * a.Wopitch;
     { int zrc = zero_fill(a.out, bytes, st); if (zrc) return zrc; }
   }
-  dim3 grid((unsigned)blocks, mtiles, 1);
+  a.nblocks = blocks; a.mtiles = mtiles;
+  CAGC_REQUIRE((int64_t)blocks * mtiles < (1ll << 31), "%s: grid too large", what);
+  dim3 grid((unsigned)(blocks * mtiles), 1, 1);
   int rc;
   if (nph == 4) {
     CAGC_REQUIRE(a.vec && nv <= 4 && !a.gs, "%s: fused-phase path needs the aligned small-tile configuration", what);
