@@ -90,6 +90,107 @@ class KDStep:
         return self.g_step(zs, inj, mask)
 
 
+def d_logistic_loss(real_pred, fake_pred):
+    """reference train.py:187-191."""
+    return F.softplus(-real_pred).mean() + F.softplus(fake_pred).mean()
+
+
+def d_r1_loss(real_pred, real_img):
+    """reference train.py:194-200 (double backward through D)."""
+    (grad_real,) = torch.autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
+    return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
+
+
+def accumulate(model_ema, model, decay=0.999):
+    """EMA of the generator weights — reference train.py:124-129 (its add_(Number, Tensor) overload is gone from
+    current PyTorch; same arithmetic)."""
+    pe, pm = dict(model_ema.named_parameters()), dict(model.named_parameters())
+    with torch.no_grad():
+        torch._foreach_mul_(list(pe.values()), decay)
+        torch._foreach_add_(list(pe.values()), [pm[k].detach() for k in pe], alpha=1 - decay)
+
+
+class TrainIteration(KDStep):
+    """The rest of one reference training iteration around the KD generator step (reference train.py:371-398):
+    D step (:241-262), lazy R1 every `d_reg_every` (:264-278), G+KD step (KDStep.g_step), lazy path-length
+    regulariser every `g_reg_every` (:310-338), EMA (:398).  Second-order passes (R1 through D, path length through
+    G) run on the twice-differentiable composed ops (`composed_autograd`), whose upfirdn2d / fused-act members are
+    still the HIP kernels."""
+
+    def __init__(self, student, teacher, discriminator, g_ema=None, lr=0.002, r1=10.0, path_regularize=2.0,
+                 path_batch_shrink=2, g_reg_every=4, d_reg_every=16, **kw):
+        super().__init__(student, teacher, discriminator, lr=lr, g_reg_every=g_reg_every, **kw)
+        self.g_ema = g_ema
+        self.r1, self.path_regularize, self.path_batch_shrink = r1, path_regularize, path_batch_shrink
+        self.g_reg_every, self.d_reg_every = g_reg_every, d_reg_every
+        c = d_reg_every / (d_reg_every + 1)
+        dparams = list(discriminator.parameters())
+        kwd = {"fused": True} if dparams[0].device.type == "cuda" else {}
+        self.d_optim = torch.optim.Adam(dparams, lr=lr * c, betas=(0.0 ** c, 0.99 ** c), **kwd)
+        self.mean_path_length = 0.0
+        self.accum = 0.5 ** (32 / (10 * 1000))
+
+    def d_step(self, real_img, zs, inject_index=None, noise=None):
+        requires_grad(self.student, False)
+        requires_grad(self.disc, True)
+        fake_img = self.student(zs, inject_index=inject_index, noise=noise)
+        fake_pred = self.disc(fake_img)
+        real_pred = self.disc(real_img)
+        d_loss = d_logistic_loss(real_pred, fake_pred)
+        self.d_optim.zero_grad(set_to_none=True)
+        d_loss.backward()
+        self.d_optim.step()
+        return {"d": d_loss.detach(), "real_score": real_pred.mean().detach(), "fake_score": fake_pred.mean().detach()}
+
+    def d_reg(self, real_img):
+        requires_grad(self.disc, True)
+        real_img = real_img.detach().requires_grad_(True)
+        with mc.composed_autograd():
+            real_pred = self.disc(real_img)
+            r1_loss = d_r1_loss(real_pred, real_img)
+            self.d_optim.zero_grad(set_to_none=True)
+            (self.r1 / 2 * r1_loss * self.d_reg_every + 0 * real_pred[0]).backward()
+        self.d_optim.step()
+        return r1_loss.detach()
+
+    def g_reg(self, zs, inject_index=None, noise=None):
+        requires_grad(self.student, True)
+        fake_img, path_lengths = self.student(zs, PPL_regularize=True, inject_index=inject_index, noise=noise)
+        path_mean = self.mean_path_length + 0.01 * (path_lengths.mean() - self.mean_path_length)
+        path_loss = (path_lengths - path_mean).pow(2).mean()
+        self.mean_path_length = path_mean.detach()
+        self.optim.zero_grad(set_to_none=True)
+        weighted = self.path_regularize * self.g_reg_every * path_loss
+        if self.path_batch_shrink:
+            weighted = weighted + 0 * fake_img[0, 0, 0, 0]
+        weighted.backward()
+        self.optim.step()
+        return path_loss.detach(), path_lengths.detach()
+
+    def ema(self):
+        if self.g_ema is not None:
+            accumulate(self.g_ema, self.student.module if hasattr(self.student, "module") else self.student, self.accum)
+
+    def iteration(self, it, real_img, mask, rng=random, generator=None):
+        """One full iteration on sampled latents (bench secondary figure)."""
+        dev, B = mask.device, real_img.shape[0]
+        out = {}
+        zs, _ = (lambda z: (z, None))(  # D step uses plain mixing_noise (train.py:249): the forward draws the index
+            list(torch.randn(2, B, self.latent, device=dev, generator=generator).unbind(0))
+            if (self.mixing > 0 and rng.random() < self.mixing) else [torch.randn(B, self.latent, device=dev, generator=generator)])
+        out.update(self.d_step(real_img, zs))
+        if it % self.d_reg_every == 0:
+            out["r1"] = self.d_reg(real_img)
+        out.update(self.sample_and_step(B, mask, rng, generator))
+        if it % self.g_reg_every == 0:
+            pb = max(1, B // self.path_batch_shrink)
+            zs = (list(torch.randn(2, pb, self.latent, device=dev, generator=generator).unbind(0))
+                  if (self.mixing > 0 and rng.random() < self.mixing) else [torch.randn(pb, self.latent, device=dev, generator=generator)])
+            out["path"], _ = self.g_reg(zs)
+        self.ema()
+        return out
+
+
 class GraphedKDStep(KDStep):
     """The same step replayed from HIP graphs (torch.cuda.CUDAGraph): one graph holds latent sampling, student /
     teacher / D forward, the losses and the whole backward; after it the (optional) gradient all-reduce runs as ONE

@@ -455,8 +455,150 @@ def gold_contract():
     save("prune_chain_tiny", **arrs)
 
 
+
+# ----------------------------------------------------------------------------------------------
+# 8. one full training iteration (train.py:371-398): D step, R1, G+KD step, path-length reg, EMA
+# ----------------------------------------------------------------------------------------------
+def gold_train_iter():
+    from Miscellaneous.distributed import reduce_sum, get_world_size
+    student = make_tiny_generator(800, shape=[5, 5, 4, 4, 3, 3, 2, 2])
+    g_ema = make_tiny_generator(800, shape=[5, 5, 4, 4, 3, 3, 2, 2])
+    teacher = make_tiny_generator(801)
+    teacher.eval()
+    for p in teacher.parameters():
+        p.requires_grad = False
+    torch.manual_seed(802)
+    disc = ref_model.Discriminator(TINY["size"])
+    B = 4
+    ns = dict(torch=torch, F=F, autograd=autograd, random=random, device="cpu", math=__import__("math"),
+              Batch_Img_Parsing=Batch_Img_Parsing, Get_Masked_Tensor=Get_Masked_Tensor, reduce_sum=reduce_sum,
+              get_world_size=get_world_size, train_hyperparams=types.SimpleNamespace(LPIPS_IMAGE_SIZE=256))
+    lift_train_functions(["requires_grad", "KD_loss", "g_nonsaturating_loss", "d_logistic_loss", "d_r1_loss", "make_noise",
+                          "mixing_noise", "index_aware_mixing_noise", "G_Loss_BackProp", "D_Loss_BackProp",
+                          "D_Reg_BackProp", "G_Reg_BackProp"], ns)
+    yy, xx = torch.meshgrid(torch.arange(512), torch.arange(512), indexing="ij")
+    cls = torch.zeros(B, 512, 512, dtype=torch.long)
+    for i in range(B):
+        cls[i][((yy - 250) / 190.0) ** 2 + ((xx - 260) / 160.0) ** 2 < 1.0] = 2 + i
+    logits = F.one_hot(cls, 19).permute(0, 3, 1, 2).float()
+    args = types.SimpleNamespace(batch_size=B, latent=TINY["style_dim"], mixing=0.9, n_latent=student.n_latent,
+                                 kd_mode="Output_Only", kd_l1_lambda=3, kd_lpips_lambda=3, size=TINY["size"], r1=10,
+                                 d_reg_every=16, g_reg_every=4, path_regularize=2, path_batch_shrink=2)
+    cg, cd = 4 / 5, 16 / 17
+    g_optim = torch.optim.Adam(student.parameters(), lr=0.002 * cg, betas=(0.0 ** cg, 0.99 ** cg))
+    d_optim = torch.optim.Adam(disc.parameters(), lr=0.002 * cd, betas=(0.0 ** cd, 0.99 ** cd))
+    gen = torch.Generator().manual_seed(803)
+    real_img = torch.rand(B, 3, TINY["size"], TINY["size"], generator=gen) * 2 - 1
+    pl_noise = torch.randn(B // 2, 3, TINY["size"], TINY["size"], generator=gen)
+
+    rec = RecordingNoise()
+    calls = []
+    orig_fwd = ref_model.Generator.forward
+
+    def capturing_forward(self, noise_z, *a, **k):
+        calls.append(([t.detach().clone() for t in noise_z], k.get("inject_index"), len(rec.log)))
+        return orig_fwd(self, noise_z, *a, **k)
+
+    out = {}
+    out.update(sd_arrays("student_sd/", {k: v.clone() for k, v in student.state_dict().items()}))
+    out.update(sd_arrays("teacher_sd/", teacher.state_dict()))
+    out["real_img"], out["pl_noise"] = real_img, pl_noise
+    d_sd0 = {k: v.clone() for k, v in disc.state_dict().items()}
+    out["d_seed"] = np.int64(802)
+    out["d_checksum"] = np.array([float(v.double().sum()) for v in d_sd0.values()])
+
+    def chk(tensors):
+        return np.array([[float(t.double().sum()), float(t.double().abs().sum())] for t in tensors])
+
+    randints = []
+    orig_randint = random.randint
+
+    def logged_randint(a, b):
+        v = orig_randint(a, b)
+        randints.append(v)
+        return v
+
+    with mock.patch.object(ref_model.NoiseInjection, "forward", lambda self, image, noise=None: rec(self, image, noise)), \
+            mock.patch.object(ref_model.Generator, "forward", capturing_forward), \
+            mock.patch.object(random, "randint", logged_randint), \
+            mock.patch.object(torch, "randn_like", lambda t: pl_noise):
+        random.seed(900)
+        torch.manual_seed(901)
+        loss_dict = {}
+        # --- D step (train.py:241-262)
+        ns["D_Loss_BackProp"](student, disc, real_img, args, "cpu", loss_dict, d_optim)
+        zs, inj, _ = calls[-1]
+        nl = student.num_layers
+        out["d/n_z"] = np.int64(len(zs))
+        for i, z in enumerate(zs):
+            out[f"d/z{i}"] = z
+        out["d/inject_index"] = np.int64(-1 if inj is None else inj)   # mixing_noise: generator draws its own index
+        for i in range(nl):
+            out[f"d/noise{i}"] = rec.log[i]
+        out["d/loss"], out["d/real_score"], out["d/fake_score"] = loss_dict["d"], loss_dict["real_score"], loss_dict["fake_score"]
+        out["d/grad_chk"] = chk([p.grad for p in disc.parameters()])
+        out["d/param_chk"] = chk([p.detach() for p in disc.parameters()])
+        out["d/final_linear.1.weight.grad"] = disc.final_linear[1].weight.grad.clone()
+        # --- R1 (train.py:264-278)
+        r1 = ns["D_Reg_BackProp"](real_img, disc, args, d_optim)
+        real_img.requires_grad = False
+        out["r1/loss"] = r1
+        out["r1/grad_chk"] = chk([p.grad for p in disc.parameters()])
+        out["r1/param_chk"] = chk([p.detach() for p in disc.parameters()])
+        out["r1/convs.0.1.bias.grad"] = disc.convs[0][1].bias.grad.clone()
+        # --- G + KD step (train.py:280-308)
+        n0 = len(rec.log)
+        ns["G_Loss_BackProp"](student, disc, args, "cpu", loss_dict, g_optim, teacher, None, lambda x: (logits,))
+        zs, inj, _ = calls[-2]
+        out["g/n_z"] = np.int64(len(zs))
+        for i, z in enumerate(zs):
+            out[f"g/z{i}"] = z
+        out["g/inject_index"] = np.int64(-1 if inj is None else inj)
+        for i in range(nl):
+            out[f"g/student_noise{i}"] = rec.log[n0 + i]
+            out[f"g/teacher_noise{i}"] = rec.log[n0 + nl + i]
+        out["g/g_loss"], out["g/kd_l1_loss"] = loss_dict["g"], loss_dict["kd_l1_loss"]
+        for n, prm in student.named_parameters():
+            out["g/grad/" + n] = prm.grad.detach().clone()
+            out["g/param_after/" + n] = prm.detach().clone()
+        # --- path-length regulariser (train.py:310-338)
+        n1 = len(rec.log)
+        path_loss, path_lengths, mean_pl, mean_pl_avg = ns["G_Reg_BackProp"](student, args, 0, g_optim)
+        zs, inj, _ = calls[-1]
+        out["pl/n_z"] = np.int64(len(zs))
+        for i, z in enumerate(zs):
+            out[f"pl/z{i}"] = z
+        # with 2 latents and inject_index=None the forward draws random.randint itself (model.py:604-605)
+        out["pl/inject_index"] = np.int64(randints[-1] if len(zs) > 1 else -1)
+        out["pl/rand_state_seed"] = np.int64(900)
+        for i in range(nl):
+            out[f"pl/noise{i}"] = rec.log[n1 + i]
+        out["pl/path_loss"], out["pl/path_lengths"], out["pl/mean_path_length"] = path_loss, path_lengths, mean_pl
+        for n, prm in student.named_parameters():
+            out["pl/grad/" + n] = prm.grad.detach().clone()
+            out["pl/param_after/" + n] = prm.detach().clone()
+    mask = ((cls > 0) * (cls != 16)).unsqueeze(0).float()
+    mask = (F.interpolate(mask, scale_factor=TINY["size"] / 512, mode="bilinear", align_corners=False).squeeze() > 0.5).float()
+    out["mask"] = mask.view(B, 1, TINY["size"], TINY["size"])
+    # EMA (train.py:124-129, restated: the removed add_(Number, Tensor) overload == add_(tensor, alpha=number))
+    accum = 0.5 ** (32 / (10 * 1000))
+    pe, pg = dict(g_ema.named_parameters()), dict(student.named_parameters())
+    with torch.no_grad():
+        for k in pe:
+            pe[k].mul_(accum).add_(pg[k], alpha=1 - accum)
+            out["ema/" + k] = pe[k].detach().clone()
+    # which inject index did the PL forward draw?  replay python's RNG: seeded 900, consumed in order by
+    # D step (mixing_noise: random()), [generator forward: randint if 2 latents], G step (random(), randint), PL (random(), [randint])
+    save("train_iter_tiny", **out)
+    with open(os.path.join(OUT, "train_iter_tiny_meta.json"), "w") as f:
+        json.dump(dict(batch=B, student_shape=[5, 5, 4, 4, 3, 3, 2, 2], teacher_shape=TINY["shape"],
+                       lr_g=0.002 * cg, betas_g=[0.0 ** cg, 0.99 ** cg], lr_d=0.002 * cd, betas_d=[0.0 ** cd, 0.99 ** cd],
+                       r1=10, d_reg_every=16, g_reg_every=4, path_regularize=2, path_batch_shrink=2, accum=accum,
+                       calls=[dict(n_z=len(c[0]), inject_index=c[1]) for c in calls]), f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fused_act", "upfirdn2d", "modconv", "generator", "kd_step", "discriminator", "contract"]
+    which = sys.argv[1:] or ["fused_act", "upfirdn2d", "modconv", "generator", "kd_step", "discriminator", "contract", "train_iter"]
     for w in which:
         print("==", w)
         globals()["gold_" + w]()

@@ -35,3 +35,28 @@ def adam_step_ref(params, grads, state, lr, betas, eps=1e-8):
         denom = (v.sqrt() / (1 - b2 ** t) ** 0.5).add_(eps)
         out[k] = p - (lr / (1 - b1 ** t)) * m / denom
     return out
+
+
+def d_losses_ref(student_sd, d_sd, real_img, zs, inject_index, noise):
+    """D step loss (reference train.py:241-262 + :187-191): softplus(-D(real)).mean() + softplus(D(G(z))).mean()."""
+    fake = generator_forward_ref(student_sd, zs, inject_index=inject_index, noise=noise)
+    fake_pred = discriminator_forward_ref(d_sd, fake)
+    real_pred = discriminator_forward_ref(d_sd, real_img)
+    return F.softplus(-real_pred).mean() + F.softplus(fake_pred).mean(), real_pred.mean(), fake_pred.mean()
+
+
+def r1_ref(d_sd, real_img):
+    """R1 penalty (reference train.py:194-200,264-278): returns (r1_loss, real_pred)."""
+    x = real_img.detach().clone().requires_grad_(True)
+    pred = discriminator_forward_ref(d_sd, x)
+    (g,) = torch.autograd.grad(pred.sum(), x, create_graph=True)
+    return g.pow(2).reshape(g.shape[0], -1).sum(1).mean(), pred
+
+
+def path_reg_ref(student_sd, zs, inject_index, noise, pl_noise, mean_path_length=0.0):
+    """Path-length regulariser (reference model.py:661-666, train.py:310-338): (path_loss, path_lengths, new mean)."""
+    from .ref_model import path_lengths_ref
+    img, latent = generator_forward_ref(student_sd, zs, inject_index=inject_index, noise=noise, return_latent=True)
+    pl = path_lengths_ref(img, latent, pl_noise)
+    mean = mean_path_length + 0.01 * (pl.mean() - mean_path_length)
+    return (pl - mean).pow(2).mean(), pl, mean.detach(), img

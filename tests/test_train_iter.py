@@ -1,0 +1,117 @@
+"""the rest of the training iteration (D step, R1, G+KD step, path-length regulariser, EMA) against
+a golden captured from the reference's own D_Loss_BackProp / D_Reg_BackProp / G_Loss_BackProp / G_Reg_BackProp
+(lifted from train.py by oracle/gen_golden.py).  The 29 MB discriminator is regenerated from its seed; its gradients
+and updated weights are pinned by per-tensor (sum, abs-sum) checksums plus two small tensors in full."""
+from unittest import mock
+
+import numpy as np
+import pytest
+import torch
+
+import cagc.model as M
+from cagc import kd
+from oracle import ref_kd
+from oracle.ref_model import regenerate_state_dict
+from _util import assert_close, load_json, load_npz, sub
+
+
+def _objects(g, meta, dev):
+    student = M.Generator(32, 24, 2, generator_net_shape=meta["student_shape"])
+    student.load_state_dict(sub(g, "student_sd/"), strict=True)
+    ema = M.Generator(32, 24, 2, generator_net_shape=meta["student_shape"])
+    ema.load_state_dict(sub(g, "student_sd/"), strict=True)
+    teacher = M.Generator(32, 24, 2, generator_net_shape=meta["teacher_shape"])
+    teacher.load_state_dict(sub(g, "teacher_sd/"), strict=True)
+    disc = M.Discriminator(32)
+    sd = regenerate_state_dict(load_json("discriminator32_keys"), g["d_seed"])
+    chk = torch.tensor([float(v.double().sum()) for v in sd.values()], dtype=torch.float64)
+    assert torch.allclose(chk, g["d_checksum"].double(), rtol=0, atol=1e-6)
+    disc.load_state_dict(sd, strict=True)
+    return student.to(dev), teacher.to(dev), disc.to(dev), ema.to(dev)
+
+
+def _check_chk(tensors, gold, tol, what):
+    got = torch.tensor([[float(t.double().sum()), float(t.double().abs().sum())] for t in tensors], dtype=torch.float64)
+    gold = gold.double()
+    scale = gold[:, 1].clamp_min(1e-12)   # compare both sums relative to the abs-sum of the tensor
+    err = ((got - gold).abs() / scale[:, None]).max().item()
+    assert err <= tol, f"{what}: checksum rel err {err:.3e} > {tol:.1e}"
+
+
+def _run(dev, tol, tol_chk):
+    g = load_npz("train_iter_tiny")
+    meta = load_json("train_iter_tiny_meta")
+    student, teacher, disc, ema = _objects(g, meta, dev)
+    it = kd.TrainIteration(student, teacher, disc, g_ema=ema, latent=24)
+    assert abs(it.d_optim.param_groups[0]["lr"] - meta["lr_d"]) < 1e-12 and np.allclose(it.d_optim.param_groups[0]["betas"], meta["betas_d"])
+    to = lambda t: t.to(dev)
+    nl = student.num_layers
+    # D step
+    zs = [to(g[f"d/z{i}"]) for i in range(g["d/n_z"])]
+    out = it.d_step(to(g["real_img"]), zs, None if g["d/inject_index"] < 0 else g["d/inject_index"],
+                    noise=[to(g[f"d/noise{i}"]) for i in range(nl)])
+    assert abs(out["d"].item() - float(g["d/loss"])) < tol * max(1, abs(float(g["d/loss"])))
+    assert abs(out["real_score"].item() - float(g["d/real_score"])) < 10 * tol and abs(out["fake_score"].item() - float(g["d/fake_score"])) < 10 * tol
+    # gradients were consumed by the optimiser step; the updated weights pin them (Adam's first step = -lr*sign(g))
+    _check_chk([p.detach() for p in disc.parameters()], g["d/param_chk"], tol_chk, "D params after D step")
+    # R1
+    r1 = it.d_reg(to(g["real_img"]))
+    assert abs(r1.item() - float(g["r1/loss"])) < 5 * tol * max(1, abs(float(g["r1/loss"])))
+    assert_close(disc.convs[0][1].bias.grad, g["r1/convs.0.1.bias.grad"], 20 * tol, "R1 grad convs.0.1.bias")
+    _check_chk([p.detach() for p in disc.parameters()], g["r1/param_chk"], tol_chk, "D params after R1")
+    # G + KD step
+    zs = [to(g[f"g/z{i}"]) for i in range(g["g/n_z"])]
+    losses = it.g_step(zs, None if g["g/inject_index"] < 0 else g["g/inject_index"], to(g["mask"]),
+                       student_noise=[to(g[f"g/student_noise{i}"]) for i in range(nl)],
+                       teacher_noise=[to(g[f"g/teacher_noise{i}"]) for i in range(nl)])
+    assert abs(losses["g"].item() - float(g["g/g_loss"])) < 10 * tol * max(1, abs(float(g["g/g_loss"])))
+    assert abs(losses["kd_l1_loss"].item() - float(g["g/kd_l1_loss"])) < 10 * tol
+    params = dict(student.named_parameters())
+    for k, v in sub(g, "g/grad/").items():
+        assert_close(params[k].grad, v, 30 * tol if v.numel() > 1 else 300 * tol, "G step grad " + k)
+    with torch.no_grad():
+        for k, v in sub(g, "g/param_after/").items():
+            params[k].copy_(to(v))
+    # path-length regulariser (second order)
+    zs = [to(g[f"pl/z{i}"]) for i in range(g["pl/n_z"])]
+    with mock.patch.object(torch, "randn_like", lambda t: to(g["pl_noise"])):
+        path_loss, pl = it.g_reg(zs, None if g["pl/inject_index"] < 0 else g["pl/inject_index"],
+                                 noise=[to(g[f"pl/noise{i}"]) for i in range(nl)])
+    assert_close(pl, g["pl/path_lengths"], 10 * tol, "path lengths")
+    assert abs(path_loss.item() - float(g["pl/path_loss"])) < 10 * tol
+    for k, v in sub(g, "pl/grad/").items():
+        assert_close(params[k].grad, v, 100 * tol if v.numel() > 1 else 1000 * tol, "PL grad " + k)
+    with torch.no_grad():
+        for k, v in sub(g, "pl/param_after/").items():
+            params[k].copy_(to(v))
+    it.ema()
+    pe = dict(ema.named_parameters())
+    for k, v in sub(g, "ema/").items():
+        assert_close(pe[k].detach(), v, 1e-6, "EMA " + k)
+
+
+def test_full_iteration_cpu_matches_reference():
+    _run("cpu", 2e-5, 2e-5)
+
+
+@pytest.mark.gpu
+def test_full_iteration_gpu_matches_reference():
+    _run("cuda", 1e-4, 2e-4)
+
+
+def test_oracle_full_iteration_pieces_match_reference():
+    g = load_npz("train_iter_tiny")
+    d_sd = regenerate_state_dict(load_json("discriminator32_keys"), g["d_seed"])
+    student = sub(g, "student_sd/")
+    nl = 7
+    zs = [g[f"d/z{i}"] for i in range(g["d/n_z"])]
+    d_loss, rs, fs = ref_kd.d_losses_ref(student, d_sd, g["real_img"], zs, None, [g[f"d/noise{i}"] for i in range(nl)])
+    assert abs(d_loss.item() - float(g["d/loss"])) < 2e-5 and abs(rs.item() - float(g["d/real_score"])) < 2e-4
+    # path-length pieces on the post-G-step student
+    post = dict(student)
+    post.update(sub(g, "g/param_after/"))
+    post = {k: (v.clone().requires_grad_(True) if k in sub(g, "g/param_after/") else v) for k, v in post.items()}
+    zs = [g[f"pl/z{i}"] for i in range(g["pl/n_z"])]
+    pl_loss, pl, mean, _ = ref_kd.path_reg_ref(post, zs, int(g["pl/inject_index"]), [g[f"pl/noise{i}"] for i in range(nl)], g["pl_noise"])
+    assert_close(pl, g["pl/path_lengths"], 1e-4, "oracle path lengths")
+    assert abs(pl_loss.item() - float(g["pl/path_loss"])) < 1e-5 and abs(mean.item() - float(g["pl/mean_path_length"])) < 1e-6
