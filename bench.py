@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-full-iteration", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches + DDP instead of HIP-graph replay")
     args = ap.parse_args()
 
@@ -226,6 +227,27 @@ def main():
                     "launches_per_step": cnt // 3, "avg_launch_ms": round(tot_ms / cnt, 4),
                     "flops_per_launch_avg": flops / cnt,
                     "cagc_kernel_ms_per_step": {k: round(v[1] / 3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+    full = None
+    if world == 1 and not args.no_full_iteration:
+        # secondary figure: the WHOLE training iteration of train.py:371-398 — D step + G/KD step + lazy
+        # R1 (every 16) + lazy path-length reg (every 4) + EMA — eagerly launched, 16 iterations = one full lazy-reg
+        # period.  Comparable in kind to the reference's README.md:108-115 wall-time figure (15.3 img/s on 2xV100,
+        # which also included BiSeNet, LPIPS, data loading and FID).
+        import copy
+        g_ema = copy.deepcopy(student)
+        it = kd.TrainIteration(student, teacher, disc, g_ema=g_ema)
+        real = torch.rand(bs, 3, SIZE, SIZE, device=dev) * 2 - 1
+        for i in range(1, 4):
+            it.iteration(i, real, mask, rng, None)
+        it.iteration(0, real, mask, rng, None)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(16):
+            it.iteration(i, real, mask, rng, None)
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t1
+        full = {"value": round(16 * bs / dtf, 2), "unit": "images/s", "ms_per_iteration": round(dtf / 16 * 1e3, 2),
+                "what": "D step + G/KD step + R1/16 + path-length/4 + EMA, bs16, eager launches (train.py:371-398 equivalent)"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -239,7 +261,7 @@ def main():
                                       "global bs16 (configs[1]); frozen D fwd+dgrad, masked-L1 KD, Adam; LPIPS/BiSeNet off",
                           "global_batch": GLOBAL_BATCH, "per_gpu_batch": bs, "parallelism": f"dp{world}", "launch_mode": mode,
                           "student_params": n_params},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu, "full_iteration": full}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
