@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-full-iteration", action="store_true")
+    ap.add_argument("--sweep", type=int, default=0, help="also time N bs-64 batches of the prune.py saliency sweep (config 5)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches + DDP instead of HIP-graph replay")
     args = ap.parse_args()
 
@@ -248,6 +249,26 @@ def main():
         dtf = time.perf_counter() - t1
         full = {"value": round(16 * bs / dtf, 2), "unit": "images/s", "ms_per_iteration": round(dtf / 16 * 1e3, 2),
                 "what": "D step + G/KD step + R1/16 + path-length/4 + EMA, bs16, eager launches (train.py:371-398 equivalent)"}
+    sweep = None
+    if world == 1 and args.sweep:
+        # BASELINE configs[4]: prune.py's content-aware saliency sweep over the FULL 256 px generator, bs 64 (forward +
+        # backward incl. weight gradients of the 512-channel layers); bounded here to a few batches
+        from cagc import prune
+        requires = [p.requires_grad_(True) for p in teacher.parameters()]   # noqa: F841
+        teacher.train()
+        mfn = lambda im: kd.ellipse_mask(im.shape[0], SIZE, dev)
+        nb = args.sweep
+        prune.content_aware_scores(teacher, 64, 64, 0.05, mfn, dev)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        sc = prune.content_aware_scores(teacher, 64 * nb, 64, 0.05, mfn, dev)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t2
+        sweep = {"value": round(64 * nb / dts, 2), "unit": "images/s", "batches": nb, "batch_size": 64,
+                 "what": "content-aware saliency sweep, full 256px generator fwd+bwd (271 GFLOP/img), on-device mask/noise/score",
+                 "tflops": round(64 * nb / dts * 271e9 / 1e12, 1), "score_layers": len(sc)}
+        teacher.eval()
+        kd.requires_grad(teacher, False)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -261,7 +282,7 @@ def main():
                                       "global bs16 (configs[1]); frozen D fwd+dgrad, masked-L1 KD, Adam; LPIPS/BiSeNet off",
                           "global_batch": GLOBAL_BATCH, "per_gpu_batch": bs, "parallelism": f"dp{world}", "launch_mode": mode,
                           "student_params": n_params},
-               "roofline": roof, "cpu_baseline": cpu, "full_iteration": full}
+               "roofline": roof, "cpu_baseline": cpu, "full_iteration": full, "saliency_sweep": sweep}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -70,3 +70,61 @@ def mask_generator_state_dict(sd, masks):
                 v = v[masks[2 * lr + 1]]
         out[k] = v.clone()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# content-aware saliency sweep (reference Util/content_aware_pruning.py:152-249 + prune.py:39-46), on device
+# ---------------------------------------------------------------------------------------------------
+def salt_pepper(mask, prob, generator=None):
+    """Vectorised stand-in for the reference's per-pixel Python loop (:152-171): inside `mask` each pixel is hit with
+    probability `prob` and takes the value -1 or +1 (shared by the 3 colour channels).  Returns (hit, sp) as float
+    [B,1,H,W].  The reference draws from NumPy's global RNG pixel by pixel, so only the distribution can match."""
+    hit = (mask > 0.5) & (torch.rand(mask.shape, device=mask.device, generator=generator) < prob)
+    sp = torch.randint(0, 2, mask.shape, device=mask.device, generator=generator).float() * 2 - 1
+    return hit.float(), sp * hit.float()
+
+
+def saliency_modules(g):
+    """[conv1] + convs + [to_rgbs[-1]] — the layers whose weight gradient is scored (:189-190)."""
+    g = g.module if hasattr(g, "module") else g
+    return [g.conv1] + list(g.convs) + [g.to_rgbs[-1]]
+
+
+def batch_saliency_scores(generator, img, hit, sp):
+    """One batch: loss = sum over hit pixels of |sp - img| (what `sum|noisy - img|` reduces to, :184), backward, and
+    per layer mean |dL/dW| over (out-channel, ky, kx) -> one score per INPUT channel (:192-195).  Stays on device."""
+    loss = (hit * (sp - img).abs()).sum()
+    generator.zero_grad(set_to_none=True)
+    loss.backward()
+    scores = [m.conv.weight.grad.abs().mean(dim=[0, 1, 3, 4]) for m in saliency_modules(generator)]
+    generator.zero_grad(set_to_none=True)
+    return scores
+
+
+def content_aware_scores(generator, n_sample, batch_size, noise_prob, mask_fn, device, latent_dim=512, rank=0, world=1,
+                         rng=None):
+    """Sum over batches of the per-batch scores (prune.py:45-46).  With world > 1 the batches are dealt round-robin
+    to the ranks and the score vectors are summed with ONE all-reduce at the end."""
+    n_batch = max(1, n_sample // batch_size)
+    sizes = [batch_size] * (n_batch - 1) + [batch_size + n_sample % batch_size]
+    total = None
+    for idx, b in enumerate(sizes):
+        if idx % world != rank:
+            continue
+        z = torch.randn(b, latent_dim, device=device, generator=rng)
+        img = generator([z])
+        hit, sp = salt_pepper(mask_fn(img.detach()), noise_prob, rng)
+        sc = batch_saliency_scores(generator, img, hit, sp)
+        total = sc if total is None else [a + c for a, c in zip(total, sc)]
+    if total is None:
+        total = [torch.zeros(m.conv.weight.shape[2], device=device) for m in saliency_modules(generator)]
+    if world > 1:
+        import torch.distributed as dist
+        flat = torch.cat(total)
+        dist.all_reduce(flat)
+        out, off = [], 0
+        for t in total:
+            out.append(flat[off:off + t.numel()])
+            off += t.numel()
+        total = out
+    return total

@@ -597,8 +597,44 @@ def gold_train_iter():
                        calls=[dict(n_z=len(c[0]), inject_index=c[1]) for c in calls]), f, indent=1)
 
 
+
+# ----------------------------------------------------------------------------------------------
+# 9. content-aware saliency scores (Util/content_aware_pruning.py:152-196,200-249; prune.py:39-46)
+# ----------------------------------------------------------------------------------------------
+def gold_saliency():
+    from Util.content_aware_pruning import Get_Salt_Pepper_Noisy_Image, Get_Weight_Gradient
+    gnet = make_tiny_generator(950)
+    B, size = 3, TINY["size"]
+    rec = RecordingNoise()
+    torch.manual_seed(951)
+    np.random.seed(952)
+    z = torch.randn(B, TINY["style_dim"])
+    with mock.patch.object(ref_model.NoiseInjection, "forward", lambda self, image, noise=None: rec(self, image, noise)):
+        img = gnet(noise_z=[z])                                   # randomize_noise=True, as :226
+    yy, xx = np.meshgrid(np.arange(size), np.arange(size), indexing="ij")
+    noisy_list, hits, sps = [], [], []
+    for i in range(B):
+        mask = ((yy - 15 - i) / 11.0) ** 2 + ((xx - 16 + i) / 9.0) ** 2 < 1.0     # stand-in for the BiSeNet face mask
+        single = img[i:i + 1]
+        noisy = Get_Salt_Pepper_Noisy_Image(single, mask, 0.3)     # the reference's own per-pixel loop (:152-171)
+        noisy_list.append(noisy)
+        hit = (noisy.detach() != single.detach()).any(1, keepdim=True)
+        hits.append(hit.float())
+        sps.append(torch.where(hit, noisy.detach()[:, :1], torch.zeros(())))
+    grad_score = Get_Weight_Gradient(torch.cat(noisy_list), img, gnet)           # :174-196
+    out = sd_arrays("sd/", gnet.state_dict())
+    out["z"] = z
+    for i, n in enumerate(rec.log):
+        out[f"noise{i}"] = n
+    out["hit"], out["sp"] = torch.cat(hits), torch.cat(sps)
+    out["n_layers"] = np.int64(len(grad_score))
+    for i, sc in enumerate(grad_score):
+        out[f"score{i}"] = np.asarray(sc)
+    save("saliency_tiny", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fused_act", "upfirdn2d", "modconv", "generator", "kd_step", "discriminator", "contract", "train_iter"]
+    which = sys.argv[1:] or ["fused_act", "upfirdn2d", "modconv", "generator", "kd_step", "discriminator", "contract", "train_iter", "saliency"]
     for w in which:
         print("==", w)
         globals()["gold_" + w]()
