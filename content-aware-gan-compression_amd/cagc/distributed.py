@@ -24,12 +24,18 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            backend = os.environ.get("CAGC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            # CAGC_SINGLE_DEVICE=1: every rank on cuda:0 with the gloo backend — exercises the N-process control flow
+            # (graph capture per rank, flat-gradient all-reduce, max-over-ranks timing) on a 1-GPU box
+            if os.environ.get("CAGC_SINGLE_DEVICE") == "1":
+                local = 0
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
+    if os.environ.get("CAGC_SINGLE_DEVICE") == "1":
+        local = 0
     return rank, world, local
 
 
