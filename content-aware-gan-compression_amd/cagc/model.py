@@ -163,6 +163,7 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
         self._packed = None  # (weight version, data_ptr, wp_fwd, wp_bwd, wsq) for frozen weights
+        self._wino = None
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
@@ -186,13 +187,28 @@ class ModulatedConv2d(nn.Module):
         key = (w._version, w.data_ptr(), w.device)
         if self._packed is None or self._packed[0] != key or (need_bwd and self._packed[1][1] is None):
             self._packed = (key, mc.pack_weights(w, need_bwd))
+            self._wino = None
         return self._packed[1]
+
+    def wino_weights(self, H, W):
+        """Winograd-domain weights for the plain 3x3 forward (None when the layer / size is not eligible)."""
+        if self.upsample or self.downsample or self.kernel_size != 3 or not mc.wino_ok(H, W):
+            return None
+        w = self.weight
+        if w.requires_grad and torch.is_grad_enabled():
+            return mc.pack_wino(w[0], self.scale, False)
+        key = (w._version, w.data_ptr(), w.device)
+        if getattr(self, "_wino", None) is None or self._wino[0] != key:
+            self._wino = (key, mc.pack_wino(w[0], self.scale, False))
+        return self._wino[1]
 
     def invalidate_packed(self):
         self._packed = None
+        self._wino = None
 
     def _apply(self, fn, *a, **k):
         self._packed = None
+        self._wino = None
         return super()._apply(fn, *a, **k)
 
     def _demod(self, s, wsq):
@@ -205,7 +221,8 @@ class ModulatedConv2d(nn.Module):
             wp_fwd, wp_bwd, wsq = self.packed_weights()
             d = self._demod(s, wsq)
             out = mc._ModConv.apply(input, self.weight, s, d, None, None, None, wp_fwd, wp_bwd,
-                                    self.blur.kernel if self.upsample else None, False, self.upsample)
+                                    self.blur.kernel if self.upsample else None, False, self.upsample,
+                                    self.wino_weights(input.shape[2], input.shape[3]))
         else:
             out = mc.modconv_composed(input, self.weight, s, self.demodulate, self.upsample, self.downsample,
                                       self.blur.kernel if (self.upsample or self.downsample) else None,
@@ -266,7 +283,8 @@ class StyledConv(nn.Module):
             elif noise.shape[0] not in (1, batch) or tuple(noise.shape[1:]) != (1, oh, ow):
                 noise = noise.expand(batch, 1, oh, ow)
             out = mc._ModConv.apply(input, conv.weight, s, d, noise, self.noise.weight, self.activate.bias, wp_fwd,
-                                    wp_bwd, conv.blur.kernel if conv.upsample else None, True, conv.upsample)
+                                    wp_bwd, conv.blur.kernel if conv.upsample else None, True, conv.upsample,
+                                    conv.wino_weights(h, w))
             styles = s.view(batch, 1, cin, 1, 1)
         else:
             if return_style_scalars:
@@ -451,6 +469,7 @@ class ConvLayer(nn.Sequential):
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
         self._fused_down = downsample and kernel_size == 3 and list(blur_kernel) == [1, 3, 3, 1]
+        self._fused_s1 = (not downsample) and kernel_size == 3 and activate and bias
         self._packed = None
 
     def _packed_weights(self, conv):
@@ -467,7 +486,25 @@ class ConvLayer(nn.Sequential):
         self._packed = None
         return super()._apply(fn, *a, **k)
 
+    def _wino_weights(self, conv):
+        w = conv.weight
+        need_bwd = torch.is_grad_enabled()
+        def bwd_pack():
+            return mc.pack_wino(w, conv.scale, True) if mc.WINO_DGRAD else mc.pack_plain_weights(w, conv.scale, True)[1]
+        if w.requires_grad and need_bwd:
+            return mc.pack_wino(w, conv.scale, False), bwd_pack()
+        key = (w._version, w.data_ptr(), w.device)
+        if self._packed is None or self._packed[0] != key or (need_bwd and self._packed[1][1] is None):
+            self._packed = (key, (mc.pack_wino(w, conv.scale, False), bwd_pack() if need_bwd else None))
+        return self._packed[1]
+
     def forward(self, input):
+        # 3x3 stride-1 conv + FusedLeakyReLU as one Winograd MFMA kernel (>= 32 px feature maps)
+        if (self._fused_s1 and mc.use_hip(input) and input.dtype == torch.float32 and mc.wino_ok(input.shape[2], input.shape[3])
+                and self[1].bias is not None and self[1].negative_slope == 0.2):
+            conv, act = self[0], self[1]
+            up_fwd, up_bwd = self._wino_weights(conv)
+            return mc._Conv3x3Act.apply(input, conv.weight, act.bias, up_fwd, up_bwd, conv.scale)
         # Blur -> 3x3 stride-2 conv as one op on the hand-written MFMA kernel (odd blurred size 2*Ho+1)
         if (self._fused_down and mc.use_hip(input) and input.dtype == torch.float32
                 and (input.shape[2] + sum(self[0].pad) - 3) % 2 == 1 and (input.shape[3] + sum(self[0].pad) - 3) % 2 == 1):

@@ -19,7 +19,11 @@ from .. import _lib
 from .upfirdn2d import _launch as _upfirdn_launch
 from .upfirdn2d import upfirdn2d
 
+import os
+
 EPI_LINEAR, EPI_STYLED = 0, 1
+# data gradient of the discriminator's stride-1 3x3 convs: Winograd (1) or the direct implicit GEMM (0)
+WINO_DGRAD = os.environ.get("CAGC_WINO_DGRAD", "1") == "1"
 SQRT2 = 2 ** 0.5
 
 # ---------------------------------------------------------------------------------------------------
@@ -60,6 +64,21 @@ def pack_weights(weight, need_bwd):
     with _lib.on_device(w):
         _lib.call("cagc_modconv_prep", _lib.ptr(wp_fwd), _lib.ptr(wp_bwd), _lib.ptr(wsq), _lib.ptr(w), cout, cin, k, scale)
     return wp_fwd, wp_bwd, wsq
+
+
+def pack_wino(weight4, scale, dgrad):
+    """weight [Cout,Cin,3,3] (contiguous view) -> Winograd-domain weights [16][Kp][Mp] (cagc_wino_prep)."""
+    cout, cin = weight4.shape[0], weight4.shape[1]
+    w = weight4.detach().contiguous()
+    K, Mm = (cout, cin) if dgrad else (cin, cout)
+    up = torch.empty(_lib.query("cagc_wino_packed_elems", K, Mm), dtype=torch.float32, device=w.device)
+    with _lib.on_device(w):
+        _lib.call("cagc_wino_prep", _lib.ptr(up), _lib.ptr(w), cout, cin, float(scale), 1 if dgrad else 0)
+    return up
+
+
+def wino_ok(H, W):
+    return bool(_lib.query("cagc_wino_eligible", H, W))
 
 
 class _Demod(Function):
@@ -104,7 +123,7 @@ class _ModConv(Function):
     (reference model.py:351-367); `upsample` the transposed-conv + blur variant (model.py:259-270)."""
 
     @staticmethod
-    def forward(ctx, x, weight, s, d, noise, noise_w, bias, wp_fwd, wp_bwd, fir, styled, upsample):
+    def forward(ctx, x, weight, s, d, noise, noise_w, bias, wp_fwd, wp_bwd, fir, styled, upsample, up_wino=None):
         x = x.contiguous()
         s = s.contiguous()
         B, cin, H, W = x.shape
@@ -124,6 +143,11 @@ class _ModConv(Function):
                           _lib.ptr(noise) if styled else None, nb, _lib.ptr(noise_w) if styled else None,
                           _lib.ptr(bias) if styled else None, B, cout, H, W, 0.2, SQRT2)
                 del t
+            elif up_wino is not None and k == 3 and wino_ok(H, W):
+                out = torch.empty(B, cout, H, W, dtype=x.dtype, device=dev)
+                _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(x), _lib.ptr(up_wino), _lib.ptr(s), B, cin, cout, H, W,
+                          EPI_STYLED if styled else EPI_LINEAR, _lib.ptr(d_c), _lib.ptr(noise) if styled else None, nb,
+                          _lib.ptr(noise_w) if styled else None, _lib.ptr(bias) if styled else None, 0.2, SQRT2)
             else:
                 out = torch.empty(B, cout, H, W, dtype=x.dtype, device=dev)
                 _lib.call("cagc_modconv_fwd", _lib.ptr(out), _lib.ptr(x), _lib.ptr(wp_fwd), _lib.ptr(s), B, cin, cout, H, W,
@@ -192,7 +216,7 @@ class _ModConv(Function):
                 gweight = torch.empty(1, cout, cin, k, k, dtype=x.dtype, device=dev)
                 _lib.call("cagc_modconv_wgrad", _lib.ptr(gweight), _lib.ptr(ws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(s), B, cin,
                           cout, H, W, k, up, 1.0 / math.sqrt(cin * k * k))
-        return (gx if need_x else None, gweight, gs, gd, None, g_nw, g_bias, None, None, None, None, None)
+        return (gx if need_x else None, gweight, gs, gd, None, g_nw, g_bias, None, None, None, None, None, None)
 
 
 def modconv_composed(x, weight, s, demodulate, upsample, downsample, blur_kernel, blur_pad):
@@ -227,6 +251,53 @@ def pack_plain_weights(weight, scale, need_bwd):
     with _lib.on_device(w):
         _lib.call("cagc_modconv_prep", _lib.ptr(wp_fwd), _lib.ptr(wp_bwd), None, _lib.ptr(w), cout, cin, k, float(scale))
     return wp_fwd, wp_bwd
+
+
+class _Conv3x3Act(Function):
+    """Discriminator ConvLayer without down-sampling (reference model.py:694-716): EqualConv2d(3x3, padding 1, no
+    conv bias) -> FusedLeakyReLU, as ONE Winograd MFMA kernel with the bias + LeakyReLU epilogue; backward = the fused
+    act backward (+ grad_bias) followed by the Winograd data gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, up_fwd, up_bwd, scale):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        cout = weight.shape[0]
+        out = torch.empty(B, cout, H, W, dtype=x.dtype, device=x.device)
+        with _lib.on_device(x):
+            _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(x), _lib.ptr(up_fwd), None, B, C, cout, H, W, EPI_STYLED,
+                      None, None, 0, None, _lib.ptr(bias.detach().contiguous()), 0.2, SQRT2)
+        ctx.save_for_backward(x if weight.requires_grad else x.new_empty(0), weight, out, up_bwd)
+        ctx.scale = scale
+        ctx.x_shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, weight, out, up_bwd = ctx.saved_tensors
+        B, C, H, W = ctx.x_shape
+        cout = weight.shape[0]
+        gout = gout.contiguous()
+        gz = torch.empty_like(gout)
+        gbias = torch.zeros(cout, dtype=gout.dtype, device=gout.device) if ctx.needs_input_grad[2] else None
+        gx = gweight = None
+        with _lib.on_device(gout):
+            _lib.call("cagc_fused_bias_act_bwd", _lib.ptr(gz), _lib.ptr(gbias), _lib.ptr(gout), _lib.ptr(out), B, cout, H * W,
+                      0.2, SQRT2)
+            if ctx.needs_input_grad[0]:
+                if up_bwd is None:
+                    raise RuntimeError("conv3x3_act: backward requested but the weights were packed forward-only")
+                gx = torch.empty(B, C, H, W, dtype=gout.dtype, device=gout.device)
+                if WINO_DGRAD:
+                    _lib.call("cagc_wino_conv3x3", _lib.ptr(gx), _lib.ptr(gz), _lib.ptr(up_bwd), None, B, cout, C, H, W,
+                              EPI_LINEAR, None, None, 0, None, None, 0.2, 1.0)
+                else:   # direct implicit GEMM (exact fp32 FMA chain) with the [tap][Cout][Cin] packing
+                    _lib.call("cagc_modconv_dgrad", _lib.ptr(gx), None, _lib.ptr(gz), _lib.ptr(up_bwd), None, None, B, C, cout,
+                              H, W, 3)
+            if ctx.needs_input_grad[1]:
+                gweight = torch.nn.grad.conv2d_weight(x, weight.shape, gz, padding=1) * ctx.scale   # D training: stock kernel
+        return gx, gweight, gbias, None, None, None
 
 
 class _BlurConvS2(Function):

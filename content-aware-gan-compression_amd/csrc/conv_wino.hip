@@ -1,0 +1,366 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores of gfx950 — stride-1 "same" 3x3 convs with H % 8 == 0 and
+// W % 32 == 0 (every 3x3 layer of the teacher / student / discriminator at >= 32 px).
+//
+//   Y = A^T [ sum_c (G g G^T)[o,c] (.) (B^T d B)[c] ] A        per 4x4 input tile d -> 2x2 outputs
+//
+// i.e. 16 independent GEMMs  M[xi][o][tile] = sum_c U[xi][o][c] * V[xi][c][tile]  with 4 multiplies per output instead of
+// 9 (2.25x fewer MFMA flops than the direct implicit GEMM of conv_igemm.hip).  All arithmetic is fp32 (exact-fp32 MFMA
+// v_mfma_f32_16x16x4_f32; the transforms use the coefficients 0, +-1, +-1/2 only).
+//
+// Workgroup = 512 threads = 8 waves; tile = MB*16 output channels x (8 x 32 output pixels = 4 x 16 Winograd tiles).
+// Wave (wn, wx) owns Winograd-tile row wn (16 tiles = one MFMA N-block) for 8 of the 16 positions xi: accumulators
+// acc[8][MB] (4 VGPRs each) -> 2 waves / SIMD.  The output transform A^T M A is linear in M: each half transforms its
+// own 8 positions in registers, the halves are added through LDS once per workgroup, and every lane stores 2x2 pixels
+// (8-byte stores, 128 B contiguous per 16-lane group).  Per K-chunk of 8 input channels:
+//   raw halo tile [8][10][40] + U slab [16*8][M_T]  --(registers, prefetched one chunk ahead)-->  LDS
+//   every thread transforms 2 (channel, tile) patches  raw -> V[16*8][64 tiles]  (LDS -> LDS)
+//   16 xi x 2 K-steps x MB MFMAs per wave out of LDS (strides == 16 mod 32: conflict-free ds_read_b32 halves)
+// The per-sample modulation s[b,c] is applied to the staged input, demodulation / noise / bias / LeakyReLU in the
+// epilogue — same contract as cagc_modconv_fwd.  The data gradient of such a conv is the same kernel on weights
+// packed with flipped taps and swapped channel roles (cagc_wino_prep(..., dgrad = 1)).
+#include "common.h"
+#include <string.h>
+
+namespace cagc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WCK = 8;      // input channels per chunk
+constexpr int WTH = 8, WTW = 32;
+constexpr int W_IH = WTH + 2, W_IWP = 40;   // raw tile rows / padded row (LDS col 0 <-> global col x0 - 4)
+constexpr int W_VS = 80;    // V row stride: 64 tiles, == 16 (mod 32)
+
+struct WinoArgs {
+  const float* in;
+  float* out;
+  const float* up;         // [16][Kp][Mp]
+  const float* in_scale;   // [B,Cin] or null
+  const float* out_scale;  // [B,Cout] or null
+  const float* noise;
+  const float* noise_w;
+  const float* bias;
+  int B, Cin, Kp, Cout, Mp, H, W;
+  int tiles_x, tiles_y, nblocks, mtiles;
+  int epi, noise_bstride_on;
+  float alpha, act_scale;
+};
+
+template <int MB>
+__global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
+  constexpr int CK = WCK;
+  constexpr int MT = MB * 16;
+  constexpr int LDA = (MT % 32 == 0) ? MT + 16 : MT;
+  constexpr int Q4M = MT / 4;
+  constexpr int NU = (16 * CK * Q4M + 511) / 512;   // float4 of the U slab per thread per chunk
+  constexpr int RPS = W_IH * W_IWP + 16;            // raw channel-plane stride
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* u_lds = smem;                         // [16*CK][LDA]
+  float* v_lds = u_lds + 16 * CK * LDA;        // [16*CK][W_VS]
+  float* raw = v_lds + 16 * CK * W_VS;         // [CK][RPS]
+
+  // 8 wavefronts: wn = Winograd-tile row (16 tiles = one MFMA N-block), wx = which half of the 16 positions xi.
+  // Two waves per SIMD, each with 8*MB accumulators: the two halves hide each other's LDS latency.
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 3, wx = wave >> 2;
+  const int lm = lane & 15, g = lane >> 4;
+
+  int pix_id, mtile;
+  {
+    const int w = blockIdx.x, nx = A.nblocks, mt = A.mtiles;
+    const int full = (nx / 8) * 8;
+    const int s = w / 8, xcd = w - s * 8;
+    const int p = (s / mt) * 8 + xcd;
+    if (w < full * mt && p < full) { pix_id = p; mtile = s % mt; }
+    else { const int r = w - full * mt; pix_id = full + r / mt; mtile = r % mt; }
+  }
+  const int tx_i = pix_id % A.tiles_x;
+  const int ty_i = (pix_id / A.tiles_x) % A.tiles_y;
+  const int b = pix_id / (A.tiles_x * A.tiles_y);
+  const int x0 = tx_i * WTW, y0 = ty_i * WTH;
+  const int m0 = mtile * MT;
+  const int HW = A.H * A.W;
+
+  // ---- staging descriptors: raw tile = CK x 10 rows x 10 float4 = 800 units -> 2 per thread ------------------
+  int e_goff[2], e_loff[2], e_meta[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + 512 * i;
+    int goff = 0, loff = 0, meta = 0;
+    if (e < CK * W_IH * 10) {
+      const int r = e / 10, q = e - r * 10;
+      const int c = r / W_IH, iy = r - c * W_IH;
+      const int gy = y0 - 1 + iy, gx = x0 - 4 + 4 * q;
+      const bool ok = (gy >= 0) && (gy < A.H) && (gx >= 0) && (gx + 4 <= A.W);
+      goff = (b * A.Cin + c) * HW + gy * A.W + gx;
+      loff = c * RPS + iy * W_IWP + 4 * q;
+      meta = (ok ? 1 : 0) | (c << 1) | 0x40000000;
+    }
+    e_goff[i] = goff; e_loff[i] = loff; e_meta[i] = meta;
+  }
+  float4 rin[2];
+  float rsc[2];
+  float4 ru[NU];
+  auto prefetch = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int meta = e_meta[i];
+      const int c = (meta >> 1) & 127;
+      const bool ok = (meta & 1) && (kc + c < A.Cin);
+      rin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rsc[i] = 1.f;
+      if (ok) {
+        rin[i] = *reinterpret_cast<const float4*>(A.in + (int64_t)e_goff[i] + (int64_t)kc * HW);
+        if (A.in_scale) rsc[i] = A.in_scale[b * A.Cin + kc + c];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const int q = tid + 512 * k;
+      const int row = q / Q4M, col = (q - row * Q4M) * 4;   // row = xi*CK + c
+      const int xi = row / CK, c = row - xi * CK;
+      ru[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < 16 * CK * Q4M && kc + c < A.Kp && m0 + col < A.Mp)
+        ru[k] = *reinterpret_cast<const float4*>(A.up + ((int64_t)xi * A.Kp + kc + c) * A.Mp + m0 + col);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (e_meta[i] & 0x40000000) {
+        float4 v = rin[i];
+        const float s = rsc[i];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        *reinterpret_cast<float4*>(raw + e_loff[i]) = v;
+      }
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const int q = tid + 512 * k;
+      if (q < 16 * CK * Q4M) {
+        const int row = q / Q4M, col = (q - row * Q4M) * 4;
+        *reinterpret_cast<float4*>(u_lds + row * LDA + col) = ru[k];
+      }
+    }
+  };
+
+  f32x4 acc[8][MB];
+#pragma unroll
+  for (int xi = 0; xi < 8; ++xi)
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[xi][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  prefetch(0);
+  for (int kc = 0; kc < A.Kp; kc += CK) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    // ---- input transform: V = B^T d B, one (channel, tile) patch per thread (512 = CK * 64) ----------------------
+    {
+      const int c = tid >> 6, tile = tid & 63;
+      const int ty = tile >> 4, tx = tile & 15;
+      const float* p = raw + c * RPS + (2 * ty) * W_IWP + 3 + 2 * tx;   // patch origin: row y0-1+2ty, col x0-1+2tx
+      float d[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[r][q] = p[r * W_IWP + q];
+      float t[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // rows: B^T d
+        t[0][q] = d[0][q] - d[2][q];
+        t[1][q] = d[1][q] + d[2][q];
+        t[2][q] = d[2][q] - d[1][q];
+        t[3][q] = d[1][q] - d[3][q];
+      }
+      float* vp = v_lds + c * W_VS + tile;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // columns: (B^T d) B ; xi = 4*r + col
+        vp[((4 * r + 0) * CK) * W_VS] = t[r][0] - t[r][2];
+        vp[((4 * r + 1) * CK) * W_VS] = t[r][1] + t[r][2];
+        vp[((4 * r + 2) * CK) * W_VS] = t[r][2] - t[r][1];
+        vp[((4 * r + 3) * CK) * W_VS] = t[r][1] - t[r][3];
+      }
+    }
+    __syncthreads();
+    if (kc + CK < A.Kp) prefetch(kc + CK);
+    // ---- this wave's 8 of the 16 GEMMs -----------------------------------------------------------------------------
+#pragma unroll
+    for (int x8 = 0; x8 < 8; ++x8) {
+      const int xi = wx * 8 + x8;
+#pragma unroll
+      for (int s = 0; s < CK / 4; ++s) {
+        const int kk = 4 * s + g;
+        const float bv = v_lds[(xi * CK + kk) * W_VS + wn * 16 + lm];
+        float av[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) av[i] = u_lds[(xi * CK + kk) * LDA + i * 16 + lm];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[x8][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[x8][i], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- output transform (linear in M: each half transforms its own 8 positions, the halves are summed through LDS)
+  // lane = (tile (wn, lm), channels m0 + i*16 + 4g + r).  xi = 4*row + col; half 0 holds rows 0,1, half 1 rows 2,3.
+  //   p[0][j] = M0j + M1j + M2j ,  p[1][j] = M1j - M2j - M3j ;  Y[a][0] = p[a][0]+p[a][1]+p[a][2], Y[a][1] = p[a][1]-p[a][2]-p[a][3]
+  __syncthreads();   // all MFMA reads of LDS done: reuse it for the exchange
+  float4* ex = reinterpret_cast<float4*>(smem);   // [wn][i][r][lane] float4 = partial 2x2 outputs
+  const bool styled = (A.epi == CAGC_EPI_STYLED);
+  const float nw = (styled && A.noise) ? A.noise_w[0] : 0.f;
+  const int oy = y0 + 2 * wn, ox = x0 + 2 * lm;
+  float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  if (wx == 0 && styled && A.noise) {
+    const float* np = A.noise + (A.noise_bstride_on ? (int64_t)b * HW : 0) + (int64_t)oy * A.W + ox;
+    nz[0][0] = nw * np[0]; nz[0][1] = nw * np[1]; nz[1][0] = nw * np[A.W]; nz[1][1] = nw * np[A.W + 1];
+  }
+  float4 part[MB][4];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float p[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a0 = acc[j][i][r], a1 = acc[4 + j][i][r];   // local rows 0,1 of this half
+        if (wx == 0) { p[0][j] = a0 + a1; p[1][j] = a1; }        // global rows 0,1
+        else         { p[0][j] = a0;      p[1][j] = -a0 - a1; }  // global rows 2,3
+      }
+      part[i][r] = make_float4(p[0][0] + p[0][1] + p[0][2], p[0][1] - p[0][2] - p[0][3],
+                               p[1][0] + p[1][1] + p[1][2], p[1][1] - p[1][2] - p[1][3]);
+      if (wx == 1) ex[((wn * MB + i) * 4 + r) * 64 + lane] = part[i][r];
+    }
+  }
+  __syncthreads();
+  if (wx == 0) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + i * 16 + 4 * g + r;
+        if (m < A.Cout) {
+          const float4 o = ex[((wn * MB + i) * 4 + r) * 64 + lane];
+          const float osc = A.out_scale ? A.out_scale[b * A.Cout + m] : 1.f;
+          const float bs = styled ? A.bias[m] : 0.f;
+          float y[2][2] = {{(part[i][r].x + o.x) * osc, (part[i][r].y + o.y) * osc},
+                           {(part[i][r].z + o.z) * osc, (part[i][r].w + o.w) * osc}};
+          float* op = A.out + ((int64_t)(b * A.Cout + m)) * HW + (int64_t)oy * A.W + ox;
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            float y0v = y[a][0], y1v = y[a][1];
+            if (styled) {
+              y0v += nz[a][0] + bs; y1v += nz[a][1] + bs;
+              y0v = (y0v > 0.f ? y0v : y0v * A.alpha) * A.act_scale;
+              y1v = (y1v > 0.f ? y1v : y1v * A.alpha) * A.act_scale;
+            }
+            *reinterpret_cast<float2*>(op + (int64_t)a * A.W) = make_float2(y0v, y1v);
+          }
+        }
+      }
+    }
+  }
+}
+
+// U[xi=(i,j)][k][m] = scale * sum_{a,b} G[i][a] g[a][b] G[j][b],  g = w[o][c] (fwd: k=c, m=o) or the flipped kernel with
+// swapped channel roles (dgrad: k=o, m=c, g[a][b] = w[o][c][2-a][2-b])
+__global__ __launch_bounds__(256) void k_wino_pack(float* __restrict__ up, const float* __restrict__ w, int Cout, int Cin,
+                                                   int Kp, int Mp, float scale, int dgrad) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over [Kp][Mp]
+  if (idx >= (int64_t)Kp * Mp) return;
+  const int m = (int)(idx % Mp), k = (int)(idx / Mp);
+  const int o = dgrad ? k : m, c = dgrad ? m : k;
+  float gk[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      float v = 0.f;
+      if (o < Cout && c < Cin) v = w[((int64_t)o * Cin + c) * 9 + (dgrad ? (2 - a) * 3 + (2 - bb) : a * 3 + bb)] * scale;
+      gk[a][bb] = v;
+    }
+  float t[4][3];
+#pragma unroll
+  for (int bb = 0; bb < 3; ++bb) {
+    t[0][bb] = gk[0][bb];
+    t[1][bb] = 0.5f * (gk[0][bb] + gk[1][bb] + gk[2][bb]);
+    t[2][bb] = 0.5f * (gk[0][bb] - gk[1][bb] + gk[2][bb]);
+    t[3][bb] = gk[2][bb];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
+    const int64_t plane = (int64_t)Kp * Mp;
+    up[(int64_t)(4 * i + 0) * plane + idx] = u0;
+    up[(int64_t)(4 * i + 1) * plane + idx] = u1;
+    up[(int64_t)(4 * i + 2) * plane + idx] = u2;
+    up[(int64_t)(4 * i + 3) * plane + idx] = u3;
+  }
+}
+
+template <int MB>
+static int launch_wino(WinoArgs& a, hipStream_t st, const char* what) {
+  constexpr int MT = MB * 16;
+  constexpr int LDA = (MT % 32 == 0) ? MT + 16 : MT;
+  size_t smem = sizeof(float) * ((size_t)16 * WCK * LDA + (size_t)16 * WCK * W_VS + (size_t)WCK * (W_IH * W_IWP + 16));
+  const size_t exch = sizeof(float) * 4 * (size_t)4 * MB * 4 * 64;   // partial-output exchange between the two xi halves
+  if (smem < exch) smem = exch;
+  static bool attr[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr[dev] = true;
+  }
+  a.mtiles = cdiv(a.Mp, MT);
+  CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
+  hipLaunchKernelGGL((k_wino<MB>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(512), smem, st, a);
+  return check_launch(what);
+}
+
+}  // namespace cagc
+
+using namespace cagc;
+
+extern "C" int cagc_wino_eligible(int H, int W) { return (H % WTH == 0 && W % WTW == 0) ? 1 : 0; }
+
+extern "C" int64_t cagc_wino_packed_elems(int K, int M) { return (int64_t)16 * round_up(K, 4) * round_up(M, 16); }
+
+extern "C" int cagc_wino_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad,
+                              cagc_stream_t stream) {
+  CAGC_REQUIRE(up && weight && Cout > 0 && Cin > 0, "cagc_wino_prep: bad argument");
+  const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
+  const int Kp = round_up(K, 4), Mp = round_up(M, 16);
+  hipLaunchKernelGGL(k_wino_pack, dim3(cdiv((int64_t)Kp * Mp, 256)), dim3(256), 0, as_stream(stream), up, weight, Cout, Cin,
+                     Kp, Mp, scale, dgrad);
+  return check_launch("cagc_wino_prep");
+}
+
+extern "C" int cagc_wino_conv3x3(float* out, const float* x, const float* up, const float* s, int B, int Cin, int Cout,
+                                 int H, int W, int epi, const float* out_scale, const float* noise, int noise_batch,
+                                 const float* noise_w, const float* bias, float alpha, float act_scale,
+                                 cagc_stream_t stream) {
+  const char* what = "cagc_wino_conv3x3";
+  CAGC_REQUIRE(out && x && up, "%s: null tensor", what);
+  CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
+  CAGC_REQUIRE(cagc_wino_eligible(H, W), "%s: needs H %% 8 == 0 and W %% 32 == 0 (got %dx%d)", what, H, W);
+  CAGC_REQUIRE(epi == CAGC_EPI_LINEAR || epi == CAGC_EPI_STYLED, "%s: bad epilogue %d", what, epi);
+  CAGC_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 8) == 0, "%s: unaligned tensor", what);
+  if (epi == CAGC_EPI_STYLED) {
+    CAGC_REQUIRE(bias, "%s: styled epilogue needs bias", what);
+    CAGC_REQUIRE(!noise || (noise_w && (noise_batch == 1 || noise_batch == B)), "%s: bad noise arguments", what);
+  }
+  CAGC_REQUIRE((int64_t)B * Cin * H * W < (1ll << 31), "%s: input too large for 32-bit offsets", what);
+  WinoArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = x; a.out = out; a.up = up; a.in_scale = s; a.out_scale = out_scale; a.noise = noise; a.noise_w = noise_w; a.bias = bias;
+  a.B = B; a.Cin = Cin; a.Kp = round_up(Cin, 4); a.Cout = Cout; a.Mp = round_up(Cout, 16); a.H = H; a.W = W;
+  a.tiles_x = W / WTW; a.tiles_y = H / WTH; a.nblocks = B * a.tiles_x * a.tiles_y;
+  a.epi = epi; a.noise_bstride_on = (noise_batch == B) ? 1 : 0; a.alpha = alpha; a.act_scale = act_scale;
+  const int nblk = a.Mp / 16;
+  hipStream_t st = as_stream(stream);
+  if (nblk <= 3 || (nblk % 4 != 0 && nblk % 3 == 0)) {
+    if (nblk == 1) return launch_wino<1>(a, st, what);
+    if (nblk == 2) return launch_wino<2>(a, st, what);
+    return launch_wino<3>(a, st, what);
+  }
+  return launch_wino<4>(a, st, what);
+}

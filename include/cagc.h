@@ -179,6 +179,21 @@ int cagc_modconv_wgrad(float* gweight, float* workspace, const float* g, const f
                        cagc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Winograd F(2x2,3x3) path          same contract as cagc_modconv_fwd (k = 3, stride 1, "same"), for layers with
+ *                                   H % 8 == 0 and W % 32 == 0 (cagc_wino_eligible): 16 GEMMs on transformed 4x4
+ *                                   tiles, 2.25x fewer fp32 MFMA flops than the direct implicit GEMM; all fp32.
+ * cagc_wino_prep: weight [Cout,Cin,3,3] -> up [16][Kp][Mp] = scale * G g G^T.  dgrad = 0: K = Cin, M = Cout
+ *   (forward);  dgrad = 1: flipped taps, K = Cout, M = Cin — cagc_wino_conv3x3 on that packing with
+ *   (Cin, Cout) swapped IS the data gradient of the conv.
+ * ---------------------------------------------------------------------------------------------- */
+int cagc_wino_eligible(int H, int W);
+int64_t cagc_wino_packed_elems(int K, int M);
+int cagc_wino_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad, cagc_stream_t stream);
+int cagc_wino_conv3x3(float* out, const float* x, const float* up, const float* s, int B, int Cin, int Cout, int H,
+                      int W, int epi, const float* out_scale, const float* noise, int noise_batch,
+                      const float* noise_w, const float* bias, float alpha, float act_scale, cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Discriminator down-sampling conv  replaces the reference's Blur(pad=(2,2)) -> EqualConv2d(3x3, stride 2,
  *                                   padding 0) pair (model.py:683-706; there: upfirdn2d + cuDNN) where it sits
  *                                   on the KD step's path (D forward + data gradient, D frozen).
