@@ -86,7 +86,7 @@ struct ConvArgs {
 
 // NV = max float4 (vec) / float (scalar) input elements staged per thread per chunk
 template <int MB, int NV, bool VEC, bool GS, int NPH>
-__global__ __launch_bounds__(256, ((NV <= 4 && !(GS && MB == 8) && NPH == 1) ? 2 : 1)) void k_conv_igemm(const ConvArgs A) {
+__global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS && MB == 8) && NPH == 1) ? 2 : 1)) void k_conv_igemm(const ConvArgs A) {
   constexpr int CK = CONV_CK;
   constexpr int MT = MB * 16;
   constexpr int LDA = (MT % 32 == 0) ? MT + 16 : MT;
@@ -501,7 +501,7 @@ static int launch_conv_nv(ConvArgs& a, int nv, size_t smem, dim3 grid, hipStream
 
 // Fill tile geometry for every work item and launch.
 static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, const char* what, bool zero_out = true,
-                    bool allow_split = true) {
+                    bool allow_split = true, int force_mb = 0) {
   CAGC_REQUIRE(nitems <= MAX_ITEMS, "%s: too many work items", what);
   int min_dy = 1 << 20, max_dy = -(1 << 20), min_dx = 1 << 20, max_dx = -(1 << 20);
   for (int p = 0; p < nitems; ++p)
@@ -516,7 +516,8 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   const int nph = raw[0].nph;
   const int nblk = a.Mp / 16;
   int mb;
-  if (nph == 4) mb = (nblk <= 5) ? nblk : ((nblk % 5 == 0) ? 5 : (nblk % 4 == 0 ? 4 : (nblk % 3 == 0 ? 3 : 4)));
+  if (force_mb) mb = force_mb;
+  else if (nph == 4) mb = (nblk <= 5) ? nblk : ((nblk % 5 == 0) ? 5 : (nblk % 4 == 0 ? 4 : (nblk % 3 == 0 ? 3 : 4)));
   else if (nblk <= 5) mb = nblk;
   else if (nblk % 8 == 0) mb = 8;
   else if (nblk % 5 == 0) mb = 5;
@@ -602,6 +603,9 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   const size_t smem = sizeof(float) * ((size_t)MAX_TAPS * CONV_CK * LDA + (size_t)CONV_CK * max_ps);
   CAGC_REQUIRE(smem <= 160 * 1024, "%s: LDS tile %zu B too large", what, smem);
   const int nv = cdiv(max_units, 256);
+  // large staging footprints (stride-2 / multi-plane inputs) do not fit 2 waves / SIMD next to 8 channel blocks of
+  // accumulators: use 4 channel blocks there (measured faster than 8 blocks at 1 wave / SIMD)
+  if (!force_mb && nv > 4 && mb == 8 && a.vec) return run_conv(a, raw, nitems, st, what, zero_out, allow_split, 4);
   if (ks > 1 && zero_out) {
     const size_t bytes = sizeof(float) * (size_t)a.B * a.Cout * a.NPout * a.Hout * a.Wopitch;
     { int zrc = zero_fill(a.out, bytes, st); if (zrc) return zrc; }
