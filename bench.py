@@ -50,7 +50,20 @@ def conv_flops(name, a):
     if name == "cagc_modconv_wgrad":     # (gw,ws,g,x,s,B,Cin,Cout,H,W,k,up,scale)
         B, cin, cout, H, W, k = a[5:11]
         return 2.0 * B * cin * cout * k * k * H * W
+    if name == "cagc_wino_conv3x3":      # (out,x,up,s,B,Cin,Cout,H,W,...): Winograd F(2x2,3x3) — count the flops the
+        B, cin, cout, H, W = a[4:9]      # MFMA pipe EXECUTES (16 GEMMs over H/2*W/2 tiles = 4 MACs per output pixel
+        return 2.0 * B * cin * cout * 4 * H * W   # and channel pair), not the 9 of the direct conv it replaces
+    if name in ("cagc_conv3x3s2_fwd", "cagc_conv3x3s2_dgrad"):   # (out,x,wp,B,Cin,Cout,Hin,Win,pitch)
+        B, cin, cout, hin, win = a[3:8]
+        return 2.0 * B * cin * cout * 9 * ((hin - 3) // 2 + 1) * ((win - 3) // 2 + 1)
     return 0.0
+
+
+# dominant-entry-point -> device symbol (for the PMC traffic lookup) and MFMA instruction
+KERNEL_OF = {"cagc_wino_conv3x3": "k_wino<4>", "cagc_modconv_fwd": "k_conv_igemm<8, 4, true, false, 1>",
+             "cagc_modconv_up_fwd": "k_conv_igemm<8, 4, true, false, 1>",
+             "cagc_modconv_dgrad": "k_conv_igemm<8, 12, true, false, 1>",
+             "cagc_modconv_up_dgrad": "k_conv_igemm<8, 12, true, false, 1>", "cagc_modconv_wgrad": "k_wgrad2<5, 2>"}
 
 
 def pmc_traffic(symbol):
@@ -70,9 +83,9 @@ def pmc_traffic(symbol):
     if len(vals) != 2:
         return None, "kernel not found in PMC summary"
     return int(2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]), (
-        f"avg bytes/launch of {symbol} (the MFMA kernel behind cagc_modconv_fwd/up_fwd/conv3x3s2) from rocprofv3 --pmc "
-        f"passes: 2x FETCH_SIZE + WRITE_SIZE; MFMA-bound kernel, re-reads of the input halo tile by the 4 channel tiles "
-        f"are served by L2/MALL")
+        f"avg HBM bytes/launch of {symbol} from the committed rocprofv3 --pmc passes (profiles/r01_pmc_*.md): "
+        f"2x FETCH_SIZE + WRITE_SIZE; MFMA-bound kernel, re-reads of the input tiles by the channel tiles are served "
+        f"by L2/MALL")
 
 
 class KernelTimer:
@@ -221,12 +234,17 @@ def main():
             mfma = {k: v for k, v in agg.items() if v[2] > 0}
             name, (cnt, tot_ms, flops) = max(mfma.items(), key=lambda kv: kv[1][1])
             ach = flops / (tot_ms * 1e-3) / 1e12
-            traffic, traffic_note = pmc_traffic("k_conv_igemm<8, 4, true, false, 1>")
-            roof = {"bound": "mfma", "kernel": name + " (k_conv_igemm, v_mfma_f32_16x16x4_f32)",
+            sym = KERNEL_OF.get(name, name)
+            traffic, traffic_note = pmc_traffic(sym)
+            roof = {"bound": "mfma", "kernel": f"{name} ({sym}, v_mfma_f32_16x16x4_f32)",
                     "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "launches_per_step": cnt // 3, "avg_launch_ms": round(tot_ms / cnt, 4),
                     "flops_per_launch_avg": flops / cnt,
+                    "flops_note": "MFMA flops executed (Winograd: 4 MACs/output/channel-pair; its direct-conv equivalent "
+                                  "rate is 2.25x 'achieved')" if name == "cagc_wino_conv3x3" else "2*MACs of the conv",
+                    "all_mfma_entry_points": {k: {"ms_per_step": round(v[1] / 3, 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
+                                              for k, v in sorted(mfma.items(), key=lambda kv: -kv[1][1])},
                     "cagc_kernel_ms_per_step": {k: round(v[1] / 3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
     full = None
     if world == 1 and not args.no_full_iteration:

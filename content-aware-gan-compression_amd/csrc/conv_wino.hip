@@ -12,9 +12,13 @@
 // acc[8][MB] (4 VGPRs each) -> 2 waves / SIMD.  The output transform A^T M A is linear in M: each half transforms its
 // own 8 positions in registers, the halves are added through LDS once per workgroup, and every lane stores 2x2 pixels
 // (8-byte stores, 128 B contiguous per 16-lane group).  Per K-chunk of 8 input channels:
-//   raw halo tile [8][10][40] + U slab [16*8][M_T]  --(registers, prefetched one chunk ahead)-->  LDS
-//   every thread transforms 2 (channel, tile) patches  raw -> V[16*8][64 tiles]  (LDS -> LDS)
-//   16 xi x 2 K-steps x MB MFMAs per wave out of LDS (strides == 16 mod 32: conflict-free ds_read_b32 halves)
+//   A operand: transformed weights U, pre-packed in MFMA register order, go global/L2 -> VGPRs directly (one 16-byte
+//     load per lane feeds MB MFMAs; a ring of 8 loads runs half a chunk ahead) — they never touch LDS, which was the
+//     co-bottleneck of the first version (LDS cycles per chunk ~= MFMA cycles per chunk);
+//   B operand: raw halo tile [8][10][40] --(registers, 3 chunks ahead)--> LDS (2 buffers) --transform, 1 (channel,tile)
+//     patch per thread--> V[16*8][64 tiles] in LDS (2 buffers, stride == 16 mod 32: conflict-free ds_read_b32);
+//   one barrier per chunk; of the two waves sharing a SIMD one transforms chunk j+1 before multiplying chunk j, the
+//   other after, so the matrix pipe has work while the other wave is in the VALU/LDS phase.
 // The per-sample modulation s[b,c] is applied to the staged input, demodulation / noise / bias / LeakyReLU in the
 // epilogue — same contract as cagc_modconv_fwd.  The data gradient of such a conv is the same kernel on weights
 // packed with flipped taps and swapped channel roles (cagc_wino_prep(..., dgrad = 1)).
@@ -33,7 +37,7 @@ constexpr int W_VS = 80;    // V row stride: 64 tiles, == 16 (mod 32)
 struct WinoArgs {
   const float* in;
   float* out;
-  const float* up;         // [16][Kp][Mp]
+  const float* up;         // [mtiles][16][Kp/4][64][4]  (k_wino_pack)
   const float* in_scale;   // [B,Cin] or null
   const float* out_scale;  // [B,Cout] or null
   const float* noise;
@@ -49,19 +53,17 @@ template <int MB>
 __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   constexpr int CK = WCK;
   constexpr int MT = MB * 16;
-  constexpr int LDA = (MT % 32 == 0) ? MT + 16 : MT;
-  constexpr int Q4M = MT / 4;
-  constexpr int NU = (16 * CK * Q4M + 511) / 512;   // float4 of the U slab per thread per chunk
   constexpr int RPS = W_IH * W_IWP + 16;            // raw channel-plane stride
+  constexpr int VSZ = 16 * CK * W_VS, RSZ = CK * RPS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* u_lds = smem;                         // [16*CK][LDA]
-  float* v_lds = u_lds + 16 * CK * LDA;        // [16*CK][W_VS]
-  float* raw = v_lds + 16 * CK * W_VS;         // [CK][RPS]
+  float* v_lds = smem;                         // [2][16*CK][W_VS]
+  float* raw = v_lds + 2 * VSZ;                // [2][CK][RPS]
 
   // 8 wavefronts: wn = Winograd-tile row (16 tiles = one MFMA N-block), wx = which half of the 16 positions xi.
-  // Two waves per SIMD, each with 8*MB accumulators: the two halves hide each other's LDS latency.
+  // Waves w and w+4 share a SIMD: the wx = 0 wave transforms the next chunk first and multiplies second, the wx = 1
+  // wave the other way round, so the MFMA pipe of every SIMD always has a wave feeding it.
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 3, wx = wave >> 2;
   const int lm = lane & 15, g = lane >> 4;
 
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   const int x0 = tx_i * WTW, y0 = ty_i * WTH;
   const int m0 = mtile * MT;
   const int HW = A.H * A.W;
+  const int nch = A.Kp / CK;
 
   // ---- staging descriptors: raw tile = CK x 10 rows x 10 float4 = 800 units -> 2 per thread ------------------
   int e_goff[2], e_loff[2], e_meta[2];
@@ -100,8 +103,8 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   }
   float4 rin[2];
   float rsc[2];
-  float4 ru[NU];
-  auto prefetch = [&](int kc) {
+  auto prefetch = [&](int j) {   // global -> registers, chunk j (no-op past the end)
+    const int kc = j * CK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int meta = e_meta[i];
@@ -114,34 +117,54 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
         if (A.in_scale) rsc[i] = A.in_scale[b * A.Cin + kc + c];
       }
     }
-#pragma unroll
-    for (int k = 0; k < NU; ++k) {
-      const int q = tid + 512 * k;
-      const int row = q / Q4M, col = (q - row * Q4M) * 4;   // row = xi*CK + c
-      const int xi = row / CK, c = row - xi * CK;
-      ru[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < 16 * CK * Q4M && kc + c < A.Kp && m0 + col < A.Mp)
-        ru[k] = *reinterpret_cast<const float4*>(A.up + ((int64_t)xi * A.Kp + kc + c) * A.Mp + m0 + col);
-    }
   };
-  auto commit = [&]() {
+  auto commit = [&](float* rbuf) {   // registers -> raw tile in LDS
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       if (e_meta[i] & 0x40000000) {
         float4 v = rin[i];
         const float s = rsc[i];
         v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-        *reinterpret_cast<float4*>(raw + e_loff[i]) = v;
+        *reinterpret_cast<float4*>(rbuf + e_loff[i]) = v;
       }
+  };
+  // input transform V = B^T d B, one (channel, tile) patch per thread (512 = CK * 64): raw tile -> V slab
+  auto transform = [&](const float* rbuf, float* vbuf) {
+    const int c = wave, tile = lane;
+    const int ty = tile >> 4, tx = tile & 15;
+    const float* p = rbuf + c * RPS + (2 * ty) * W_IWP + 3 + 2 * tx;   // patch origin: row y0-1+2ty, col x0-1+2tx
+    float d[4][4];
 #pragma unroll
-    for (int k = 0; k < NU; ++k) {
-      const int q = tid + 512 * k;
-      if (q < 16 * CK * Q4M) {
-        const int row = q / Q4M, col = (q - row * Q4M) * 4;
-        *reinterpret_cast<float4*>(u_lds + row * LDA + col) = ru[k];
-      }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[r][q] = p[r * W_IWP + q];
+    float t[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // rows: B^T d
+      t[0][q] = d[0][q] - d[2][q];
+      t[1][q] = d[1][q] + d[2][q];
+      t[2][q] = d[2][q] - d[1][q];
+      t[3][q] = d[1][q] - d[3][q];
+    }
+    float* vp = vbuf + c * W_VS + tile;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // columns: (B^T d) B ; xi = 4*r + col
+      vp[((4 * r + 0) * CK) * W_VS] = t[r][0] - t[r][2];
+      vp[((4 * r + 1) * CK) * W_VS] = t[r][1] + t[r][2];
+      vp[((4 * r + 2) * CK) * W_VS] = t[r][2] - t[r][1];
+      vp[((4 * r + 3) * CK) * W_VS] = t[r][1] - t[r][3];
     }
   };
+
+  // ---- A operand (transformed weights): straight from global / L2 into MFMA register layout, no LDS ------------------
+  // packed as [mtile][xi][Kp/4][lane = (k % 4, m % 16)][4 channel blocks]: one 16-byte load per lane feeds MB MFMAs.
+  // Stream order of this wave: chunk j, position x8 = 0..7, K-step s = 0..1  ->  element t = 2*x8 + s;  a ring of 8
+  // loads (half a chunk, ~1000+ cycles of MFMA work) runs ahead of the multiplies.
+  const int KQ = A.Kp / 4;
+  const float4* ua = reinterpret_cast<const float4*>(A.up) + ((int64_t)mtile * 16 + wx * 8) * KQ * 64 + lane;
+  float4 ring[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) ring[t] = ua[((int64_t)(t >> 1) * KQ + (t & 1)) * 64];
 
   f32x4 acc[8][MB];
 #pragma unroll
@@ -149,55 +172,44 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
 #pragma unroll
     for (int i = 0; i < MB; ++i) acc[xi][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  auto gemms = [&](const float* vbuf, int j) {   // this wave's 8 of the 16 GEMMs on chunk j
+    const int jn = (j + 1 < nch) ? j + 1 : j;   // last chunk: re-read valid data instead of branching (keeps vmcnt exact)
+    const float* vb = vbuf + (wx * 8 * CK + g) * W_VS + wn * 16 + lm;   // step t = (x8, s): row (x8*CK + 4*s) * W_VS
+    float bv = vb[0];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int x8 = t >> 1, s = t & 1;
+      float bvn = 0.f;
+      if (t < 15) bvn = vb[(((t + 1) >> 1) * CK + 4 * ((t + 1) & 1)) * W_VS];   // B operand one step ahead
+      const float4 a4 = ring[t & 7];
+      if (t < 8) ring[t & 7] = ua[((int64_t)(x8 + 4) * KQ + 2 * j + s) * 64];
+      else ring[t & 7] = ua[((int64_t)(x8 - 4) * KQ + 2 * jn + s) * 64];
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int i = 0; i < MB; ++i) acc[x8][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[x8][i], 0, 0, 0);
+      bv = bvn;
+      __builtin_amdgcn_sched_barrier(0);   // keep the ring load 8 steps ahead of its use (the scheduler sinks it otherwise)
+    }
+  };
+
+  // ---- pipeline: raw tiles two chunks ahead in LDS (+ one more in registers), V slabs one chunk ahead ----------------
   prefetch(0);
-  for (int kc = 0; kc < A.Kp; kc += CK) {
+  commit(raw);
+  prefetch(1);
+  __syncthreads();
+  transform(raw, v_lds);
+  commit(raw + RSZ);
+  prefetch(2);
+  __syncthreads();
+  for (int j = 0; j < nch; ++j) {
+    const int cur = j & 1;
+    // raw[cur] (chunk j) was consumed during iteration j-1: refill it with chunk j+2, fetch chunk j+3
+    commit(raw + cur * RSZ);
+    prefetch(j + 3);
+    if (wx == 0 && j + 1 < nch) transform(raw + (cur ^ 1) * RSZ, v_lds + (cur ^ 1) * VSZ);
+    gemms(v_lds + cur * VSZ, j);
+    if (wx != 0 && j + 1 < nch) transform(raw + (cur ^ 1) * RSZ, v_lds + (cur ^ 1) * VSZ);
     __syncthreads();
-    commit();
-    __syncthreads();
-    // ---- input transform: V = B^T d B, one (channel, tile) patch per thread (512 = CK * 64) ----------------------
-    {
-      const int c = tid >> 6, tile = tid & 63;
-      const int ty = tile >> 4, tx = tile & 15;
-      const float* p = raw + c * RPS + (2 * ty) * W_IWP + 3 + 2 * tx;   // patch origin: row y0-1+2ty, col x0-1+2tx
-      float d[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) d[r][q] = p[r * W_IWP + q];
-      float t[4][4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {   // rows: B^T d
-        t[0][q] = d[0][q] - d[2][q];
-        t[1][q] = d[1][q] + d[2][q];
-        t[2][q] = d[2][q] - d[1][q];
-        t[3][q] = d[1][q] - d[3][q];
-      }
-      float* vp = v_lds + c * W_VS + tile;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {   // columns: (B^T d) B ; xi = 4*r + col
-        vp[((4 * r + 0) * CK) * W_VS] = t[r][0] - t[r][2];
-        vp[((4 * r + 1) * CK) * W_VS] = t[r][1] + t[r][2];
-        vp[((4 * r + 2) * CK) * W_VS] = t[r][2] - t[r][1];
-        vp[((4 * r + 3) * CK) * W_VS] = t[r][1] - t[r][3];
-      }
-    }
-    __syncthreads();
-    if (kc + CK < A.Kp) prefetch(kc + CK);
-    // ---- this wave's 8 of the 16 GEMMs -----------------------------------------------------------------------------
-#pragma unroll
-    for (int x8 = 0; x8 < 8; ++x8) {
-      const int xi = wx * 8 + x8;
-#pragma unroll
-      for (int s = 0; s < CK / 4; ++s) {
-        const int kk = 4 * s + g;
-        const float bv = v_lds[(xi * CK + kk) * W_VS + wn * 16 + lm];
-        float av[MB];
-#pragma unroll
-        for (int i = 0; i < MB; ++i) av[i] = u_lds[(xi * CK + kk) * LDA + i * 16 + lm];
-#pragma unroll
-        for (int i = 0; i < MB; ++i) acc[x8][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[x8][i], 0, 0, 0);
-      }
-    }
   }
 
   // ---- output transform (linear in M: each half transforms its own 8 positions, the halves are summed through LDS)
@@ -261,12 +273,15 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
 }
 
 // U[xi=(i,j)][k][m] = scale * sum_{a,b} G[i][a] g[a][b] G[j][b],  g = w[o][c] (fwd: k=c, m=o) or the flipped kernel with
-// swapped channel roles (dgrad: k=o, m=c, g[a][b] = w[o][c][2-a][2-b])
+// swapped channel roles (dgrad: k=o, m=c, g[a][b] = w[o][c][2-a][2-b]);  stored in MFMA A-operand order
+//   up[mtile][xi][k/4][k%4][m%16][4]  with m = mtile*MT + blk*16 + m%16, blk < MB = MT/16 (zero beyond)
 __global__ __launch_bounds__(256) void k_wino_pack(float* __restrict__ up, const float* __restrict__ w, int Cout, int Cin,
-                                                   int Kp, int Mp, float scale, int dgrad) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over [Kp][Mp]
-  if (idx >= (int64_t)Kp * Mp) return;
-  const int m = (int)(idx % Mp), k = (int)(idx / Mp);
+                                                   int Kp, int mtiles, int MB, float scale, int dgrad) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over [mtiles][Kp/4][64][4]
+  if (idx >= (int64_t)mtiles * Kp * 64) return;
+  const int blk = (int)(idx & 3), ln = (int)((idx >> 2) & 63);
+  const int kq = (int)((idx >> 8) % (Kp / 4)), mt = (int)((idx >> 8) / (Kp / 4));
+  const int k = 4 * kq + (ln >> 4), m = mt * MB * 16 + blk * 16 + (ln & 15);
   const int o = dgrad ? k : m, c = dgrad ? m : k;
   float gk[3][3];
 #pragma unroll
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(256) void k_wino_pack(float* __restrict__ up, const
 #pragma unroll
     for (int bb = 0; bb < 3; ++bb) {
       float v = 0.f;
-      if (o < Cout && c < Cin) v = w[((int64_t)o * Cin + c) * 9 + (dgrad ? (2 - a) * 3 + (2 - bb) : a * 3 + bb)] * scale;
+      if (blk < MB && o < Cout && c < Cin) v = w[((int64_t)o * Cin + c) * 9 + (dgrad ? (2 - a) * 3 + (2 - bb) : a * 3 + bb)] * scale;
       gk[a][bb] = v;
     }
   float t[4][3];
@@ -285,22 +300,30 @@ __global__ __launch_bounds__(256) void k_wino_pack(float* __restrict__ up, const
     t[2][bb] = 0.5f * (gk[0][bb] - gk[1][bb] + gk[2][bb]);
     t[3][bb] = gk[2][bb];
   }
+  const int64_t xs = (int64_t)(Kp / 4) * 256;                                  // stride between positions xi
+  float* dst = up + ((int64_t)mt * 16 * (Kp / 4) + kq) * 256 + ln * 4 + blk;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
-    const int64_t plane = (int64_t)Kp * Mp;
-    up[(int64_t)(4 * i + 0) * plane + idx] = u0;
-    up[(int64_t)(4 * i + 1) * plane + idx] = u1;
-    up[(int64_t)(4 * i + 2) * plane + idx] = u2;
-    up[(int64_t)(4 * i + 3) * plane + idx] = u3;
+    dst[(4 * i + 0) * xs] = u0;
+    dst[(4 * i + 1) * xs] = u1;
+    dst[(4 * i + 2) * xs] = u2;
+    dst[(4 * i + 3) * xs] = u3;
   }
+}
+
+// channel blocks (of 16) per workgroup tile for M output channels: 4, or fewer when that wastes less of the last tile
+static int wino_mb(int M) {
+  const int nblk = cdiv(M, 16);
+  if (nblk <= 3) return nblk;
+  if (nblk % 4 != 0 && nblk % 3 == 0) return 3;
+  return 4;
 }
 
 template <int MB>
 static int launch_wino(WinoArgs& a, hipStream_t st, const char* what) {
   constexpr int MT = MB * 16;
-  constexpr int LDA = (MT % 32 == 0) ? MT + 16 : MT;
-  size_t smem = sizeof(float) * ((size_t)16 * WCK * LDA + (size_t)16 * WCK * W_VS + (size_t)WCK * (W_IH * W_IWP + 16));
+  size_t smem = sizeof(float) * ((size_t)2 * 16 * WCK * W_VS + (size_t)2 * WCK * (W_IH * W_IWP + 16));
   const size_t exch = sizeof(float) * 4 * (size_t)4 * MB * 4 * 64;   // partial-output exchange between the two xi halves
   if (smem < exch) smem = exch;
   static bool attr[64] = {};
@@ -310,7 +333,7 @@ static int launch_wino(WinoArgs& a, hipStream_t st, const char* what) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr[dev] = true;
   }
-  a.mtiles = cdiv(a.Mp, MT);
+  a.mtiles = cdiv(a.Cout, MT);
   CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
   hipLaunchKernelGGL((k_wino<MB>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(512), smem, st, a);
   return check_launch(what);
@@ -322,15 +345,19 @@ using namespace cagc;
 
 extern "C" int cagc_wino_eligible(int H, int W) { return (H % WTH == 0 && W % WTW == 0) ? 1 : 0; }
 
-extern "C" int64_t cagc_wino_packed_elems(int K, int M) { return (int64_t)16 * round_up(K, 4) * round_up(M, 16); }
+extern "C" int64_t cagc_wino_packed_elems(int K, int M) {
+  if (K <= 0 || M <= 0) return 0;
+  const int mb = wino_mb(M);
+  return (int64_t)cdiv(M, mb * 16) * 16 * round_up(K, WCK) * 64;
+}
 
 extern "C" int cagc_wino_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad,
                               cagc_stream_t stream) {
   CAGC_REQUIRE(up && weight && Cout > 0 && Cin > 0, "cagc_wino_prep: bad argument");
   const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
-  const int Kp = round_up(K, 4), Mp = round_up(M, 16);
-  hipLaunchKernelGGL(k_wino_pack, dim3(cdiv((int64_t)Kp * Mp, 256)), dim3(256), 0, as_stream(stream), up, weight, Cout, Cin,
-                     Kp, Mp, scale, dgrad);
+  const int Kp = round_up(K, WCK), mb = wino_mb(M), mtiles = cdiv(M, mb * 16);
+  hipLaunchKernelGGL(k_wino_pack, dim3(cdiv((int64_t)mtiles * Kp * 64, 256)), dim3(256), 0, as_stream(stream), up, weight,
+                     Cout, Cin, Kp, mtiles, mb, scale, dgrad);
   return check_launch("cagc_wino_prep");
 }
 
@@ -352,15 +379,14 @@ extern "C" int cagc_wino_conv3x3(float* out, const float* x, const float* up, co
   WinoArgs a;
   memset(&a, 0, sizeof(a));
   a.in = x; a.out = out; a.up = up; a.in_scale = s; a.out_scale = out_scale; a.noise = noise; a.noise_w = noise_w; a.bias = bias;
-  a.B = B; a.Cin = Cin; a.Kp = round_up(Cin, 4); a.Cout = Cout; a.Mp = round_up(Cout, 16); a.H = H; a.W = W;
+  a.B = B; a.Cin = Cin; a.Kp = round_up(Cin, WCK); a.Cout = Cout; a.Mp = round_up(Cout, 16); a.H = H; a.W = W;
   a.tiles_x = W / WTW; a.tiles_y = H / WTH; a.nblocks = B * a.tiles_x * a.tiles_y;
   a.epi = epi; a.noise_bstride_on = (noise_batch == B) ? 1 : 0; a.alpha = alpha; a.act_scale = act_scale;
-  const int nblk = a.Mp / 16;
   hipStream_t st = as_stream(stream);
-  if (nblk <= 3 || (nblk % 4 != 0 && nblk % 3 == 0)) {
-    if (nblk == 1) return launch_wino<1>(a, st, what);
-    if (nblk == 2) return launch_wino<2>(a, st, what);
-    return launch_wino<3>(a, st, what);
+  switch (wino_mb(Cout)) {
+    case 1: return launch_wino<1>(a, st, what);
+    case 2: return launch_wino<2>(a, st, what);
+    case 3: return launch_wino<3>(a, st, what);
+    default: return launch_wino<4>(a, st, what);
   }
-  return launch_wino<4>(a, st, what);
 }

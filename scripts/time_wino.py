@@ -1,0 +1,18 @@
+import os, sys, ctypes, torch, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "content-aware-gan-compression_amd")]
+from cagc import _lib
+if len(sys.argv) > 1:
+    _lib.LIB_PATH = os.path.join(ROOT, "content-aware-gan-compression_amd", "cagc", sys.argv[1])
+from cagc.op import modconv as mc
+B, C, H = 16, 512, 64
+x = torch.randn(B, C, H, H, device="cuda"); w = torch.randn(C, C, 3, 3, device="cuda")
+up = mc.pack_wino(w, 0.01, False); out = torch.empty_like(x)
+def run():
+    _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(x), _lib.ptr(up), None, B, C, C, H, H, 0, None, None, 0, None, None, 0.2, 1.0)
+for _ in range(3): run()
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(10): run()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
+fl = 2.0 * B * C * C * 9 * H * H
+print(sys.argv[1:] or "default", f"{dt*1e3:.3f} ms  direct-equiv {fl/dt/1e12:.1f} TF  mfma {fl*4/9/dt/1e12:.1f} TF")
