@@ -8,17 +8,19 @@
 // v_mfma_f32_16x16x4_f32; the transforms use the coefficients 0, +-1, +-1/2 only).
 //
 // Workgroup = 512 threads = 8 waves; tile = MB*16 output channels x (8 x 32 output pixels = 4 x 16 Winograd tiles).
-// Wave (wn, wx) owns Winograd-tile row wn (16 tiles = one MFMA N-block) for 8 of the 16 positions xi: accumulators
-// acc[8][MB] (4 VGPRs each) -> 2 waves / SIMD.  The output transform A^T M A is linear in M: each half transforms its
-// own 8 positions in registers, the halves are added through LDS once per workgroup, and every lane stores 2x2 pixels
-// (8-byte stores, 128 B contiguous per 16-lane group).  Per K-chunk of 8 input channels:
+// Wave (q, nh) owns row q of the 4x4 grid of Winograd positions (xi = 4q..4q+3) for half nh of the tiles (2 MFMA
+// N-blocks) and all MB channel blocks: accumulators acc[4][MB][2] (4 VGPRs each) -> 2 waves / SIMD.  Per K-chunk of 8
+// input channels:
 //   A operand: transformed weights U, pre-packed in MFMA register order, go global/L2 -> VGPRs directly (one 16-byte
-//     load per lane feeds MB MFMAs; a ring of 8 loads runs half a chunk ahead) — they never touch LDS, which was the
+//     load per lane feeds 2*MB MFMAs; the ring holds a whole chunk ahead) — they never touch LDS, which was the
 //     co-bottleneck of the first version (LDS cycles per chunk ~= MFMA cycles per chunk);
 //   B operand: raw halo tile [8][10][40] --(registers, 3 chunks ahead)--> LDS (2 buffers) --transform, 1 (channel,tile)
-//     patch per thread--> V[16*8][64 tiles] in LDS (2 buffers, stride == 16 mod 32: conflict-free ds_read_b32);
+//     patch per thread--> V[16*8][64 tiles] in LDS (2 buffers; tiles stored [ty/2][tx][ty%2] so one ds_read_b64 feeds
+//     both N-blocks of a wave; row stride == 16 mod 32);
 //   one barrier per chunk; of the two waves sharing a SIMD one transforms chunk j+1 before multiplying chunk j, the
 //   other after, so the matrix pipe has work while the other wave is in the VALU/LDS phase.
+// Output transform A^T M A: column direction in registers, row direction across the four q waves through LDS, every
+// lane then stores 2x2 pixels (8-byte stores, 128 B contiguous per 16-lane group).
 // The per-sample modulation s[b,c] is applied to the staged input, demodulation / noise / bias / LeakyReLU in the
 // epilogue — same contract as cagc_modconv_fwd.  The data gradient of such a conv is the same kernel on weights
 // packed with flipped taps and swapped channel roles (cagc_wino_prep(..., dgrad = 1)).
@@ -59,12 +61,14 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   float* v_lds = smem;                         // [2][16*CK][W_VS]
   float* raw = v_lds + 2 * VSZ;                // [2][CK][RPS]
 
-  // 8 wavefronts: wn = Winograd-tile row (16 tiles = one MFMA N-block), wx = which half of the 16 positions xi.
-  // Waves w and w+4 share a SIMD: the wx = 0 wave transforms the next chunk first and multiplies second, the wx = 1
-  // wave the other way round, so the MFMA pipe of every SIMD always has a wave feeding it.
+  // 8 wavefronts: wave (q, nh) owns row q of the 4x4 grid of Winograd positions (xi = 4q .. 4q+3) for half nh of the
+  // tiles (2 MFMA N-blocks = Winograd-tile rows 2nh, 2nh+1) and all MB channel blocks: acc[4][MB][2].  Every K-step
+  // is one 16-byte global load (A, 4 channel blocks) + one 8-byte LDS read (B, 2 tile rows) for 2*MB MFMAs.
+  // Waves w and w+4 = (q, 0) and (q, 1) share a SIMD (and their A stream): the nh = 0 wave transforms the next chunk
+  // first and multiplies second, the nh = 1 wave the other way round, so the MFMA pipe always has a wave feeding it.
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave & 3, wx = wave >> 2;
+  const int q = wave & 3, nh = wave >> 2;
   const int lm = lane & 15, g = lane >> 4;
 
   int pix_id, mtile;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
       t[2][q] = d[2][q] - d[1][q];
       t[3][q] = d[1][q] - d[3][q];
     }
-    float* vp = vbuf + c * W_VS + tile;
+    float* vp = vbuf + c * W_VS + (ty >> 1) * 32 + tx * 2 + (ty & 1);   // tile (ty, tx) -> [ty/2][tx][ty%2]: b64 B reads
 #pragma unroll
     for (int r = 0; r < 4; ++r) {   // columns: (B^T d) B ; xi = 4*r + col
       vp[((4 * r + 0) * CK) * W_VS] = t[r][0] - t[r][2];
@@ -157,38 +161,43 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   };
 
   // ---- A operand (transformed weights): straight from global / L2 into MFMA register layout, no LDS ------------------
-  // packed as [mtile][xi][Kp/4][lane = (k % 4, m % 16)][4 channel blocks]: one 16-byte load per lane feeds MB MFMAs.
-  // Stream order of this wave: chunk j, position x8 = 0..7, K-step s = 0..1  ->  element t = 2*x8 + s;  a ring of 8
-  // loads (half a chunk, ~1000+ cycles of MFMA work) runs ahead of the multiplies.
+  // packed as [mtile][xi][Kp/4][lane = (k % 4, m % 16)][4 channel blocks]: one 16-byte load per lane feeds 2*MB MFMAs.
+  // Stream order of this wave: chunk j, grid column c4 = 0..3, K-step s = 0..1  ->  slot t = 2*c4 + s;  the ring holds
+  // one whole chunk, each slot is refilled for chunk j+1 right after it is consumed (~2000 cycles of MFMA work ahead).
   const int KQ = A.Kp / 4;
-  const float4* ua = reinterpret_cast<const float4*>(A.up) + ((int64_t)mtile * 16 + wx * 8) * KQ * 64 + lane;
+  const float4* ua = reinterpret_cast<const float4*>(A.up) + ((int64_t)mtile * 16 + q * 4) * KQ * 64 + lane;
   float4 ring[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) ring[t] = ua[((int64_t)(t >> 1) * KQ + (t & 1)) * 64];
 
-  f32x4 acc[8][MB];
+  f32x4 acc[4][MB][2];
 #pragma unroll
-  for (int xi = 0; xi < 8; ++xi)
+  for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
-    for (int i = 0; i < MB; ++i) acc[xi][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MB; ++i) {
+      acc[c4][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[c4][i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
-  auto gemms = [&](const float* vbuf, int j) {   // this wave's 8 of the 16 GEMMs on chunk j
+  auto gemms = [&](const float* vbuf, int j) {   // this wave's 4 of the 16 GEMMs on chunk j
     const int jn = (j + 1 < nch) ? j + 1 : j;   // last chunk: re-read valid data instead of branching (keeps vmcnt exact)
-    const float* vb = vbuf + (wx * 8 * CK + g) * W_VS + wn * 16 + lm;   // step t = (x8, s): row (x8*CK + 4*s) * W_VS
-    float bv = vb[0];
+    const float2* vb = reinterpret_cast<const float2*>(vbuf + (q * 4 * CK + g) * W_VS + nh * 32 + lm * 2);
+    float2 bv = vb[0];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int x8 = t >> 1, s = t & 1;
-      float bvn = 0.f;
-      if (t < 15) bvn = vb[(((t + 1) >> 1) * CK + 4 * ((t + 1) & 1)) * W_VS];   // B operand one step ahead
-      const float4 a4 = ring[t & 7];
-      if (t < 8) ring[t & 7] = ua[((int64_t)(x8 + 4) * KQ + 2 * j + s) * 64];
-      else ring[t & 7] = ua[((int64_t)(x8 - 4) * KQ + 2 * jn + s) * 64];
+    for (int t = 0; t < 8; ++t) {
+      const int c4 = t >> 1, s = t & 1;
+      float2 bvn = make_float2(0.f, 0.f);
+      if (t < 7) bvn = vb[((((t + 1) >> 1) * CK + 4 * ((t + 1) & 1)) * W_VS) / 2];   // B operand one step ahead
+      const float4 a4 = ring[t];
+      ring[t] = ua[((int64_t)c4 * KQ + 2 * jn + s) * 64];
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-      for (int i = 0; i < MB; ++i) acc[x8][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[x8][i], 0, 0, 0);
+      for (int i = 0; i < MB; ++i) {
+        acc[c4][i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv.x, acc[c4][i][0], 0, 0, 0);
+        acc[c4][i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv.y, acc[c4][i][1], 0, 0, 0);
+      }
       bv = bvn;
-      __builtin_amdgcn_sched_barrier(0);   // keep the ring load 8 steps ahead of its use (the scheduler sinks it otherwise)
+      __builtin_amdgcn_sched_barrier(0);   // keep the ring load a chunk ahead of its use (the scheduler sinks it otherwise)
     }
   };
 
@@ -206,55 +215,52 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
     // raw[cur] (chunk j) was consumed during iteration j-1: refill it with chunk j+2, fetch chunk j+3
     commit(raw + cur * RSZ);
     prefetch(j + 3);
-    if (wx == 0 && j + 1 < nch) transform(raw + (cur ^ 1) * RSZ, v_lds + (cur ^ 1) * VSZ);
+    if (nh == 0 && j + 1 < nch) transform(raw + (cur ^ 1) * RSZ, v_lds + (cur ^ 1) * VSZ);
     gemms(v_lds + cur * VSZ, j);
-    if (wx != 0 && j + 1 < nch) transform(raw + (cur ^ 1) * RSZ, v_lds + (cur ^ 1) * VSZ);
+    if (nh != 0 && j + 1 < nch) transform(raw + (cur ^ 1) * RSZ, v_lds + (cur ^ 1) * VSZ);
     __syncthreads();
   }
 
-  // ---- output transform (linear in M: each half transforms its own 8 positions, the halves are summed through LDS)
-  // lane = (tile (wn, lm), channels m0 + i*16 + 4g + r).  xi = 4*row + col; half 0 holds rows 0,1, half 1 rows 2,3.
-  //   p[0][j] = M0j + M1j + M2j ,  p[1][j] = M1j - M2j - M3j ;  Y[a][0] = p[a][0]+p[a][1]+p[a][2], Y[a][1] = p[a][1]-p[a][2]-p[a][3]
-  __syncthreads();   // all MFMA reads of LDS done: reuse it for the exchange
-  float4* ex = reinterpret_cast<float4*>(smem);   // [wn][i][r][lane] float4 = partial 2x2 outputs
+  // ---- output transform Y = A^T M A.  Row q of the position grid lives in wave (q, nh): the column direction is done
+  // in registers,  z[0] = M[q][0] + M[q][1] + M[q][2],  z[1] = M[q][1] - M[q][2] - M[q][3],  the row direction
+  //   Y[0][b] = z0[b] + z1[b] + z2[b],   Y[1][b] = z1[b] - z2[b] - z3[b]   (subscript = q)
+  // across the four q waves through LDS; wave (f, nh) then finishes tile row 2nh + (f & 1) for the channel blocks
+  // i = f/2, f/2 + 2, ...  Lane = (tile column lm, channels 4g + r): 2x2 pixels, 8-byte stores.
+  float2* ex = reinterpret_cast<float2*>(smem);   // [nh][q][i][nbl][r][lane]
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a0 = acc[0][i][nbl][r], a1 = acc[1][i][nbl][r], a2 = acc[2][i][nbl][r], a3 = acc[3][i][nbl][r];
+        ex[(((((nh * 4 + q) * MB + i) * 2 + nbl) * 4 + r) << 6) + lane] = make_float2(a0 + a1 + a2, a1 - a2 - a3);
+      }
+  __syncthreads();
   const bool styled = (A.epi == CAGC_EPI_STYLED);
   const float nw = (styled && A.noise) ? A.noise_w[0] : 0.f;
-  const int oy = y0 + 2 * wn, ox = x0 + 2 * lm;
+  const int nbl_f = q & 1;
+  const int oy = y0 + 2 * (nh * 2 + nbl_f), ox = x0 + 2 * lm;
   float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  if (wx == 0 && styled && A.noise) {
+  if (styled && A.noise) {
     const float* np = A.noise + (A.noise_bstride_on ? (int64_t)b * HW : 0) + (int64_t)oy * A.W + ox;
     nz[0][0] = nw * np[0]; nz[0][1] = nw * np[1]; nz[1][0] = nw * np[A.W]; nz[1][1] = nw * np[A.W + 1];
   }
-  float4 part[MB][4];
 #pragma unroll
-  for (int i = 0; i < MB; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float p[2][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a0 = acc[j][i][r], a1 = acc[4 + j][i][r];   // local rows 0,1 of this half
-        if (wx == 0) { p[0][j] = a0 + a1; p[1][j] = a1; }        // global rows 0,1
-        else         { p[0][j] = a0;      p[1][j] = -a0 - a1; }  // global rows 2,3
-      }
-      part[i][r] = make_float4(p[0][0] + p[0][1] + p[0][2], p[0][1] - p[0][2] - p[0][3],
-                               p[1][0] + p[1][1] + p[1][2], p[1][1] - p[1][2] - p[1][3]);
-      if (wx == 1) ex[((wn * MB + i) * 4 + r) * 64 + lane] = part[i][r];
-    }
-  }
-  __syncthreads();
-  if (wx == 0) {
-#pragma unroll
-    for (int i = 0; i < MB; ++i) {
+  for (int ii = 0; ii < (MB + 1) / 2; ++ii) {
+    const int i = (q >> 1) + 2 * ii;
+    if (i < MB) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + i * 16 + 4 * g + r;
+        float2 z[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) z[qq] = ex[(((((nh * 4 + qq) * MB + i) * 2 + nbl_f) * 4 + r) << 6) + lane];
         if (m < A.Cout) {
-          const float4 o = ex[((wn * MB + i) * 4 + r) * 64 + lane];
           const float osc = A.out_scale ? A.out_scale[b * A.Cout + m] : 1.f;
           const float bs = styled ? A.bias[m] : 0.f;
-          float y[2][2] = {{(part[i][r].x + o.x) * osc, (part[i][r].y + o.y) * osc},
-                           {(part[i][r].z + o.z) * osc, (part[i][r].w + o.w) * osc}};
+          float y[2][2] = {{(z[0].x + z[1].x + z[2].x) * osc, (z[0].y + z[1].y + z[2].y) * osc},
+                           {(z[1].x - z[2].x - z[3].x) * osc, (z[1].y - z[2].y - z[3].y) * osc}};
           float* op = A.out + ((int64_t)(b * A.Cout + m)) * HW + (int64_t)oy * A.W + ox;
 #pragma unroll
           for (int a = 0; a < 2; ++a) {
@@ -324,7 +330,7 @@ template <int MB>
 static int launch_wino(WinoArgs& a, hipStream_t st, const char* what) {
   constexpr int MT = MB * 16;
   size_t smem = sizeof(float) * ((size_t)2 * 16 * WCK * W_VS + (size_t)2 * WCK * (W_IH * W_IWP + 16));
-  const size_t exch = sizeof(float) * 4 * (size_t)4 * MB * 4 * 64;   // partial-output exchange between the two xi halves
+  const size_t exch = sizeof(float) * 2 * (size_t)8 * MB * 2 * 4 * 64;   // row-direction output transform across the q waves
   if (smem < exch) smem = exch;
   static bool attr[64] = {};
   int dev = 0;
