@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run ON THE GPU BOX (gpurun -- 'bash scripts/profile_step.sh TAG'):  rocprofv3 kernel-trace of the eager KD step + separate
+# --pmc FETCH_SIZE / WRITE_SIZE passes (never combined with other trace domains), summarised into gpurun_out/ as
+# markdown by scripts/rocpd_stats.py / rocpd_pmc.py.  Copy the summaries you keep into profiles/.
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+CMD="python bench.py --no-graph --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-full-iteration"
+mkdir -p gpurun_out
+rm -rf /tmp/prof_kt
+rocprofv3 --kernel-trace -d /tmp/prof_kt -o kt -- $CMD > gpurun_out/${TAG}_kt.log 2>&1
+DB=$(find /tmp/prof_kt -name '*.db' | head -1)
+{ echo "command: rocprofv3 --kernel-trace -- $CMD  (eager launches, per-kernel view of the same step bench.py replays as a HIP graph)"; echo;
+  python scripts/rocpd_stats.py "$DB" --marker k_masked_l1 --last 4 --top 45; } > gpurun_out/${TAG}_kernel_stats.md
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/prof_pmc
+  rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_pmc -o pmc -- $CMD > gpurun_out/${TAG}_pmc_$C.log 2>&1
+  DB=$(find /tmp/prof_pmc -name '*.db' | head -1)
+  { echo "command: rocprofv3 --kernel-trace --pmc $C -- $CMD   (counter unit: KB; see bench.py pmc_traffic for the gfx950 correction)"; echo;
+    python scripts/rocpd_pmc.py "$DB" --marker k_masked_l1 --last 2 --top 30; } > gpurun_out/${TAG}_pmc_$C.md
+done
+tail -3 gpurun_out/${TAG}_kt.log | cut -c1-300
+head -12 gpurun_out/${TAG}_kernel_stats.md
