@@ -154,16 +154,21 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
 
 __global__ __launch_bounds__(256) void k_wgrad_reduce(float* __restrict__ gw, const float* __restrict__ ws, int Cout,
                                                       int Cin, int ntaps, int Mp32, int Np32, int nsplit, float scale) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [Cout][Cin][ntaps]
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [ntaps][Cout][Cin]: slab order, coalesced reads
   if (idx >= (int64_t)Cout * Cin * ntaps) return;
-  const int t = (int)(idx % ntaps);
-  const int64_t q = idx / ntaps;
-  const int i = (int)(q % Cin), o = (int)(q / Cin);
+  const int i = (int)(idx % Cin);
+  const int64_t q = idx / Cin;
+  const int o = (int)(q % Cout), t = (int)(q / Cout);
   const int64_t slab = (int64_t)ntaps * Mp32 * Np32;
   const float* p = ws + ((int64_t)t * Mp32 + o) * Np32 + i;
-  float a = 0.f;
-  for (int s = 0; s < nsplit; ++s) a += p[s * slab];
-  gw[idx] = a * scale;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // fixed summation tree: deterministic
+  int sidx = 0;
+  for (; sidx + 4 <= nsplit; sidx += 4) {
+    a0 += p[(int64_t)sidx * slab]; a1 += p[(int64_t)(sidx + 1) * slab];
+    a2 += p[(int64_t)(sidx + 2) * slab]; a3 += p[(int64_t)(sidx + 3) * slab];
+  }
+  for (; sidx < nsplit; ++sidx) a0 += p[(int64_t)sidx * slab];
+  gw[((int64_t)o * Cin + i) * ntaps + t] = ((a0 + a1) + (a2 + a3)) * scale;
 }
 
 
@@ -190,6 +195,9 @@ struct Wg2Args {
   int b_y0;                    // B tile row 0 relative to the tile origin (-1)
   int ntaps, Mp, Np;           // padded slab dims
   int a_off[9], b_off[9];
+  // (tap, input-channel block) pairs of every wavefront, grouped by A plane so that consecutive slots of a wave
+  // share their A fragments: pair_tap[w][q] (or -1), pair_nb[w][q], pair_newa[w][q] = A fragments must be (re)loaded
+  signed char pair_tap[4][12], pair_nb[4][12], pair_newa[4][12];
 };
 
 template <int MB, int NB>
@@ -206,13 +214,14 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)
 
   // wave-uniform pair descriptors
   int p_aoff[PPW], p_boff[PPW], p_tap[PPW], p_nb[PPW];
-  bool p_ok[PPW];
+  bool p_ok[PPW], p_newa[PPW];
 #pragma unroll
   for (int q = 0; q < PPW; ++q) {
-    const int p = wave + 4 * q;
-    p_ok[q] = p < A.ntaps * NB;
-    const int tap = p_ok[q] ? p / NB : 0;
-    const int nb = p_ok[q] ? p - tap * NB : 0;
+    const int tp = A.pair_tap[wave][q];
+    p_ok[q] = tp >= 0;
+    const int tap = p_ok[q] ? tp : 0;
+    const int nb = p_ok[q] ? A.pair_nb[wave][q] : 0;
+    p_newa[q] = A.pair_newa[wave][q] != 0;
     p_tap[q] = tap; p_nb[q] = nb;
     p_aoff[q] = A.a_off[tap];
     p_boff[q] = A.b_off[tap] + nb * 16 * A.BCS;
@@ -282,12 +291,14 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)
       for (int s4 = 0; s4 < QA; ++s4) {
         const int px = 4 * s4 + g;
         const int ao = row * TW + px, bo = row * A.BWp + px;
+        float av[MB];
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
           if (p_ok[q]) {
-            float av[MB];
+            if (p_newa[q]) {
 #pragma unroll
-            for (int i = 0; i < MB; ++i) av[i] = a_lds[(i * 16 + lm) * A.ACS + p_aoff[q] + ao];
+              for (int i = 0; i < MB; ++i) av[i] = a_lds[(i * 16 + lm) * A.ACS + p_aoff[q] + ao];
+            }
             const float bv = b_lds[lm * A.BCS + p_boff[q] + bo];
 #pragma unroll
             for (int i = 0; i < MB; ++i) acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[q][i], 0, 0, 0);
@@ -331,9 +342,21 @@ static void wgrad2_geometry(Wg2Args& a, Wg2Plan pl, int B, int Cin, int Cout, in
   a.NPA = up ? 4 : 1; a.AHg = a.Hk; a.APitch = up ? ((W + 1 + 3) & ~3) : W;
   int tw = 4;
   while (tw < a.Wk && tw < 32) tw <<= 1;
+  if (up) {   // odd K grid (W + 1 columns): the multiple of 4 in [16, 44] (or the whole padded row) that wastes least
+    const int wk4 = (a.Wk + 3) & ~3;
+    if (wk4 <= 44) tw = wk4;
+    else {
+      long best = -1;
+      for (int c = 16; c <= 44; c += 4) {
+        const long cover = (long)cdiv(a.Wk, c) * c;
+        if (best < 0 || cover < best || (cover == best && c > tw)) { best = cover; tw = c; }
+      }
+    }
+  }
   a.TW = tw;
   a.TH = (up ? 64 : 128) / tw;
   if (a.TH > 16) a.TH = 16;
+  if (a.TH < 1) a.TH = 1;
   a.tiles_x = cdiv(a.Wk, a.TW); a.tiles_y = cdiv(a.Hk, a.TH);
   a.ntiles = B * a.tiles_x * a.tiles_y;
   a.ntaps = ksize * ksize;
@@ -358,11 +381,31 @@ static void wgrad2_geometry(Wg2Args& a, Wg2Plan pl, int B, int Cin, int Cout, in
         a.b_off[t] = ky * a.BWp + 4 + kx - r;                    // xs[y + ky - r, x + kx - r]; LDS row 0 = y0 - r
       }
     }
+  // split-K: two full rounds of the chip (256 CUs x occupancy), never one workgroup more
   const int mn = (a.Mp / (16 * pl.mb)) * (a.Np / (16 * pl.nb));
-  int ns = (1024 + mn - 1) / mn;
+  const int ppw = (9 * pl.nb + 3) / 4;
+  const int slots = 256 * ((ppw * pl.mb * 4 <= 110) ? 2 : 1);
+  int ns = (2 * slots) / mn;
   if (ns > a.ntiles) ns = a.ntiles;
   if (ns < 1) ns = 1;
   a.nsplit = ns;
+  // pairs sorted by A plane (LDS offset of the tap's A operand), dealt to the 4 waves in consecutive runs
+  int order[9], no = 0;
+  for (int t = 0; t < a.ntaps; ++t) order[no++] = t;
+  for (int i = 1; i < no; ++i)
+    for (int j = i; j > 0 && a.a_off[order[j]] < a.a_off[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  memset(a.pair_tap, -1, sizeof(a.pair_tap));
+  const int npairs = a.ntaps * pl.nb;
+  int next = 0;
+  for (int w = 0; w < 4; ++w) {
+    const int cnt = npairs / 4 + (w < npairs % 4 ? 1 : 0);
+    for (int q = 0; q < cnt; ++q, ++next) {
+      const int t = order[next / pl.nb];
+      a.pair_tap[w][q] = (signed char)t;
+      a.pair_nb[w][q] = (signed char)(next % pl.nb);
+      a.pair_newa[w][q] = (signed char)((q == 0 || a.a_off[t] != a.a_off[a.pair_tap[w][q - 1]]) ? 1 : 0);
+    }
+  }
 }
 
 template <int MB, int NB>
