@@ -164,7 +164,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-full-iteration", action="store_true")
+    ap.add_argument("--full-iteration", action="store_true",
+                    help="also time 16 whole training iterations (D step, R1, path-length, EMA); opt-in: its second-order "
+                         "paths go through MIOpen, which JIT-compiles several kernels on a fresh box (minutes)")
+    ap.add_argument("--no-full-iteration", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--sweep", type=int, default=0, help="also time N bs-64 batches of the prune.py saliency sweep (config 5)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches + DDP instead of HIP-graph replay")
     args = ap.parse_args()
@@ -247,7 +250,7 @@ def main():
                                               for k, v in sorted(mfma.items(), key=lambda kv: -kv[1][1])},
                     "cagc_kernel_ms_per_step": {k: round(v[1] / 3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
     full = None
-    if world == 1 and not args.no_full_iteration:
+    if world == 1 and args.full_iteration and not args.no_full_iteration:
         # secondary figure: the WHOLE training iteration of train.py:371-398 — D step + G/KD step + lazy
         # R1 (every 16) + lazy path-length reg (every 4) + EMA — eagerly launched, 16 iterations = one full lazy-reg
         # period.  Comparable in kind to the reference's README.md:108-115 wall-time figure (15.3 img/s on 2xV100,

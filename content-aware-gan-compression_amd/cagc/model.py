@@ -470,6 +470,8 @@ class ConvLayer(nn.Sequential):
         super().__init__(*layers)
         self._fused_down = downsample and kernel_size == 3 and list(blur_kernel) == [1, 3, 3, 1]
         self._fused_s1 = (not downsample) and kernel_size == 3 and activate and bias
+        self._fused_skip = (downsample and kernel_size == 1 and not activate and not bias
+                            and list(blur_kernel) == [1, 3, 3, 1])
         self._packed = None
 
     def _packed_weights(self, conv):
@@ -516,6 +518,12 @@ class ConvLayer(nn.Sequential):
             for layer in list(self)[2:]:
                 out = layer(out)
             return out
+        # Blur -> 1x1 stride-2 conv (ResBlock skip): FIR evaluated at the kept positions only, 1x1 conv as NCHW MFMA GEMM
+        if (self._fused_skip and mc.use_hip(input) and input.dtype == torch.float32 and input.shape[2] % 2 == 0
+                and input.shape[3] % 2 == 0 and self[1].bias is None):
+            blur, conv = self[0], self[1]
+            wp_fwd, wp_bwd = self._packed_weights(conv)
+            return mc._BlurDownConv1x1.apply(input, conv.weight, blur.kernel, wp_fwd, wp_bwd, tuple(blur.pad), conv.scale)
         return super().forward(input)
 
 

@@ -348,6 +348,54 @@ class _BlurConvS2(Function):
         return gx, gweight, None, None, None, None, None
 
 
+class _BlurDownConv1x1(Function):
+    """Discriminator ResBlock skip (reference model.py:724-726: Blur(pad 1,1) -> EqualConv2d(1x1, stride 2, no bias)):
+    the stride-2 conv only ever reads every other blurred pixel, so the FIR is evaluated at those positions alone
+    (upfirdn2d with down = 2 — same samples, a quarter of the work and traffic) and the 1x1 conv runs on the MFMA
+    implicit-GEMM kernel in NCHW (no layout transposes)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, fir, wp_fwd, wp_bwd, pad, scale):
+        from .upfirdn2d import _launch
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        cout = weight.shape[0]
+        ho, wo = (H + pad[0] + pad[1] - 4) // 2 + 1, (W + pad[0] + pad[1] - 4) // 2 + 1
+        y = _launch(x, fir, (1, 1), (2, 2), (pad[0], pad[1], pad[0], pad[1]), (ho, wo))
+        out = torch.empty(B, cout, ho, wo, dtype=x.dtype, device=x.device)
+        with _lib.on_device(x):
+            _lib.call("cagc_modconv_fwd", _lib.ptr(out), _lib.ptr(y), _lib.ptr(wp_fwd), None, B, C, cout, ho, wo, 1, EPI_LINEAR,
+                      None, None, 0, None, None, 0.2, 1.0)
+        ctx.cfg = (pad, scale, ho, wo)
+        ctx.save_for_backward(y if weight.requires_grad else x.new_empty(0), weight, fir, wp_bwd)
+        ctx.x_shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        from .upfirdn2d import _launch
+        y, weight, fir, wp_bwd = ctx.saved_tensors
+        pad, scale, ho, wo = ctx.cfg
+        B, C, H, W = ctx.x_shape
+        cout = weight.shape[0]
+        gout = gout.contiguous()
+        gx = gweight = None
+        if ctx.needs_input_grad[0]:
+            if wp_bwd is None:
+                raise RuntimeError("blur_down_conv1x1: backward requested but the weights were packed forward-only")
+            gy = torch.empty(B, C, ho, wo, dtype=gout.dtype, device=gout.device)
+            with _lib.on_device(gout):
+                _lib.call("cagc_modconv_dgrad", _lib.ptr(gy), None, _lib.ptr(gout), _lib.ptr(wp_bwd), None, None, B, C, cout,
+                          ho, wo, 1)
+            # adjoint of (up 1, down 2, pad p): up 2, down 1 with the flipped kernel (reference op/upfirdn2d.py:111-116)
+            gp = (4 - pad[0] - 1, W - 2 * wo + pad[0], 4 - pad[0] - 1, H - 2 * ho + pad[0])   # (x0, x1, y0, y1)
+            gx = _launch(gy, torch.flip(fir, [0, 1]).contiguous(), (2, 2), (1, 1), (gp[0], gp[1], gp[2], gp[3]), (H, W))
+        if ctx.needs_input_grad[1]:
+            gweight = (torch.einsum("bop,bip->oi", gout.reshape(B, cout, -1), y.reshape(B, C, -1)) * scale).reshape(weight.shape)
+        return gx, gweight, None, None, None, None, None
+
+
 # ---------------------------------------------------------------------------------------------------
 # ToRGB
 # ---------------------------------------------------------------------------------------------------

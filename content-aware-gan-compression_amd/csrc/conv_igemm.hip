@@ -271,14 +271,19 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
       _Pragma("unroll 1") for (int tt = 0; tt < np; ++tt) {                                                      \
         const int t = tbase + tt;                                                                                \
         const int to = I.taps[t].lds_off;                                                                        \
-        _Pragma("unroll") for (int s = 0; s < CK / 4; ++s) {                                                     \
-          const int kk = 4 * s + g;                                                                              \
-          float av[MB], bv[NBW];                                                                                 \
-          _Pragma("unroll") for (int i = 0; i < MB; ++i) av[i] = a_lds[(t * CK + kk) * LDA + i * 16 + lm];       \
-          _Pragma("unroll") for (int j = 0; j < NBW; ++j) bv[j] = b_lds[kk * PS + lb[j] + to];                   \
-          _Pragma("unroll") for (int i = 0; i < MB; ++i)                                                         \
-            _Pragma("unroll") for (int j = 0; j < NBW; ++j)                                                      \
-              acc[P][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[P][i][j], 0, 0, 0);          \
+        float bv[CK / 4][NBW];                                                                                   \
+        _Pragma("unroll") for (int s = 0; s < CK / 4; ++s)                                                       \
+          _Pragma("unroll") for (int j = 0; j < NBW; ++j) bv[s][j] = b_lds[(4 * s + g) * PS + lb[j] + to];       \
+        const float* ap = a_lds + (t * CK + g) * LDA + lm;                                                       \
+        float a_cur = ap[0];                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < (CK / 4) * MB; ++u) {   /* A fragment one group of MFMAs ahead */  \
+          const int s = u / MB, i = u - s * MB;                                                                  \
+          float a_nxt = 0.f;                                                                                     \
+          if (u + 1 < (CK / 4) * MB) a_nxt = ap[4 * ((u + 1) / MB) * LDA + ((u + 1) % MB) * 16];                 \
+          _Pragma("unroll") for (int j = 0; j < NBW; ++j)                                                        \
+            acc[P][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, bv[s][j], acc[P][i][j], 0, 0, 0);         \
+          a_cur = a_nxt;                                                                                         \
+          __builtin_amdgcn_sched_barrier(0);                                                                     \
         }                                                                                                        \
       }                                                                                                          \
       tbase += np;                                                                                               \

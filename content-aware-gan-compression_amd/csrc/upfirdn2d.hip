@@ -9,6 +9,7 @@
 //                         epilogue (demod scale, noise, bias, LeakyReLU) fused into the forward
 // All HBM-bound: each input element is fetched from HBM once per tile (+halo), outputs written once.
 #include "common.h"
+#include <stdlib.h>
 
 namespace cagc {
 
@@ -44,6 +45,64 @@ __global__ __launch_bounds__(256) void k_upfirdn2d_generic(float* __restrict__ o
 }
 
 constexpr int FT = 32;  // output tile edge
+
+// 4x4 FIR with decimation (UP = 1, DOWN = 2: the discriminator's skip path, evaluated only at the positions its
+// stride-2 1x1 conv keeps) or zero-insertion (UP = 2, DOWN = 1: its adjoint, and the ToRGB skip upsample): 32x32 output
+// tile per workgroup, the input footprint of the tile staged once in LDS (zero outside the image), 4 outputs/thread.
+template <int UP, int DOWN>
+__global__ __launch_bounds__(256) void k_fir4_updown(float* __restrict__ out, const float* __restrict__ x,
+                                                     const float* __restrict__ kern, int in_h, int in_w, int out_h,
+                                                     int out_w, int pad_x0, int pad_y0, int tiles_x, int tiles_y) {
+  constexpr int K = 4;
+  constexpr int SPAN = (FT - 1) * DOWN + K;          // extent of the tile's taps in the zero-inserted grid
+  constexpr int IT = (SPAN + UP - 1) / UP + 1;       // input rows / cols that can be touched
+  constexpr int LW = IT + 1;
+  __shared__ float tile[IT * LW];
+  __shared__ float kf[K * K];
+  int bid = blockIdx.x;
+  const int ox0 = (bid % tiles_x) * FT;
+  bid /= tiles_x;
+  const int oy0 = (bid % tiles_y) * FT;
+  const int64_t p = bid / tiles_y;
+  const int tid = threadIdx.x;
+  if (tid < K * K) kf[tid] = kern[(K - 1 - tid / K) * K + (K - 1 - tid % K)];   // flipped: true convolution
+  // first zero-inserted-grid coordinate of the tile and the input pixel at / after it
+  const int uy_lo = oy0 * DOWN - pad_y0, ux_lo = ox0 * DOWN - pad_x0;
+  const int iy_lo = (uy_lo >= 0) ? (uy_lo + UP - 1) / UP : -((-uy_lo) / UP);
+  const int ix_lo = (ux_lo >= 0) ? (ux_lo + UP - 1) / UP : -((-ux_lo) / UP);
+  const float* xp = x + p * (int64_t)in_h * in_w;
+  for (int e = tid; e < IT * IT; e += 256) {
+    const int r = e / IT, c = e - r * IT;
+    const int iy = iy_lo + r, ix = ix_lo + c;
+    tile[r * LW + c] = (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) ? xp[(int64_t)iy * in_w + ix] : 0.f;
+  }
+  __syncthreads();
+  const int tx = tid & 31, ty = tid >> 5;
+  const int ox = ox0 + tx;
+  const int ux0 = ox * DOWN - pad_x0;
+#pragma unroll
+  for (int rr = 0; rr < FT / 8; ++rr) {
+    const int oy = oy0 + ty + 8 * rr;
+    const int uy0 = oy * DOWN - pad_y0;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int uy = uy0 + i;
+      const bool vy = (UP == 1) || ((uy & (UP - 1)) == 0);
+      const int ly = ((UP == 1) ? uy : (uy >> 1)) - iy_lo;      // arithmetic shift: floor for negatives; masked when odd
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int ux = ux0 + j;
+        const bool vx = (UP == 1) || ((ux & (UP - 1)) == 0);
+        const int lx = ((UP == 1) ? ux : (ux >> 1)) - ix_lo;
+        const bool ok = vy && vx && ly >= 0 && ly < IT && lx >= 0 && lx < IT;
+        const float v = ok ? tile[ly * LW + lx] : 0.f;
+        acc += v * kf[i * K + j];
+      }
+    }
+    if (oy < out_h && ox < out_w) out[(p * out_h + oy) * (int64_t)out_w + ox] = acc;
+  }
+}
 
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void k_fir_s1(float* __restrict__ out, const float* __restrict__ x,
@@ -230,6 +289,16 @@ extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, i
     CAGC_REQUIRE(nb < (1ll << 31), "cagc_upfirdn2d: too large");
     hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w, out_h, out_w,
                        out_w, pad_x0, pad_y0, tx, ty);
+  } else if (kh == 4 && kw == 4 && up_x == up_y && down_x == down_y && ((up_x == 1 && down_x == 2) || (up_x == 2 && down_x == 1))) {
+    const int tx = cdiv(out_w, FT), ty = cdiv(out_h, FT);
+    const int64_t nb = planes * tx * ty;
+    CAGC_REQUIRE(nb < (1ll << 31), "cagc_upfirdn2d: too large");
+    if (up_x == 1)
+      hipLaunchKernelGGL((k_fir4_updown<1, 2>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w,
+                         pad_x0, pad_y0, tx, ty);
+    else
+      hipLaunchKernelGGL((k_fir4_updown<2, 1>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w,
+                         pad_x0, pad_y0, tx, ty);
   } else {
     const int64_t total = planes * out_h * out_w;
     const int64_t nb = (total + 255) / 256;

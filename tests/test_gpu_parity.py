@@ -80,7 +80,9 @@ def test_upfirdn2d_golden_all_configs_with_grad_and_gradgrad():
 
 @pytest.mark.parametrize("cfg", [((16, 128, 257, 257), 4.0, 1, 1, (1, 1)), ((4, 128, 128, 128), 1.0, 1, 1, (2, 2)),
                                  ((16, 3, 128, 128), 4.0, 2, 1, (2, 1)), ((16, 3, 256, 256), 1.0, 1, 2, (1, 1)),
-                                 ((2, 5, 67, 41), 1.0, 1, 1, (1, 1))])
+                                 ((2, 5, 67, 41), 1.0, 1, 1, (1, 1)), ((4, 128, 128, 128), 1.0, 1, 2, (1, 1)),
+                                 ((4, 256, 64, 64), 4.0, 2, 1, (2, 1)), ((3, 5, 33, 47), 1.0, 1, 2, (1, 1)),
+                                 ((3, 5, 33, 47), 4.0, 2, 1, (2, 1)), ((2, 7, 34, 46), 1.0, 1, 2, (2, 1))])
 def test_upfirdn2d_full_size_vs_oracle(cfg):
     shape, gain, up, down, pad = cfg
     torch.manual_seed(2)
@@ -436,3 +438,29 @@ def test_discriminator_conv3x3_act_winograd_vs_oracle(cfg):
     gg = torch.autograd.grad(yg, [xg, lg[0].weight, lg[1].bias], cu(go))
     for nm, a, b in zip(("x", "weight", "bias"), gg, gr):
         assert_close(a, b, TOL, f"{cfg} grad {nm}")
+
+
+@pytest.mark.parametrize("cfg", [(2, 128, 256, 64, 64), (3, 20, 36, 18, 22), (1, 512, 512, 8, 8), (4, 128, 256, 128, 128)])
+def test_discriminator_skip_blur_down_conv1x1_vs_oracle(cfg):
+    """ResBlock skip: Blur(pad 1,1) -> 1x1 stride-2 EqualConv2d (no bias / activation) on the fused path (decimating FIR +
+    1x1 MFMA GEMM) vs the oracle: forward, input gradient, weight gradient."""
+    B, cin, cout, H, W = cfg
+    torch.manual_seed(9)
+    layer = M.ConvLayer(cin, cout, 1, downsample=True, activate=False, bias=False)
+    assert layer._fused_skip
+    sd = {"l." + k: v.detach().clone() for k, v in layer.state_dict().items()}
+    x = torch.randn(B, cin, H, W)
+    lg = layer.to(DEV)
+    xg = cu(x).requires_grad_(True)
+    yg = lg(xg)
+    assert yg.grad_fn is not None and "BlurDownConv1x1" in type(yg.grad_fn).__name__
+    go = torch.randn(yg.shape)
+    xr = x.clone().requires_grad_(True)
+    wr = sd["l.1.weight"].clone().requires_grad_(True)
+    sd["l.1.weight"] = wr
+    yr = ref_model._conv_layer(sd, "l", xr, 1, downsample=True, activate=False, bias=False)
+    gxr, gwr = torch.autograd.grad(yr, [xr, wr], go)
+    assert_close(yg, yr, TOL, "out")
+    gxg, gwg = torch.autograd.grad(yg, [xg, lg[1].weight], cu(go))
+    assert_close(gxg, gxr, TOL, "grad x")
+    assert_close(gwg, gwr, TOL, "grad weight")
