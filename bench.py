@@ -183,6 +183,8 @@ def main():
     torch.backends.cudnn.benchmark = os.environ.get("CAGC_MIOPEN_BENCHMARK", "0") == "1"
     assert GLOBAL_BATCH % world == 0
     bs = GLOBAL_BATCH // world
+    if os.environ.get("CAGC_BENCH_LOCAL_BS"):   # experiment knob: per-GPU batch of an N-GPU run, on one GPU (value then = bs*K/t)
+        bs = int(os.environ["CAGC_BENCH_LOCAL_BS"])
 
     student, teacher, disc = kd.build_synthetic_workload(SIZE, dev, seed=0)
     n_params = sum(p.numel() for p in student.parameters())

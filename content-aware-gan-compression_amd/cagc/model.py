@@ -116,7 +116,36 @@ class EqualLinear(nn.Module):
         self.scale = (1 / math.sqrt(in_dim)) * lr_mul
         self.lr_mul = lr_mul
 
+    def _frozen_scaled(self):
+        """(weight * scale, bias * lr_mul) of a frozen layer (teacher, D on the generator step), cached against the
+        tensors' version counters — two elementwise launches per layer and step that never change."""
+        w, b = self.weight, self.bias
+        key = (w._version, w.data_ptr(), w.device, None if b is None else (b._version, b.data_ptr()))
+        c = getattr(self, "_scaled", None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                c = (key, (w * self.scale), None if b is None else (b * self.lr_mul))
+            self._scaled = c
+        return c[1], c[2]
+
+    def _apply(self, fn, *a, **k):
+        self._scaled = None
+        return super()._apply(fn, *a, **k)
+
     def forward(self, input):
+        w, b = self.weight, self.bias
+        trainable = torch.is_grad_enabled() and (w.requires_grad or (b is not None and b.requires_grad))
+        if not trainable and not torch.jit.is_tracing():
+            ws, bs = self._frozen_scaled()
+            if self.activation:
+                return fused_leaky_relu(F.linear(input, ws), bs)
+            return F.linear(input, ws, bias=bs)
+        if input.dim() == 2 and b is not None:
+            # scale folded into the GEMM (alpha) instead of a weight-sized elementwise pass; lr_mul == 1 needs no pass
+            be = b if self.lr_mul == 1 else b * self.lr_mul
+            if self.activation:
+                return fused_leaky_relu(torch.addmm(be, input, w.t(), beta=0, alpha=self.scale), be)
+            return torch.addmm(be, input, w.t(), alpha=self.scale)
         if self.activation:
             out = F.linear(input, self.weight * self.scale)
             return fused_leaky_relu(out, self.bias * self.lr_mul)

@@ -44,6 +44,21 @@ class composed_autograd:
         _composed_depth -= 1
 
 
+_flip_cache = {}
+
+
+def _flipped(fir):
+    """fir flipped along both axes (the adjoint FIR), cached per tensor OBJECT: saves a flip + copy launch per backward
+    call.  The entry keeps a reference to `fir`, so neither its id nor its storage can be recycled while it is cached."""
+    e = _flip_cache.get(id(fir))
+    if e is None or e[0] is not fir or e[1] != fir._version:
+        if len(_flip_cache) > 64:
+            _flip_cache.clear()
+        e = (fir, fir._version, torch.flip(fir.detach(), [0, 1]).contiguous())
+        _flip_cache[id(fir)] = e
+    return e[2]
+
+
 def use_hip(t):
     return t.is_cuda and _composed_depth == 0
 
@@ -339,7 +354,7 @@ class _BlurConvS2(Function):
                 _lib.call("cagc_conv3x3s2_dgrad", _lib.ptr(gtmp), _lib.ptr(gout), _lib.ptr(wp_bwd), B, C, cout, hb, wb, pitch)
                 gx = torch.empty(B, C, H, W, dtype=gout.dtype, device=gout.device)
                 gp = 4 - pad[0] - 1   # adjoint padding (reference op/upfirdn2d.py:111-116)
-                _lib.call("cagc_fir4x4_pitched", _lib.ptr(gx), _lib.ptr(gtmp), _lib.ptr(torch.flip(fir, [0, 1]).contiguous()),
+                _lib.call("cagc_fir4x4_pitched", _lib.ptr(gx), _lib.ptr(gtmp), _lib.ptr(_flipped(fir)),
                           B * C, hb, wb, pitch, H, W, W, gp, gp)
             if ctx.needs_input_grad[1]:
                 # weight gradient (discriminator training step — not on the KD generator step): stock kernel
@@ -390,7 +405,7 @@ class _BlurDownConv1x1(Function):
                           ho, wo, 1)
             # adjoint of (up 1, down 2, pad p): up 2, down 1 with the flipped kernel (reference op/upfirdn2d.py:111-116)
             gp = (4 - pad[0] - 1, W - 2 * wo + pad[0], 4 - pad[0] - 1, H - 2 * ho + pad[0])   # (x0, x1, y0, y1)
-            gx = _launch(gy, torch.flip(fir, [0, 1]).contiguous(), (2, 2), (1, 1), (gp[0], gp[1], gp[2], gp[3]), (H, W))
+            gx = _launch(gy, _flipped(fir), (2, 2), (1, 1), (gp[0], gp[1], gp[2], gp[3]), (H, W))
         if ctx.needs_input_grad[1]:
             gweight = (torch.einsum("bop,bip->oi", gout.reshape(B, cout, -1), y.reshape(B, C, -1)) * scale).reshape(weight.shape)
         return gx, gweight, None, None, None, None, None
@@ -435,7 +450,7 @@ class _ToRGB(Function):
         gskip = None
         if ctx.has_skip:
             # adjoint of upfirdn2d(up=2, pad=(2,1)): flipped FIR, down=2, pad=(1,1)  (reference op/upfirdn2d.py:111-116)
-            gskip = _upfirdn_launch(g, torch.flip(fir, [0, 1]).contiguous(), (1, 1), (2, 2), (1, 1, 1, 1), (H // 2, W // 2))
+            gskip = _upfirdn_launch(g, _flipped(fir), (1, 1), (2, 2), (1, 1, 1, 1), (H // 2, W // 2))
         return gx, gweight, gs, gbias, gskip, None
 
 
