@@ -264,16 +264,33 @@ __global__ __launch_bounds__(256) void k_demod_fwd(float* __restrict__ d, const 
 __global__ __launch_bounds__(256) void k_demod_bwd_s(float* __restrict__ gs, const float* __restrict__ gd,
                                                      const float* __restrict__ d, const float* __restrict__ s,
                                                      const float* __restrict__ wsq, int B, int Cin, int Cout) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  // workgroup = (b, 64 input channels); its 4 waves split the output channels 4-way (4 independent partial sums
+  // each, so 16 loads are in flight per lane), partial sums meet in LDS
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   const int b = blockIdx.y;
-  if (i >= Cin) return;
-  float acc = 0.f;
-  for (int o = 0; o < Cout; ++o) {
-    const float dv = d[b * Cout + o];
-    const float t = -0.5f * gd[b * Cout + o] * dv * dv * dv;
-    acc += t * wsq[(int64_t)o * Cin + i];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (i < Cin) {
+    const float* dp = d + (int64_t)b * Cout;
+    const float* gp = gd + (int64_t)b * Cout;
+    int o = w;
+    for (; o + 12 < Cout; o += 16) {
+      const float d0 = dp[o], d1 = dp[o + 4], d2 = dp[o + 8], d3 = dp[o + 12];
+      a0 += -0.5f * gp[o] * d0 * d0 * d0 * wsq[(int64_t)o * Cin + i];
+      a1 += -0.5f * gp[o + 4] * d1 * d1 * d1 * wsq[(int64_t)(o + 4) * Cin + i];
+      a2 += -0.5f * gp[o + 8] * d2 * d2 * d2 * wsq[(int64_t)(o + 8) * Cin + i];
+      a3 += -0.5f * gp[o + 12] * d3 * d3 * d3 * wsq[(int64_t)(o + 12) * Cin + i];
+    }
+    for (; o < Cout; o += 4) {
+      const float dv = dp[o];
+      a0 += -0.5f * gp[o] * dv * dv * dv * wsq[(int64_t)o * Cin + i];
+    }
   }
-  gs[(int64_t)b * Cin + i] += 2.f * s[(int64_t)b * Cin + i] * acc;
+  part[w][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (w == 0 && i < Cin)
+    gs[(int64_t)b * Cin + i] += 2.f * s[(int64_t)b * Cin + i] * ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
 }
 __global__ __launch_bounds__(256) void k_demod_bwd_w(float* __restrict__ gwsq, const float* __restrict__ gd,
                                                      const float* __restrict__ d, const float* __restrict__ s, int B,
@@ -388,7 +405,7 @@ extern "C" int cagc_demod_bwd(float* gs, float* gwsq, const float* gd, const flo
                               const float* wsq, int B, int Cin, int Cout, cagc_stream_t stream) {
   CAGC_REQUIRE(gd && d && s && wsq && B > 0 && Cin > 0 && Cout > 0, "cagc_demod_bwd: bad argument");
   hipStream_t st = as_stream(stream);
-  if (gs) hipLaunchKernelGGL(k_demod_bwd_s, dim3(cdiv(Cin, 256), B), dim3(256), 0, st, gs, gd, d, s, wsq, B, Cin, Cout);
+  if (gs) hipLaunchKernelGGL(k_demod_bwd_s, dim3(cdiv(Cin, 64), B), dim3(256), 0, st, gs, gd, d, s, wsq, B, Cin, Cout);
   if (gwsq) hipLaunchKernelGGL(k_demod_bwd_w, dim3(cdiv(Cin, 256), Cout), dim3(256), 0, st, gwsq, gd, d, s, B, Cin, Cout);
   return check_launch("cagc_demod_bwd");
 }

@@ -9,6 +9,7 @@
 //                         epilogue (demod scale, noise, bias, LeakyReLU) fused into the forward
 // All HBM-bound: each input element is fetched from HBM once per tile (+halo), outputs written once.
 #include "common.h"
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace cagc {
@@ -155,6 +156,60 @@ __global__ __launch_bounds__(256) void k_fir_s1(float* __restrict__ out, const f
   }
 }
 
+// 4x4 FIR, up = down = 1, 16-byte path: rows of both tensors start 16-byte aligned (pitches % 4 == 0) and pad <= 4.
+// 32 x 32 output tile; the input footprint is staged with float4 loads from the aligned superset of columns
+// [tx0 - 4, tx0 + 36); every thread produces 4 horizontally adjacent outputs (4 x 7 register window) and stores them
+// as one float4 — 3.5x fewer memory instructions than the scalar kernel on the discriminator's large blurs.
+__global__ __launch_bounds__(256) void k_fir4_vec(float* __restrict__ out, const float* __restrict__ x,
+                                                  const float* __restrict__ kern, int in_h, int in_w, int in_pitch,
+                                                  int out_h, int out_w, int out_pitch, int pad_x0, int pad_y0,
+                                                  int tiles_x, int tiles_y) {
+  constexpr int IH = FT + 3, Q = (FT + 8) / 4, LW = FT + 8 + 1;   // 35 rows x 10 float4; odd row stride
+  __shared__ float tile[IH * LW];
+  __shared__ float kf[16];
+  int bid = blockIdx.x;
+  const int tx0 = (bid % tiles_x) * FT;
+  bid /= tiles_x;
+  const int ty0 = (bid % tiles_y) * FT;
+  const int64_t p = bid / tiles_y;
+  const float* xp = x + p * (int64_t)in_h * in_pitch;
+  if (threadIdx.x < 16) kf[threadIdx.x] = kern[(3 - threadIdx.x / 4) * 4 + (3 - threadIdx.x % 4)];
+  for (int e = threadIdx.x; e < IH * Q; e += 256) {
+    const int r = e / Q, q = e - r * Q;
+    const int iy = ty0 + r - pad_y0, ix = tx0 - 4 + 4 * q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) {
+      v = *reinterpret_cast<const float4*>(xp + (int64_t)iy * in_pitch + ix);   // ix + 3 < in_pitch: pitch % 4 == 0
+      if (ix + 3 >= in_w) {   // pitch padding of the source is not trusted
+        if (ix + 1 >= in_w) v.y = 0.f;
+        if (ix + 2 >= in_w) v.z = 0.f;
+        v.w = 0.f;
+      }
+    }
+    float* t = tile + r * LW + 4 * q;
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+  }
+  __syncthreads();
+  const int cg = threadIdx.x & 7, row = threadIdx.x >> 3;
+  const int oy = ty0 + row, ox = tx0 + 4 * cg;
+  if (oy >= out_h || ox >= out_pitch) return;
+  const float* w0 = tile + row * LW + (4 - pad_x0) + 4 * cg;   // LDS col 0 <-> global col tx0 - 4
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float w[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) w[j] = w0[i * LW + j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float k = kf[i * 4 + j];
+      a0 += w[j] * k; a1 += w[j + 1] * k; a2 += w[j + 2] * k; a3 += w[j + 3] * k;
+    }
+  }
+  float4 o = make_float4(ox < out_w ? a0 : 0.f, ox + 1 < out_w ? a1 : 0.f, ox + 2 < out_w ? a2 : 0.f, ox + 3 < out_w ? a3 : 0.f);
+  *reinterpret_cast<float4*>(out + (p * out_h + oy) * (int64_t)out_pitch + ox) = o;   // pitch padding written as zero
+}
+
 // ---------------------------------------------------------------------------------------------------
 // blur after the transposed conv, phase-planar input.  T_full[Y,X] = t[plane 2*(Y&1)+(X&1)][Y>>1][X>>1].
 // out[Y,X] = sum_{a,b} kf[a][b] * T_full[Y-1+a, X-1+b],  Y in [0,2H), kf = flipped fir.
@@ -287,8 +342,12 @@ extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, i
     const int tx = cdiv(out_w, FT), ty = cdiv(out_h, FT);
     const int64_t nb = planes * tx * ty;
     CAGC_REQUIRE(nb < (1ll << 31), "cagc_upfirdn2d: too large");
-    hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w, out_h, out_w,
-                       out_w, pad_x0, pad_y0, tx, ty);
+    if (in_w % 4 == 0 && out_w % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0)
+      hipLaunchKernelGGL(k_fir4_vec, dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w, out_h, out_w, out_w,
+                         pad_x0, pad_y0, tx, ty);
+    else
+      hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w, out_h, out_w,
+                         out_w, pad_x0, pad_y0, tx, ty);
   } else if (kh == 4 && kw == 4 && up_x == up_y && down_x == down_y && ((up_x == 1 && down_x == 2) || (up_x == 2 && down_x == 1))) {
     const int tx = cdiv(out_w, FT), ty = cdiv(out_h, FT);
     const int64_t nb = planes * tx * ty;
@@ -347,7 +406,11 @@ extern "C" int cagc_fir4x4_pitched(float* out, const float* x, const float* kern
   const int tx = cdiv(out_pitch, FT), ty = cdiv(out_h, FT);
   const int64_t nb = planes * tx * ty;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_fir4x4_pitched: too large");
-  hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, x, kernel, in_h, in_w,
-                     in_pitch, out_h, out_w, out_pitch, pad_x0, pad_y0, tx, ty);
+  if (in_pitch % 4 == 0 && out_pitch % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0)
+    hipLaunchKernelGGL(k_fir4_vec, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, x, kernel, in_h, in_w, in_pitch,
+                       out_h, out_w, out_pitch, pad_x0, pad_y0, tx, ty);
+  else
+    hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, x, kernel, in_h, in_w,
+                       in_pitch, out_h, out_w, out_pitch, pad_x0, pad_y0, tx, ty);
   return check_launch("cagc_fir4x4_pitched");
 }
