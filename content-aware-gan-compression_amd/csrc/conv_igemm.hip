@@ -84,6 +84,11 @@ struct ConvArgs {
   ConvItem items[MAX_ITEMS];
 };
 
+// float index of element (tap t, k, m) in the packed weights [t][Kp/4][Mp/16][k % 4][m % 16] (k_pack_weights)
+__device__ __forceinline__ int64_t wp_index(int t, int k, int m, int Kp, int Mp) {
+  return ((((int64_t)t * (Kp >> 2) + (k >> 2)) * (Mp >> 4) + (m >> 4)) << 6) + ((k & 3) << 4) + (m & 15);
+}
+
 // NV = max float4 (vec) / float (scalar) input elements staged per thread per chunk
 template <int MB, int NV, bool VEC, bool GS, int NPH>
 __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS && MB == 8) && NPH == 1) ? 2 : 1)) void k_conv_igemm(const ConvArgs A) {
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
     for (int t = 0; t < MAX_TAPS; ++t) {
       rw[t] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (t < ntaps && w_thread && kc + wc < A.Kp)
-        rw[t] = *reinterpret_cast<const float4*>(A.wp + ((int64_t)widx[t] * A.Kp + kc + wc) * A.Mp + m0 + wcol);
+        rw[t] = *reinterpret_cast<const float4*>(A.wp + wp_index(widx[t], kc + wc, m0 + wcol, A.Kp, A.Mp));
     }
   };
   auto commit = [&]() {
@@ -434,17 +439,21 @@ __global__ __launch_bounds__(256) void k_styled_epilogue(float* __restrict__ out
 }
 
 // -------------------------------------------------------------------------------------------------
-// weight packing:  wp_fwd[t][Kp(Cin)][Mp(Cout)], wp_bwd[t][Kp(Cout)][Mp(Cin)], wsq[Cout][Cin]
+// weight packing:  wp_fwd[t][Kp(Cin)/4][Mp(Cout)/16][4][16], wp_bwd likewise with the channel roles swapped, wsq[Cout][Cin]
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_weights(float* __restrict__ wp, const float* __restrict__ w, int Cout,
                                                       int Cin, int kk, int Kp, int Mp, float scale, int transpose) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // dest index = (t*Kp + k)*Mp + m
+  // dest = MFMA A-operand order [t][Kp/4][Mp/16][k % 4][m % 16]: the 64 floats of one (tap, K-step, channel block) are the
+  // 64 lanes' operands of one v_mfma_f32_16x16x4_f32 (lane = (k % 4) * 16 + m % 16), contiguous in memory
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)kk * Kp * Mp;
   if (idx >= total) return;
-  const int m = (int)(idx % Mp);
-  const int64_t q = idx / Mp;
-  const int k = (int)(q % Kp);
-  const int t = (int)(q / Kp);
+  const int ln = (int)(idx & 63);
+  int64_t q = idx >> 6;
+  const int mblk = (int)(q % (Mp / 16)); q /= (Mp / 16);
+  const int kq = (int)(q % (Kp / 4));
+  const int t = (int)(q / (Kp / 4));
+  const int k = 4 * kq + (ln >> 4), m = 16 * mblk + (ln & 15);
   const int o = transpose ? k : m, i = transpose ? m : k;
   float v = 0.f;
   if (o < Cout && i < Cin) v = w[((int64_t)o * Cin + i) * kk + t] * scale;

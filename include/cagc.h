@@ -111,11 +111,12 @@ int cagc_demod_bwd(float* gs, float* gwsq, const float* gd, const float* d, cons
  * d / noise / bias / LeakyReLU applied in the MFMA epilogue.
  *
  * cagc_modconv_prep: repack W [Cout,Cin,k,k] (k = 1 or 3) into the two GEMM-A layouts
- *   wp_fwd [k*k][Kp(Cin)][Mp(Cout)]  and  wp_bwd [k*k][Kp(Cout)][Mp(Cin)]   (Kp = round_up(.,4),
- *   Mp = round_up(.,16), zero padded, multiplied by `scale`) and wsq [Cout,Cin] (see demod).
+ *   wp_fwd [k*k][Kp(Cin)/4][Mp(Cout)/16][4][16]  and  wp_bwd [k*k][Kp(Cout)/4][Mp(Cin)/16][4][16]  (Kp = round_up(.,4),
+ *   Mp = round_up(.,16), zero padded, multiplied by `scale`; the innermost 64 floats are the 64 lanes' A operands of
+ *   one v_mfma_f32_16x16x4_f32: lane = (k % 4) * 16 + m % 16 — opaque to callers) and wsq [Cout,Cin] (see demod).
  *   Any of the three outputs may be null.  Sizes: cagc_modconv_packed_elems().
  * ---------------------------------------------------------------------------------------------- */
-int64_t cagc_modconv_packed_elems(int K, int M, int ksize); /* elements of a packed [k*k][Kp][Mp] tensor */
+int64_t cagc_modconv_packed_elems(int K, int M, int ksize); /* elements of a packed [k*k][Kp/4][Mp/16][64] tensor */
 int cagc_modconv_prep(float* wp_fwd, float* wp_bwd, float* wsq, const float* weight, int Cout, int Cin,
                       int ksize, float scale, cagc_stream_t stream);
 
@@ -182,7 +183,8 @@ int cagc_modconv_wgrad(float* gweight, float* workspace, const float* g, const f
  * Winograd F(2x2,3x3) path          same contract as cagc_modconv_fwd (k = 3, stride 1, "same"), for layers with
  *                                   H % 8 == 0 and W % 32 == 0 (cagc_wino_eligible): 16 GEMMs on transformed 4x4
  *                                   tiles, 2.25x fewer fp32 MFMA flops than the direct implicit GEMM; all fp32.
- * cagc_wino_prep: weight [Cout,Cin,3,3] -> up [16][Kp][Mp] = scale * G g G^T.  dgrad = 0: K = Cin, M = Cout
+ * cagc_wino_prep: weight [Cout,Cin,3,3] -> up = scale * G g G^T in MFMA A-operand order [Mtiles][16][Kp/4][64][4]
+ *   (Kp = round_up(K,8); opaque to callers, size from cagc_wino_packed_elems).  dgrad = 0: K = Cin, M = Cout
  *   (forward);  dgrad = 1: flipped taps, K = Cout, M = Cin — cagc_wino_conv3x3 on that packing with
  *   (Cin, Cout) swapped IS the data gradient of the conv.
  * ---------------------------------------------------------------------------------------------- */
