@@ -597,8 +597,10 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
     int tiles_all = 0;
     for (int p = 0; p < nitems; ++p) tiles_all += cdiv(a.B, a.items[p].IPB) * a.items[p].tiles_x * a.items[p].tiles_y;
     int ks = 1;
+    // target ~256 workgroups: every extra split adds a pass of fp32 atomics over the tile, which costs more than the
+    // shorter (latency-bound, ~2 us per chunk) K loop saves beyond that (sweep: 512 -> 256 saves 0.75 ms per step)
     if (allow_split && tiles_all * mt < 256 && nchunks >= 4) {
-      ks = cdiv(512, tiles_all * mt);
+      ks = cdiv(256, tiles_all * mt);
       if (ks > nchunks / 2) ks = nchunks / 2;
       if (ks < 1) ks = 1;
     }
