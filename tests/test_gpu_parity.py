@@ -299,6 +299,84 @@ def test_pruned_256_generator_vs_oracle_image_and_every_grad():
         assert_close(a, b, TOL if b.numel() > 1 else 5e-3, "grad " + k)
 
 
+def test_pruned_1024_generator_vs_oracle_image_and_grads():
+    """BASELINE configs[3] shape: 1024 px 70 %-pruned student [154x10,77,77,39,39,20,20,10,10], bs 1: image and every
+    parameter gradient.  At this size (10^7 LeakyReLU gates on a random-init net) fp32 itself is only reproducible to
+    ~1e-3 on the gradients: the fp32 CPU oracle differs from its own float64 evaluation by up to 2e-3.  So the truth
+    here is the oracle in float64; the image must meet the 1e-3 bar, the gradients 5e-3 (the fp32 CPU reference's own
+    spread against float64 reaches 2.4e-3 on this net; HIP path observed: 3e-4 on most conv layers, up to 1.5e-3 on the
+    mapping-network gradients that sum every layer's contribution).  That this is gate-flip chaos and not kernel error
+    is pinned separately: test_styled_conv_layers_vs_float64 holds every layer to 5e-6 of float64."""
+    torch.manual_seed(11)
+    shape = [154] * 10 + [77, 77, 39, 39, 20, 20, 10, 10]
+    net = M.Generator(1024, 512, 8, generator_net_shape=shape)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith("noise.weight"):
+                p.fill_(0.1)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    z = [torch.randn(1, 512), torch.randn(1, 512)]
+    proj = torch.randn(1, 3, 1024, 1024)   # linear functional of the image
+    names = [n for n, _ in net.named_parameters()]
+
+    def ref(dtype):
+        leaves = {k: sd[k].to(dtype).clone().requires_grad_(True) for k in names}
+        sdr = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+        sdr.update(leaves)
+        img = ref_model.generator_forward_ref(sdr, [a.to(dtype) for a in z], inject_index=7, randomize_noise=False)
+        return img.detach(), torch.autograd.grad((img * proj.to(dtype)).mean(), [leaves[k] for k in names], allow_unused=True)
+
+    img32, g32 = ref(torch.float32)
+    img64, g64 = ref(torch.float64)
+    assert tuple(img64.shape) == (1, 3, 1024, 1024)
+    netg = net.to(DEV)
+    img_g = netg([cu(z[0]), cu(z[1])], inject_index=7, randomize_noise=False)
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-300))
+    assert rel(img_g.detach(), img64) <= TOL, "image 1024"
+    (img_g * cu(proj)).mean().backward()
+    params = dict(netg.named_parameters())
+    for k, b32, b64 in zip(names, g32, g64):
+        a = params[k].grad
+        if b64 is None:
+            assert a is None or float(a.abs().max()) == 0.0
+            continue
+        e_gpu, e_cpu = rel(a, b64), rel(b32, b64)
+        bar = max(5e-3, 3 * e_cpu) if b64.numel() > 1 else max(5e-2, 5 * e_cpu)   # noise.weight: one cancelling sum over up to 10^6 pixels
+        assert e_gpu <= bar, f"grad {k}: HIP vs float64 {e_gpu:.2e}, fp32 CPU reference vs float64 {e_cpu:.2e}"
+
+
+@pytest.mark.parametrize("cfg", [(154, 154, 4, True, 16), (154, 154, 8, False, 1), (154, 154, 16, True, 1),
+                                 (512, 512, 4, True, 2), (154, 154, 32, True, 1), (77, 39, 32, False, 2)])
+def test_styled_conv_layers_vs_float64(cfg):
+    """Single StyledConv layers (direct, transposed and Winograd paths) against the oracle evaluated in float64:
+    output and every gradient within 5e-6 — the fp32 MFMA path is as accurate as the fp32 CPU reference (2-7e-7)."""
+    cin, cout, H, up, B = cfg
+    torch.manual_seed(3)
+    m = M.StyledConv(cin, cout, 3, 512, upsample=up)
+    with torch.no_grad():
+        m.noise.weight.fill_(0.1)
+        m.activate.bias.copy_(0.1 * torch.randn(cout))
+    sd = {"l." + k: v.detach().double() for k, v in m.state_dict().items() if v.is_floating_point()}
+    Ho = 2 * H if up else H
+    x, w = torch.randn(B, cin, H, H), torch.randn(B, 512)
+    noise, go = torch.randn(B, 1, Ho, Ho), torch.randn(B, cout, Ho, Ho)
+    names = [n for n, _ in m.named_parameters()]
+    leaves = {"l." + k: sd["l." + k].clone().requires_grad_(True) for k in names}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr, _ = ref_model._styled_conv(sdr, "l", xr, wr, noise.double(), upsample=up)
+    gr = torch.autograd.grad(yr, [xr, wr] + [leaves["l." + k] for k in names], go.double())
+    mg = m.to(DEV)
+    xg, wg = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
+    yg = mg(xg, wg, noise=cu(noise))
+    gg = torch.autograd.grad(yg, [xg, wg] + [dict(mg.named_parameters())[k] for k in names], cu(go))
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-300))
+    assert rel(yg.detach(), yr.detach()) <= 5e-6, "out"
+    for nm, a, b in zip(["x", "style"] + names, gg, gr):
+        assert rel(a, b) <= 5e-6, f"{cfg} grad {nm}: {rel(a, b):.2e}"
+
+
 def test_full_256_teacher_forward_vs_oracle():
     torch.manual_seed(6)
     net = M.Generator(256, 512, 8)
