@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void k_styled_epilogue(float* __restrict__ out
   const int64_t plane = idx / HW;
   const int c = (int)(plane % C);
   const int b = (int)(plane / C);
-  float v = out[idx] * d[plane] + bias[c];
+  float v = out[idx] * (d ? d[plane] : 1.f) + bias[c];
   if (noise) v += noise_w[0] * noise[(noise_bstride_on ? (int64_t)b * HW : 0) + p];
   out[idx] = (v > 0.f ? v : v * alpha) * act_scale;
 }
