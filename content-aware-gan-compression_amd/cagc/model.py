@@ -564,7 +564,10 @@ class ResBlock(nn.Module):
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, activate=False, bias=False)
 
     def forward(self, input):
-        return (self.conv2(self.conv1(input)) + self.skip(input)) / math.sqrt(2)
+        a, b = self.conv2(self.conv1(input)), self.skip(input)
+        if mc.use_hip(a):
+            return mc.add_scale(a, b, 1.0 / math.sqrt(2))
+        return (a + b) / math.sqrt(2)
 
 
 class Discriminator(nn.Module):

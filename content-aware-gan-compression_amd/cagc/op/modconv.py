@@ -484,6 +484,31 @@ def pixel_norm(x):
     return x * torch.rsqrt(torch.mean(x * x, dim=1, keepdim=True) + 1e-8)
 
 
+class _AddScale(Function):
+    """(a + b) * scale in one pass; backward is g * scale for both inputs (plain differentiable ops, so the op can be
+    differentiated twice)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        with _lib.on_device(a):
+            _lib.call("cagc_add_scale", _lib.ptr(out), _lib.ptr(a), _lib.ptr(b), a.numel(), float(scale))
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = g * ctx.scale
+        return gs, gs, None
+
+
+def add_scale(a, b, scale):
+    if use_hip(a) and a.dtype == torch.float32 and a.shape == b.shape and b.is_cuda and b.dtype == torch.float32:
+        return _AddScale.apply(a, b, scale)
+    return (a + b) * scale
+
+
 class _MaskedL1(Function):
     """mean | mask*teacher - mask*student |, gradient to the student only (reference train.py:156-164 with the
     {0,1} mask of Util/content_aware_pruning.py:102-115)."""

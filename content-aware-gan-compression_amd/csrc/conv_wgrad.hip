@@ -325,12 +325,20 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)
 
 struct Wg2Plan { int mb, nb; };
 static Wg2Plan wg2_plan(int Cout, int Cin) {
-  static const Wg2Plan cands[] = {{1, 1}, {2, 2}, {3, 3}, {5, 2}, {2, 5}, {3, 5}, {5, 3}};
+  // least padded work first; among equals prefer a plan that runs 2 waves / SIMD (<= 110 accumulator registers), then
+  // the larger tile
+  static const Wg2Plan cands[] = {{1, 1}, {2, 2}, {3, 1}, {3, 3}, {5, 1}, {5, 2}, {2, 5}, {3, 5}, {5, 3}};
+  auto occ2 = [](const Wg2Plan& c) { return ((9 * c.nb + 3) / 4) * c.mb * 4 <= 110; };
   Wg2Plan best = cands[0];
   long best_cost = -1;
   for (const Wg2Plan& c : cands) {
     const long cost = (long)cdiv(Cout, 16 * c.mb) * c.mb * cdiv(Cin, 16 * c.nb) * c.nb;
-    if (best_cost < 0 || cost < best_cost || (cost == best_cost && c.mb * c.nb > best.mb * best.nb)) { best = c; best_cost = cost; }
+    bool better = best_cost < 0 || cost < best_cost;
+    if (!better && cost == best_cost) {
+      if (occ2(c) != occ2(best)) better = occ2(c);
+      else better = c.mb * c.nb > best.mb * best.nb;
+    }
+    if (better) { best = c; best_cost = cost; }
   }
   return best;
 }
@@ -510,6 +518,8 @@ extern "C" int cagc_modconv_wgrad(float* gweight, float* workspace, const float*
     const int key = pl.mb * 10 + pl.nb;
     if (key == 11) rc2 = launch_wgrad2<1, 1>(b, st2, what);
     else if (key == 22) rc2 = launch_wgrad2<2, 2>(b, st2, what);
+    else if (key == 51) rc2 = launch_wgrad2<5, 1>(b, st2, what);
+    else if (key == 31) rc2 = launch_wgrad2<3, 1>(b, st2, what);
     else if (key == 33) rc2 = launch_wgrad2<3, 3>(b, st2, what);
     else if (key == 52) rc2 = launch_wgrad2<5, 2>(b, st2, what);
     else if (key == 25) rc2 = launch_wgrad2<2, 5>(b, st2, what);

@@ -6,6 +6,7 @@
 // index is a workgroup-uniform scalar (the reference kernel pays an integer div + mod per element,
 // op/fused_bias_act_kernel.cu:25-29) and every access is a coalesced 16-byte-per-lane stream.
 #include "common.h"
+#include <stdint.h>
 
 namespace cagc {
 
@@ -408,6 +409,29 @@ extern "C" int cagc_demod_bwd(float* gs, float* gwsq, const float* gd, const flo
   if (gs) hipLaunchKernelGGL(k_demod_bwd_s, dim3(cdiv(Cin, 64), B), dim3(256), 0, st, gs, gd, d, s, wsq, B, Cin, Cout);
   if (gwsq) hipLaunchKernelGGL(k_demod_bwd_w, dim3(cdiv(Cin, 256), Cout), dim3(256), 0, st, gwsq, gd, d, s, B, Cin, Cout);
   return check_launch("cagc_demod_bwd");
+}
+
+// out = (a + b) * scale — the residual merge of the discriminator's ResBlock ((conv path + skip) / sqrt(2), reference
+// model.py:736) in one pass instead of an add and a divide
+__global__ __launch_bounds__(256) void k_add_scale(float* __restrict__ out, const float* __restrict__ a,
+                                                   const float* __restrict__ b, int64_t n4, int64_t n, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4((x.x + y.x) * scale, (x.y + y.y) * scale, (x.z + y.z) * scale, (x.w + y.w) * scale);
+  }
+  if (i == 0)
+    for (int64_t j = n4 * 4; j < n; ++j) out[j] = (a[j] + b[j]) * scale;
+}
+extern "C" int cagc_add_scale(float* out, const float* a, const float* b, int64_t n, float scale, cagc_stream_t stream) {
+  CAGC_REQUIRE(out && a && b && n >= 0, "cagc_add_scale: bad argument");
+  if (n == 0) return CAGC_OK;
+  const bool al = (((uintptr_t)out | (uintptr_t)a | (uintptr_t)b) % 16) == 0;
+  const int64_t n4 = al ? n / 4 : 0;
+  const int64_t nb = cdiv(n4 > 0 ? n4 : 1, 256);
+  CAGC_REQUIRE(nb < (1ll << 31), "cagc_add_scale: too large");
+  hipLaunchKernelGGL(k_add_scale, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, a, b, n4, n, scale);
+  return check_launch("cagc_add_scale");
 }
 
 extern "C" int cagc_masked_l1(float* loss_sum, float* gs, const float* t, const float* s, const float* mask, int B,

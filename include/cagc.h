@@ -239,6 +239,9 @@ int cagc_torgb_bwd(float* gx, float* gws, const float* g, const float* x, const 
 int cagc_masked_l1(float* loss_sum, float* gs, const float* t, const float* s, const float* mask, int B,
                    int C, int64_t HW, float coef, cagc_stream_t stream);
 
+/* out[i] = (a[i] + b[i]) * scale — ResBlock merge (conv path + skip) / sqrt(2) (model.py:736) in one pass. */
+int cagc_add_scale(float* out, const float* a, const float* b, int64_t n, float scale, cagc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
