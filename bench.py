@@ -160,8 +160,8 @@ def cpu_baseline(sample_batch=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--full-iteration", action="store_true",
@@ -246,6 +246,7 @@ def main():
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "launches_per_step": cnt // 3, "avg_launch_ms": round(tot_ms / cnt, 4),
                     "flops_per_launch_avg": flops / cnt,
+                    "achieved_direct_conv_equivalent": round(ach * (2.25 if name == "cagc_wino_conv3x3" else 1.0), 2),
                     "flops_note": "MFMA flops executed (Winograd: 4 MACs/output/channel-pair; its direct-conv equivalent "
                                   "rate is 2.25x 'achieved')" if name == "cagc_wino_conv3x3" else "2*MACs of the conv",
                     "all_mfma_entry_points": {k: {"ms_per_step": round(v[1] / 3, 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
