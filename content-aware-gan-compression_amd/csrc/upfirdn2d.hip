@@ -328,8 +328,8 @@ using namespace cagc;
 extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, int64_t planes, int in_h, int in_w,
                               int out_h, int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
                               int pad_x0, int pad_x1, int pad_y0, int pad_y1, cagc_stream_t stream) {
-  CAGC_REQUIRE(out && x && kernel, "cagc_upfirdn2d: null tensor");
   CAGC_REQUIRE(planes >= 0 && in_h > 0 && in_w > 0 && kh > 0 && kw > 0, "cagc_upfirdn2d: bad shape");
+  CAGC_REQUIRE(planes == 0 || (out && x && kernel), "cagc_upfirdn2d: null tensor");
   CAGC_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, "cagc_upfirdn2d: up/down must be positive");
   const int eh = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
   const int ew = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;

@@ -542,3 +542,27 @@ def test_discriminator_skip_blur_down_conv1x1_vs_oracle(cfg):
     gxg, gwg = torch.autograd.grad(yg, [xg, lg[1].weight], cu(go))
     assert_close(gxg, gxr, TOL, "grad x")
     assert_close(gwg, gwr, TOL, "grad weight")
+
+
+def test_c_abi_error_contract():
+    """errors come back as negative codes + cagc_last_error(), never as exceptions across the ABI; the
+    Python binding turns them into RuntimeError.  Also: edge shapes the reference accepts (empty batch planes)."""
+    x = torch.randn(1, 8, 10, 12, device=DEV)
+    out = torch.empty(1, 16, 10, 12, device=DEV)
+    up = torch.empty(_lib.query("cagc_wino_packed_elems", 8, 16), device=DEV)
+    with pytest.raises(RuntimeError, match="H % 8 == 0"):      # ineligible size for the Winograd entry point
+        _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(x), _lib.ptr(up), None, 1, 8, 16, 10, 12, 0, None, None, 0, None,
+                  None, 0.2, 1.0)
+    with pytest.raises(RuntimeError, match="null tensor"):
+        _lib.call("cagc_upfirdn2d", None, _lib.ptr(x), _lib.ptr(x), 8, 10, 12, 10, 12, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0)
+    with pytest.raises(RuntimeError, match="expected"):         # wrong output size
+        k = torch.ones(4, 4, device=DEV) / 16
+        _lib.call("cagc_upfirdn2d", _lib.ptr(out), _lib.ptr(x), _lib.ptr(k), 8, 10, 12, 10, 12, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1)
+    lib = _lib.load()
+    assert lib.cagc_last_error().decode() != ""
+    # zero planes: a no-op that succeeds (the reference's ops accept empty batches)
+    k = torch.ones(4, 4, device=DEV) / 16
+    _lib.call("cagc_upfirdn2d", _lib.ptr(out), _lib.ptr(x), _lib.ptr(k), 0, 10, 12, 9, 11, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1)
+    e = torch.empty(0, 8, 10, 12, device=DEV)
+    assert fused_leaky_relu(e, torch.zeros(8, device=DEV)).shape == e.shape
+    assert upfirdn2d(e, k, pad=(1, 1)).shape == (0, 8, 9, 11)
