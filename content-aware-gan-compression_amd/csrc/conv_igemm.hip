@@ -775,6 +775,8 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   // phase (py,px), virtual (m,n): ky = py + 2jy, input row = m - jy
   RawTap taps[4][4];
   RawItem items[12];
+  int ns = 0;   // strips: the full output has 2H+1 rows / 2W+1 columns, so only the even phases own a row m = H / a column
+                // n = W; the odd phases' planes stay zero there (k_zero_rowcol / zero_fill below)
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       const int ph = py * 2 + px;
@@ -782,8 +784,8 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
       for (int jy = 0; jy < (py ? 1 : 2); ++jy)
         for (int jx = 0; jx < (px ? 1 : 2); ++jx) taps[ph][n++] = RawTap{0, -jy, -jx, (py + 2 * jy) * 3 + (px + 2 * jx)};
       items[ph] = RawItem{n, taps[ph], ph, 0, 0, H, W};              // exact H x W main region
-      items[4 + 2 * ph] = RawItem{n, taps[ph], ph, H, 0, 1, W + 1};  // bottom row m = H (incl. the corner)
-      items[5 + 2 * ph] = RawItem{n, taps[ph], ph, 0, W, H, 1};      // right column n = W
+      if (py == 0) items[4 + ns++] = RawItem{n, taps[ph], ph, H, 0, 1, px ? W : W + 1};  // bottom row m = H (+ corner)
+      if (px == 0) items[4 + ns++] = RawItem{n, taps[ph], ph, 0, W, H, 1};               // right column n = W
     }
   // Two launches: the main regions keep the small staging footprint (NV = 4 -> 2 waves / SIMD); the thin strips
   // need longer halo tiles.  Split-K launches accumulate with atomics, so t is zeroed once up front.
@@ -808,8 +810,8 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
     hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (H + 1 + W + 1), 256)), dim3(256), 0, st, t, planes, H + 1,
                        W + 1, a.Wopitch, H, W);
   }
-  for (int q = 4; q < 12; ++q) items[q].strip = 1;
-  return run_conv(a2, items + 4, 8, st, what, false, true);
+  for (int q = 4; q < 4 + ns; ++q) items[q].strip = 1;
+  return run_conv(a2, items + 4, ns, st, what, false, true);
 }
 
 extern "C" int cagc_modconv_dgrad(float* gx, float* gs, const float* gz, const float* wp, const float* s, const float* x,
