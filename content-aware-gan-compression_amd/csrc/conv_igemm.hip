@@ -599,8 +599,8 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
     int ks = 1;
     // target ~256 workgroups: every extra split adds a pass of fp32 atomics over the tile, which costs more than the
     // shorter (latency-bound, ~2 us per chunk) K loop saves beyond that (sweep: 512 -> 256 saves 0.75 ms per step)
-    if (allow_split && tiles_all * mt < 256 && nchunks >= 4) {
-      ks = cdiv(256, tiles_all * mt);
+    if (allow_split && tiles_all * mt < 512 && nchunks >= 4) {
+      ks = (tiles_all * mt < 256) ? cdiv(256, tiles_all * mt) : 2;   // half a round of workgroups: split once
       if (ks > nchunks / 2) ks = nchunks / 2;
       if (ks < 1) ks = 1;
     }
@@ -910,15 +910,22 @@ extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_b
   hipStream_t st = as_stream(stream);
   ConvArgs a2 = a;
   int rc;
+  // low-resolution layers: too few pixel tiles to fill the chip and a 64-chunk K loop per workgroup -> split K
+  // (atomics), which needs the whole gradient zeroed first
+  const bool small = (int64_t)B * Ho * Wo <= 32768;
+  if (small) {
+    const size_t bytes = sizeof(float) * (size_t)B * Cin * Hin * out_pitch;
+    { int zrc = zero_fill(gx, bytes, st); if (zrc) return zrc; }
+  }
   if (fused_phase_ok(B, Ho, Wo, a.Mp)) {
     RawTap t9[9];
     RawItem fi = fused_phase_item(t9, Ho, Wo, /*planar_out=*/false);
     rc = run_conv(a, &fi, 1, st, what, false, false);
   } else {
-    rc = run_conv(a, main_items, 4, st, what, false, false);
+    rc = run_conv(a, main_items, 4, st, what, false, small);
   }
   if (rc) return rc;
-  {
+  if (!small) {
     const int64_t planes = (int64_t)B * Cin;
     hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (Hin + Win), 256)), dim3(256), 0, st, gx, planes, Hin, Win,
                        out_pitch, Hin - 1, Win - 1);
