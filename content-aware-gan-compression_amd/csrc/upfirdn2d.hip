@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void k_fir4_vec(float* __restrict__ out, const
 // blur after the transposed conv, phase-planar input.  T_full[Y,X] = t[plane 2*(Y&1)+(X&1)][Y>>1][X>>1].
 // out[Y,X] = sum_{a,b} kf[a][b] * T_full[Y-1+a, X-1+b],  Y in [0,2H), kf = flipped fir.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blur_up_fwd(float* __restrict__ out, const float* __restrict__ t,
+// generic fallback of k_blur_up_fwd below (odd W or unaligned tensors): scalar loads / stores
+__global__ __launch_bounds__(256) void k_blur_up_fwd_scalar(float* __restrict__ out, const float* __restrict__ t,
                                                      const float* __restrict__ fir, const float* __restrict__ d,
                                                      const float* __restrict__ noise, int noise_bstride_on,
                                                      const float* __restrict__ noise_w, const float* __restrict__ bias,
@@ -274,6 +275,83 @@ __global__ __launch_bounds__(256) void k_blur_up_fwd(float* __restrict__ out, co
       out[((int64_t)plane * OH + Y) * OW + X] = v;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_blur_up_fwd(float* __restrict__ out, const float* __restrict__ t,
+                                                     const float* __restrict__ fir, const float* __restrict__ d,
+                                                     const float* __restrict__ noise, int noise_bstride_on,
+                                                     const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                     int C, int H, int W, int tiles_x, int tiles_y, float alpha,
+                                                     float act_scale) {
+  constexpr int LR = FT + 4, LW = FT + 4 + 1;  // rows Y0-2 .. Y0+33 (36), same for cols
+  __shared__ float tile[LR * LW];
+  __shared__ float kf[16];
+  int bid = blockIdx.x;
+  const int X0 = (bid % tiles_x) * FT;
+  bid /= tiles_x;
+  const int Y0 = (bid % tiles_y) * FT;
+  const int plane = bid / tiles_y;  // b*C + c
+  const int b = plane / C, c = plane - b * C;
+  const int PH = H + 1, PW = W + 1, PWp = (W + 1 + 3) & ~3;  // valid width, row pitch (cagc_phase_pitch)
+  const float* tp = t + (int64_t)plane * 4 * PH * PWp;
+  if (threadIdx.x < 16) kf[threadIdx.x] = fir[15 - threadIdx.x];
+  // stage: LDS row r <-> Y = Y0 - 2 + r ; for each phase (py,px): m = (Y0-2)/2 + mr, mr in [0,18).  16-byte loads from the
+  // aligned superset of columns [n0 - 3, n0 + 21) of every phase-plane row (the pitch is a multiple of 4).
+  const int m0 = (Y0 - 2) / 2, n0 = (X0 - 2) / 2;  // Y0,X0 are multiples of 32 -> exact (may be -1); n0 == 3 (mod 4)
+  constexpr int HR = LR / 2;                         // 18
+  for (int e = threadIdx.x; e < 4 * HR * 6; e += 256) {
+    const int q = e % 6;
+    const int mr = (e / 6) % HR;
+    const int ph = e / (6 * HR);
+    const int m = m0 + mr, na = n0 - 3 + 4 * q;      // first column of this float4 (multiple of 4, may be -4)
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m >= 0 && m < PH && na >= 0 && na < PWp) v = *reinterpret_cast<const float4*>(tp + ((int64_t)ph * PH + m) * PWp + na);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    float* trow = tile + (2 * mr + (ph >> 1)) * LW + (ph & 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int n = na + k, nc = n - n0;
+      if (nc >= 0 && nc < HR) trow[2 * nc] = (n >= 0 && n < PW) ? vv[k] : 0.f;   // pitch padding is not trusted
+    }
+  }
+  __syncthreads();
+  const int OH = 2 * H, OW = 2 * W;
+  // thread = (row, 4 adjacent columns): 4 x 7 register window, one 16-byte store
+  const int cg = threadIdx.x & 7, yy = threadIdx.x >> 3;
+  const int X = X0 + 4 * cg, Y = Y0 + yy;
+  if (X >= OW || Y >= OH) return;
+  const float dv = d ? d[plane] : 1.f;
+  const float nw = noise ? noise_w[0] : 0.f;
+  const float bv = bias ? bias[c] : 0.f;
+  const bool act = (bias != nullptr);  // styled epilogue (noise + bias + LeakyReLU); otherwise blur * d only
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // T_full row Y-1+a -> LDS row yy + 1 + a ; column X-1+bb -> LDS column 4*cg + 1 + bb
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float w[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) w[j] = tile[(yy + 1 + a) * LW + 4 * cg + 1 + j];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const float k = kf[a * 4 + bb];
+      acc[0] += w[bb] * k; acc[1] += w[bb + 1] * k; acc[2] += w[bb + 2] * k; acc[3] += w[bb + 3] * k;
+    }
+  }
+  float4 nzv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (act && noise)   // OW % 4 == 0 and X % 4 == 0: aligned
+    nzv = *reinterpret_cast<const float4*>(noise + (noise_bstride_on ? (int64_t)b * OH * OW : 0) + (int64_t)Y * OW + X);
+  const float nn[4] = {nzv.x, nzv.y, nzv.z, nzv.w};
+  float o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float v = acc[k] * dv;
+    if (act) {
+      v += bv + nw * nn[k];
+      v = (v > 0.f ? v : v * alpha) * act_scale;
+    }
+    o[k] = v;
+  }
+  *reinterpret_cast<float4*>(out + ((int64_t)plane * OH + Y) * OW + X) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // gT_full[Yt,Xt] = sum_{a,b} kf[a][b] * gz[Yt+1-a, Xt+1-b]  for Yt in [0,2H], Xt in [0,2W]; the phase
@@ -377,8 +455,13 @@ extern "C" int cagc_blur_up_fwd(float* out, const float* t, const float* fir, co
   const int tx = cdiv(2 * W, FT), ty = cdiv(2 * H, FT);
   const int64_t nb = (int64_t)B * C * tx * ty;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_blur_up_fwd: too large");
-  hipLaunchKernelGGL(k_blur_up_fwd, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, t, fir, d, noise,
-                     noise_batch == B ? 1 : 0, noise_w, bias, C, H, W, tx, ty, alpha, act_scale);
+  const bool vec = (W % 2 == 0) && (((uintptr_t)out | (uintptr_t)t | (uintptr_t)noise) % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL(k_blur_up_fwd, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, t, fir, d, noise,
+                       noise_batch == B ? 1 : 0, noise_w, bias, C, H, W, tx, ty, alpha, act_scale);
+  else
+    hipLaunchKernelGGL(k_blur_up_fwd_scalar, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, t, fir, d, noise,
+                       noise_batch == B ? 1 : 0, noise_w, bias, C, H, W, tx, ty, alpha, act_scale);
   return check_launch("cagc_blur_up_fwd");
 }
 

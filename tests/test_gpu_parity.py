@@ -120,7 +120,7 @@ def test_modulated_conv_golden_plain_up_rgb_all_grads():
 @pytest.mark.parametrize("cfg", [  # (B, cin, cout, H, W, upsample)
     (2, 154, 154, 16, 16, False), (2, 154, 77, 32, 32, True), (2, 77, 39, 64, 64, True), (2, 39, 39, 96, 64, False),
     (1, 512, 512, 4, 4, False), (3, 512, 256, 8, 8, True), (2, 128, 128, 64, 64, False), (5, 20, 10, 12, 20, False),
-    (16, 154, 154, 4, 4, True)])
+    (16, 154, 154, 4, 4, True), (2, 24, 20, 9, 7, True), (1, 16, 16, 6, 10, True)])   # last two: odd / non-pow2 sizes (scalar fallbacks)
 def test_styled_conv_vs_oracle_forward_and_all_grads(cfg):
     B, cin, cout, H, W, up = cfg
     torch.manual_seed(3)
