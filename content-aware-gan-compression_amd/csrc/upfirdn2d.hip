@@ -156,6 +156,56 @@ __global__ __launch_bounds__(256) void k_fir_s1(float* __restrict__ out, const f
   }
 }
 
+// 4x4 FIR after 2x zero-insertion with pad0 = 2 (the StyleGAN2 `Upsample`, pad (2,1), and the adjoint of the decimating
+// skip blur): polyphase — every output has exactly 2x2 non-zero taps.  32x32 output tile from an 18x18 input patch;
+// thread = (output row, 4 adjacent columns): 2 rows x 4 columns of the patch in registers (8 LDS reads for 4 outputs,
+// the generic kernel does 16 predicated reads per output), one 16-byte store.  Requires out_w % 4 == 0.
+__global__ __launch_bounds__(256) void k_fir4_up2(float* __restrict__ out, const float* __restrict__ x,
+                                                  const float* __restrict__ kern, int in_h, int in_w, int out_h, int out_w,
+                                                  int tiles_x, int tiles_y) {
+  constexpr int IT = FT / 2 + 2, LW = IT + 1;   // 18 input rows / cols: iy = Y0/2 - 1 .. Y0/2 + 16
+  __shared__ float tile[IT * LW];
+  __shared__ float kf[16];
+  int bid = blockIdx.x;
+  const int X0 = (bid % tiles_x) * FT;
+  bid /= tiles_x;
+  const int Y0 = (bid % tiles_y) * FT;
+  const int64_t p = bid / tiles_y;
+  const int tid = threadIdx.x;
+  if (tid < 16) kf[tid] = kern[15 - tid];   // flipped: true convolution
+  const float* xp = x + p * (int64_t)in_h * in_w;
+  const int iy0 = Y0 / 2 - 1, ix0 = X0 / 2 - 1;
+  for (int e = tid; e < IT * IT; e += 256) {
+    const int r = e / IT, c = e - r * IT;
+    const int iy = iy0 + r, ix = ix0 + c;
+    tile[r * LW + c] = (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) ? xp[(int64_t)iy * in_w + ix] : 0.f;
+  }
+  __syncthreads();
+  const int cg = tid & 7, yy = tid >> 3;
+  const int Y = Y0 + yy, X = X0 + 4 * cg;
+  if (Y >= out_h || X >= out_w) return;
+  // out[Y,X] = sum_{i,j} kf[i][j] * U[Y-2+i, X-2+j],  U[u,v] = in[u/2, v/2] for even u,v else 0
+  //   Y even: i in {0,2} -> input rows Y/2-1, Y/2 ;  Y odd: i in {1,3} -> rows (Y-1)/2, (Y+1)/2     (LDS row = iy - iy0)
+  const int pi = Y & 1;                       // first contributing kernel row
+  const int r0 = ((Y - 2 + pi) >> 1) - iy0;   // LDS row of tap i = pi; tap pi + 2 is the next row
+  const int c0 = (X >> 1) - 1 - ix0;          // LDS column of input column X/2 - 1
+  float w[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[a][j] = tile[(r0 + a) * LW + c0 + j];
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const float k0 = kf[(pi + 2 * a) * 4 + 0], k1 = kf[(pi + 2 * a) * 4 + 1], k2 = kf[(pi + 2 * a) * 4 + 2], k3 = kf[(pi + 2 * a) * 4 + 3];
+    o[0] += w[a][0] * k0 + w[a][1] * k2;   // X   (even): j = 0 -> col X/2-1, j = 2 -> col X/2
+    o[1] += w[a][1] * k1 + w[a][2] * k3;   // X+1 (odd):  j = 1 -> col X/2,   j = 3 -> col X/2+1
+    o[2] += w[a][1] * k0 + w[a][2] * k2;   // X+2 (even): cols X/2, X/2+1
+    o[3] += w[a][2] * k1 + w[a][3] * k3;   // X+3 (odd):  cols X/2+1, X/2+2
+  }
+  *reinterpret_cast<float4*>(out + (p * out_h + Y) * (int64_t)out_w + X) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // 4x4 FIR, up = down = 1, 16-byte path: rows of both tensors start 16-byte aligned (pitches % 4 == 0) and pad <= 4.
 // 32 x 32 output tile; the input footprint is staged with float4 loads from the aligned superset of columns
 // [tx0 - 4, tx0 + 36); every thread produces 4 horizontally adjacent outputs (4 x 7 register window) and stores them
@@ -433,6 +483,8 @@ extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, i
     if (up_x == 1)
       hipLaunchKernelGGL((k_fir4_updown<1, 2>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w,
                          pad_x0, pad_y0, tx, ty);
+    else if (pad_x0 == 2 && pad_y0 == 2 && out_w % 4 == 0 && ((uintptr_t)out % 16) == 0)
+      hipLaunchKernelGGL(k_fir4_up2, dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w, tx, ty);
     else
       hipLaunchKernelGGL((k_fir4_updown<2, 1>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w,
                          pad_x0, pad_y0, tx, ty);
