@@ -206,6 +206,57 @@ __global__ __launch_bounds__(256) void k_fir4_up2(float* __restrict__ out, const
   *reinterpret_cast<float4*>(out + (p * out_h + Y) * (int64_t)out_w + X) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// 4x4 FIR + 2x decimation with pad0 = 1 (the discriminator's skip path evaluated only where its stride-2 1x1 conv
+// samples, and the adjoint of `Upsample`): 32x32 output tile from a 66x66 input patch staged with 16-byte loads from the
+// aligned superset of columns [2*X0 - 4, 2*X0 + 68); every thread produces 4 vertically adjacent outputs from a 10x4
+// register window (10 LDS reads per output instead of 16 predicated ones).  Requires in_w % 4 == 0, x 16-byte aligned.
+__global__ __launch_bounds__(256) void k_fir4_down2(float* __restrict__ out, const float* __restrict__ x,
+                                                    const float* __restrict__ kern, int in_h, int in_w, int out_h,
+                                                    int out_w, int tiles_x, int tiles_y) {
+  constexpr int IR = 2 * FT + 2, Q = (2 * FT + 8) / 4, LW = 2 * FT + 8 + 1;   // 66 rows; 18 float4 per row; odd stride
+  __shared__ float tile[IR * LW];
+  __shared__ float kf[16];
+  int bid = blockIdx.x;
+  const int X0 = (bid % tiles_x) * FT;
+  bid /= tiles_x;
+  const int Y0 = (bid % tiles_y) * FT;
+  const int64_t p = bid / tiles_y;
+  const int tid = threadIdx.x;
+  if (tid < 16) kf[tid] = kern[15 - tid];   // flipped: true convolution
+  const float* xp = x + p * (int64_t)in_h * in_w;
+  const int iy0 = 2 * Y0 - 1, ixa = 2 * X0 - 4;   // LDS row 0 <-> input row iy0; LDS column 0 <-> input column ixa
+  for (int e = tid; e < IR * Q; e += 256) {
+    const int r = e / Q, q = e - r * Q;
+    const int iy = iy0 + r, ix = ixa + 4 * q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = *reinterpret_cast<const float4*>(xp + (int64_t)iy * in_w + ix);
+    float* t = tile + r * LW + 4 * q;
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+  }
+  __syncthreads();
+  const int lx = tid & 31, ly = tid >> 5;
+  const int ox = X0 + lx;
+  if (ox >= out_w) return;
+  // out[oy,ox] = sum_{i,j} kf[i][j] * in[2oy-1+i, 2ox-1+j]: LDS row 2*(oy-Y0) + i, LDS column 2*lx + 3 + j
+  float win[10][4];
+#pragma unroll
+  for (int r = 0; r < 10; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) win[r][j] = tile[(8 * ly + r) * LW + 2 * lx + 3 + j];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int oy = Y0 + 4 * ly + q;
+    if (oy < out_h) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += win[2 * q + i][j] * kf[i * 4 + j];
+      out[(p * out_h + oy) * (int64_t)out_w + ox] = acc;
+    }
+  }
+}
+
 // 4x4 FIR, up = down = 1, 16-byte path: rows of both tensors start 16-byte aligned (pitches % 4 == 0) and pad <= 4.
 // 32 x 32 output tile; the input footprint is staged with float4 loads from the aligned superset of columns
 // [tx0 - 4, tx0 + 36); every thread produces 4 horizontally adjacent outputs (4 x 7 register window) and stores them
@@ -480,7 +531,9 @@ extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, i
     const int tx = cdiv(out_w, FT), ty = cdiv(out_h, FT);
     const int64_t nb = planes * tx * ty;
     CAGC_REQUIRE(nb < (1ll << 31), "cagc_upfirdn2d: too large");
-    if (up_x == 1)
+    if (up_x == 1 && pad_x0 == 1 && pad_y0 == 1 && in_w % 4 == 0 && ((uintptr_t)x % 16) == 0)
+      hipLaunchKernelGGL(k_fir4_down2, dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w, tx, ty);
+    else if (up_x == 1)
       hipLaunchKernelGGL((k_fir4_updown<1, 2>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w,
                          pad_x0, pad_y0, tx, ty);
     else if (pad_x0 == 2 && pad_y0 == 2 && out_w % 4 == 0 && ((uintptr_t)out % 16) == 0)
