@@ -48,6 +48,7 @@ _PROTOS = {
     "cagc_torgb_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "cagc_masked_l1": [_p, _p, _p, _p, _p, _i, _i, _i64, _f, _p],
     "cagc_add_scale": [_p, _p, _p, _i64, _f, _p],
+    "cagc_scale_reduce": [_p, _p, _p, _p, _i, _i, _i64, _p],
 }
 _RESTYPES = {
     "cagc_last_error": ctypes.c_char_p,

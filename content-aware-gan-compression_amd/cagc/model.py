@@ -231,6 +231,15 @@ class ModulatedConv2d(nn.Module):
             self._wino = (key, mc.pack_wino(w[0], self.scale, False))
         return self._wino[1]
 
+    def wino_weights_bwd(self, H, W):
+        """Winograd-domain weights of the data gradient (flipped taps, swapped channel roles) — only for trainable
+        weights under autograd, i.e. when a backward pass will run (None otherwise)."""
+        w = self.weight
+        if (self.upsample or self.downsample or self.kernel_size != 3 or not mc.wino_ok(H, W) or not mc.WINO_DGRAD
+                or not (torch.is_grad_enabled() and w.requires_grad)):
+            return None
+        return mc.pack_wino(w[0], self.scale, True)
+
     def invalidate_packed(self):
         self._packed = None
         self._wino = None
@@ -251,7 +260,8 @@ class ModulatedConv2d(nn.Module):
             d = self._demod(s, wsq)
             out = mc._ModConv.apply(input, self.weight, s, d, None, None, None, wp_fwd, wp_bwd,
                                     self.blur.kernel if self.upsample else None, False, self.upsample,
-                                    self.wino_weights(input.shape[2], input.shape[3]))
+                                    self.wino_weights(input.shape[2], input.shape[3]),
+                                    self.wino_weights_bwd(input.shape[2], input.shape[3]))
         else:
             out = mc.modconv_composed(input, self.weight, s, self.demodulate, self.upsample, self.downsample,
                                       self.blur.kernel if (self.upsample or self.downsample) else None,
@@ -313,7 +323,7 @@ class StyledConv(nn.Module):
                 noise = noise.expand(batch, 1, oh, ow)
             out = mc._ModConv.apply(input, conv.weight, s, d, noise, self.noise.weight, self.activate.bias, wp_fwd,
                                     wp_bwd, conv.blur.kernel if conv.upsample else None, True, conv.upsample,
-                                    conv.wino_weights(h, w))
+                                    conv.wino_weights(h, w), conv.wino_weights_bwd(h, w))
             styles = s.view(batch, 1, cin, 1, 1)
         else:
             if return_style_scalars:

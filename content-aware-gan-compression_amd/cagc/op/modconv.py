@@ -138,7 +138,8 @@ class _ModConv(Function):
     (reference model.py:351-367); `upsample` the transposed-conv + blur variant (model.py:259-270)."""
 
     @staticmethod
-    def forward(ctx, x, weight, s, d, noise, noise_w, bias, wp_fwd, wp_bwd, fir, styled, upsample, up_wino=None):
+    def forward(ctx, x, weight, s, d, noise, noise_w, bias, wp_fwd, wp_bwd, fir, styled, upsample, up_wino=None,
+                up_wino_bwd=None):
         x = x.contiguous()
         s = s.contiguous()
         B, cin, H, W = x.shape
@@ -169,13 +170,14 @@ class _ModConv(Function):
                           k, EPI_STYLED if styled else EPI_LINEAR, _lib.ptr(d_c), _lib.ptr(noise) if styled else None, nb,
                           _lib.ptr(noise_w) if styled else None, _lib.ptr(bias) if styled else None, 0.2, SQRT2)
         ctx.styled, ctx.upsample, ctx.k = styled, upsample, k
-        ctx.save_for_backward(x, s, d_c, noise, noise_w, bias, out, wp_bwd, fir)
+        ctx.save_for_backward(x, s, d_c, noise, noise_w, bias, out, wp_bwd, fir,
+                              up_wino_bwd if (up_wino_bwd is not None and not upsample and k == 3 and wino_ok(H, W)) else None)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        x, s, d, noise, noise_w, bias, out, wp_bwd, fir = ctx.saved_tensors
+        x, s, d, noise, noise_w, bias, out, wp_bwd, fir, up_wino_bwd = ctx.saved_tensors
         styled, upsample, k = ctx.styled, ctx.upsample, ctx.k
         if wp_bwd is None:
             raise RuntimeError("modulated conv: backward requested but the weights were packed forward-only")
@@ -221,6 +223,12 @@ class _ModConv(Function):
                 if upsample:
                     _lib.call("cagc_modconv_up_dgrad", _lib.ptr(gx), _lib.ptr(gs), _lib.ptr(g), _lib.ptr(wp_bwd), _lib.ptr(s),
                               _lib.ptr(x), B, cin, cout, H, W)
+                elif up_wino_bwd is not None:
+                    # Winograd data gradient (2.25x fewer MFMA flops than the direct kernel), then one pass that takes the
+                    # style gradient sum_p gx*x and applies the modulation s to gx
+                    _lib.call("cagc_wino_conv3x3", _lib.ptr(gx), _lib.ptr(g), _lib.ptr(up_wino_bwd), None, B, cout, cin, H, W,
+                              EPI_LINEAR, None, None, 0, None, None, 0.2, 1.0)
+                    _lib.call("cagc_scale_reduce", _lib.ptr(gx), _lib.ptr(x), _lib.ptr(s), _lib.ptr(gs), B, cin, H * W)
                 else:
                     _lib.call("cagc_modconv_dgrad", _lib.ptr(gx), _lib.ptr(gs), _lib.ptr(g), _lib.ptr(wp_bwd), _lib.ptr(s),
                               _lib.ptr(x), B, cin, cout, H, W, k)
@@ -231,7 +239,7 @@ class _ModConv(Function):
                 gweight = torch.empty(1, cout, cin, k, k, dtype=x.dtype, device=dev)
                 _lib.call("cagc_modconv_wgrad", _lib.ptr(gweight), _lib.ptr(ws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(s), B, cin,
                           cout, H, W, k, up, 1.0 / math.sqrt(cin * k * k))
-        return (gx if need_x else None, gweight, gs, gd, None, g_nw, g_bias, None, None, None, None, None, None)
+        return (gx if need_x else None, gweight, gs, gd, None, g_nw, g_bias, None, None, None, None, None, None, None)
 
 
 def modconv_composed(x, weight, s, demodulate, upsample, downsample, blur_kernel, blur_pad):

@@ -411,6 +411,52 @@ extern "C" int cagc_demod_bwd(float* gs, float* gwsq, const float* gd, const flo
   return check_launch("cagc_demod_bwd");
 }
 
+// gs[b,c] += sum_p gx[b,c,p] * x[b,c,p];  gx[b,c,p] *= s[b,c]   — closes a modulated conv's data gradient when the
+// contraction itself ran on a kernel without the fused style reduction (the Winograd dgrad): one pass, one atomic per
+// workgroup.
+__global__ __launch_bounds__(EW_THREADS) void k_scale_reduce(float* __restrict__ gx, const float* __restrict__ x,
+                                                             const float* __restrict__ s, float* __restrict__ gs,
+                                                             int64_t HW, int nchunk) {
+  __shared__ float sm[4];
+  const int plane = blockIdx.x / nchunk;
+  const int chunk = blockIdx.x - plane * nchunk;
+  const float sv = s ? s[plane] : 1.f;
+  float* gp = gx + (int64_t)plane * HW;
+  const float* xp = x + (int64_t)plane * HW;
+  const int64_t lo = (int64_t)chunk * EW_CHUNK;
+  const bool vec = (HW % 4 == 0) && ((((uintptr_t)gx | (uintptr_t)x) % 16) == 0);
+  float acc = 0.f;
+#pragma unroll
+  for (int it = 0; it < EW_ITERS; ++it) {
+    const int64_t i = lo + ((int64_t)it * EW_THREADS + threadIdx.x) * EW_VEC;
+    if (vec && i + EW_VEC <= HW) {
+      float4 g = *reinterpret_cast<const float4*>(gp + i);
+      const float4 xv = *reinterpret_cast<const float4*>(xp + i);
+      acc += g.x * xv.x + g.y * xv.y + g.z * xv.z + g.w * xv.w;
+      g.x *= sv; g.y *= sv; g.z *= sv; g.w *= sv;
+      *reinterpret_cast<float4*>(gp + i) = g;
+    } else {
+      for (int k = 0; k < EW_VEC; ++k)
+        if (i + k < HW) { const float g = gp[i + k]; acc += g * xp[i + k]; gp[i + k] = g * sv; }
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && gs) atomicAdd(gs + plane, (sm[0] + sm[1]) + (sm[2] + sm[3]));
+}
+extern "C" int cagc_scale_reduce(float* gx, const float* x, const float* s, float* gs, int B, int C, int64_t HW,
+                                 cagc_stream_t stream) {
+  CAGC_REQUIRE(B >= 0 && C >= 0 && HW >= 0, "cagc_scale_reduce: bad shape");
+  if ((int64_t)B * C * HW == 0) return CAGC_OK;
+  CAGC_REQUIRE(gx && x, "cagc_scale_reduce: null tensor");
+  const int nchunk = (int)cdiv(HW, (int64_t)EW_CHUNK);
+  const int64_t nb = (int64_t)B * C * nchunk;
+  CAGC_REQUIRE(nb < (1ll << 31), "cagc_scale_reduce: too large");
+  hipLaunchKernelGGL(k_scale_reduce, dim3((unsigned)nb), dim3(EW_THREADS), 0, as_stream(stream), gx, x, s, gs, HW, nchunk);
+  return check_launch("cagc_scale_reduce");
+}
+
 // out = (a + b) * scale — the residual merge of the discriminator's ResBlock ((conv path + skip) / sqrt(2), reference
 // model.py:736) in one pass instead of an add and a divide
 __global__ __launch_bounds__(256) void k_add_scale(float* __restrict__ out, const float* __restrict__ a,

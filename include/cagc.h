@@ -239,6 +239,11 @@ int cagc_torgb_bwd(float* gx, float* gws, const float* g, const float* x, const 
 int cagc_masked_l1(float* loss_sum, float* gs, const float* t, const float* s, const float* mask, int B,
                    int C, int64_t HW, float coef, cagc_stream_t stream);
 
+/* Close a modulated conv's data gradient computed WITHOUT the style scaling (e.g. by cagc_wino_conv3x3 on dgrad-packed
+ * weights): gs[b,c] += sum_p gx[b,c,p] * x[b,c,p]  (gs nullable), then gx[b,c,p] *= s[b,c]  (s nullable).  One pass. */
+int cagc_scale_reduce(float* gx, const float* x, const float* s, float* gs, int B, int C, int64_t HW,
+                      cagc_stream_t stream);
+
 /* out[i] = (a[i] + b[i]) * scale — ResBlock merge (conv path + skip) / sqrt(2) (model.py:736) in one pass. */
 int cagc_add_scale(float* out, const float* a, const float* b, int64_t n, float scale, cagc_stream_t stream);
 
