@@ -509,6 +509,7 @@ class ConvLayer(nn.Sequential):
         super().__init__(*layers)
         self._fused_down = downsample and kernel_size == 3 and list(blur_kernel) == [1, 3, 3, 1]
         self._fused_s1 = (not downsample) and kernel_size == 3 and activate and bias
+        self._fused_1x1 = (not downsample) and kernel_size == 1 and activate and bias
         self._fused_skip = (downsample and kernel_size == 1 and not activate and not bias
                             and list(blur_kernel) == [1, 3, 3, 1])
         self._packed = None
@@ -546,6 +547,12 @@ class ConvLayer(nn.Sequential):
             conv, act = self[0], self[1]
             up_fwd, up_bwd = self._wino_weights(conv)
             return mc._Conv3x3Act.apply(input, conv.weight, act.bias, up_fwd, up_bwd, conv.scale)
+        # 1x1 conv + FusedLeakyReLU (the discriminator's from-RGB layer) as one implicit-GEMM launch
+        if (self._fused_1x1 and mc.use_hip(input) and input.dtype == torch.float32 and input.shape[3] % 4 == 0
+                and self[1].bias is not None and self[1].negative_slope == 0.2):
+            conv, act = self[0], self[1]
+            wp_fwd, wp_bwd = self._packed_weights(conv)
+            return mc._Conv1x1Act.apply(input, conv.weight, act.bias, wp_fwd, wp_bwd, conv.scale)
         # Blur -> 3x3 stride-2 conv as one op on the hand-written MFMA kernel (odd blurred size 2*Ho+1)
         if (self._fused_down and mc.use_hip(input) and input.dtype == torch.float32
                 and (input.shape[2] + sum(self[0].pad) - 3) % 2 == 1 and (input.shape[3] + sum(self[0].pad) - 3) % 2 == 1):

@@ -743,7 +743,7 @@ extern "C" int cagc_modconv_fwd(float* out, const float* x, const float* wp, con
   CAGC_REQUIRE(ksize == 1 || ksize == 3, "%s: ksize %d unsupported", what, ksize);
   CAGC_REQUIRE(epi == CAGC_EPI_LINEAR || epi == CAGC_EPI_STYLED, "%s: bad epilogue %d", what, epi);
   if (epi == CAGC_EPI_STYLED) {
-    CAGC_REQUIRE(bias && out_scale, "%s: styled epilogue needs bias and d", what);
+    CAGC_REQUIRE(bias, "%s: styled epilogue needs bias", what);   // d (out_scale) may be null: plain conv + bias + act
     CAGC_REQUIRE(!noise || (noise_w && (noise_batch == 1 || noise_batch == B)), "%s: bad noise arguments", what);
   }
   ConvArgs a;

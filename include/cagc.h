@@ -127,7 +127,7 @@ int cagc_modconv_prep(float* wp_fwd, float* wp_bwd, float* wsq, const float* wei
 
 /* Plain (stride-1, "same") modulated conv, k = 3 or 1.
  *   x [B,Cin,H,W], wp = wp_fwd, s [B,Cin] [nullable = all ones], out [B,Cout,H,W].
- *   epi = CAGC_EPI_LINEAR: out_scale [B,Cout] [nullable];  CAGC_EPI_STYLED: out_scale = d (required),
+ *   epi = CAGC_EPI_LINEAR: out_scale [B,Cout] [nullable];  CAGC_EPI_STYLED: out_scale = d [nullable: un-demodulated],
  *   noise [noise_batch,1,H,W] with noise_batch in {1,B}, noise_w device scalar, bias [Cout].       */
 int cagc_modconv_fwd(float* out, const float* x, const float* wp, const float* s, int B, int Cin, int Cout,
                      int H, int W, int ksize, int epi, const float* out_scale, const float* noise,
