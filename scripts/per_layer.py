@@ -7,10 +7,11 @@ import bench
 from cagc import _lib, kd
 dev = torch.device("cuda")
 student, teacher, disc = kd.build_synthetic_workload(256, dev, seed=0)
-mask = kd.ellipse_mask(16, 256, dev)
+BS = int(os.environ.get("BS", "16"))
+mask = kd.ellipse_mask(BS, 256, dev)
 step = kd.KDStep(student, teacher, disc)
 rng = random.Random(0)
-for _ in range(2): step.sample_and_step(16, mask, rng, None)
+for _ in range(2): step.sample_and_step(BS, mask, rng, None)
 orig = _lib.call
 recs = []
 def timed(name, *args):
@@ -20,7 +21,7 @@ def timed(name, *args):
     recs.append((name, ints[:7], s, e, bench.conv_flops(name, args)))
 _lib.call = timed
 N = 3
-for _ in range(N): step.sample_and_step(16, mask, rng, None)
+for _ in range(N): step.sample_and_step(BS, mask, rng, None)
 torch.cuda.synchronize()
 agg = {}
 for name, key, s, e, fl in recs:
