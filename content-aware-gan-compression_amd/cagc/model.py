@@ -526,6 +526,7 @@ class ConvLayer(nn.Sequential):
 
     def _apply(self, fn, *a, **k):
         self._packed = None
+        self._packed_wino = None
         return super()._apply(fn, *a, **k)
 
     def _wino_weights(self, conv):
@@ -536,9 +537,11 @@ class ConvLayer(nn.Sequential):
         if w.requires_grad and need_bwd:
             return mc.pack_wino(w, conv.scale, False), bwd_pack()
         key = (w._version, w.data_ptr(), w.device)
-        if self._packed is None or self._packed[0] != key or (need_bwd and self._packed[1][1] is None):
-            self._packed = (key, (mc.pack_wino(w, conv.scale, False), bwd_pack() if need_bwd else None))
-        return self._packed[1]
+        c = getattr(self, "_packed_wino", None)   # own slot: the same layer may see Winograd-eligible and other sizes
+        if c is None or c[0] != key or (need_bwd and c[1][1] is None):
+            c = (key, (mc.pack_wino(w, conv.scale, False), bwd_pack() if need_bwd else None))
+            self._packed_wino = c
+        return c[1]
 
     def forward(self, input):
         # 3x3 stride-1 conv + FusedLeakyReLU as one Winograd MFMA kernel (>= 32 px feature maps)
@@ -547,12 +550,13 @@ class ConvLayer(nn.Sequential):
             conv, act = self[0], self[1]
             up_fwd, up_bwd = self._wino_weights(conv)
             return mc._Conv3x3Act.apply(input, conv.weight, act.bias, up_fwd, up_bwd, conv.scale)
-        # 1x1 conv + FusedLeakyReLU (the discriminator's from-RGB layer) as one implicit-GEMM launch
-        if (self._fused_1x1 and mc.use_hip(input) and input.dtype == torch.float32 and input.shape[3] % 4 == 0
-                and self[1].bias is not None and self[1].negative_slope == 0.2):
+        # 1x1 conv + FusedLeakyReLU (the discriminator's from-RGB layer), and the 3x3 ones too small for the Winograd tiling
+        # (4^2 .. 16^2), as one implicit-GEMM launch with the bias + LeakyReLU epilogue
+        if ((self._fused_1x1 or self._fused_s1) and mc.use_hip(input) and input.dtype == torch.float32
+                and input.shape[3] % 4 == 0 and self[1].bias is not None and self[1].negative_slope == 0.2):
             conv, act = self[0], self[1]
             wp_fwd, wp_bwd = self._packed_weights(conv)
-            return mc._Conv1x1Act.apply(input, conv.weight, act.bias, wp_fwd, wp_bwd, conv.scale)
+            return mc._ConvActDirect.apply(input, conv.weight, act.bias, wp_fwd, wp_bwd, conv.scale)
         # Blur -> 3x3 stride-2 conv as one op on the hand-written MFMA kernel (odd blurred size 2*Ho+1)
         if (self._fused_down and mc.use_hip(input) and input.dtype == torch.float32
                 and (input.shape[2] + sum(self[0].pad) - 3) % 2 == 1 and (input.shape[3] + sum(self[0].pad) - 3) % 2 == 1):

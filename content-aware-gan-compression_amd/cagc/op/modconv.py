@@ -323,19 +323,19 @@ class _Conv3x3Act(Function):
         return gx, gweight, gbias, None, None, None
 
 
-class _Conv1x1Act(Function):
-    """Discriminator input layer ConvLayer(3, C, 1) (reference model.py:756): EqualConv2d(1x1) -> FusedLeakyReLU as one
-    launch of the implicit-GEMM kernel with the bias + LeakyReLU epilogue (the op is bound by writing its output once;
-    the stock path writes it, re-reads it and writes it again, and goes through layout transposes)."""
+class _ConvActDirect(Function):
+    """Discriminator ConvLayer without down-sampling, k = 1 (the from-RGB layer, reference model.py:756) or k = 3 at sizes
+    the Winograd tiling does not cover (4^2 .. 16^2): EqualConv2d -> FusedLeakyReLU as one launch of the implicit-GEMM
+    kernel with the bias + LeakyReLU epilogue (no stock convolution left on the generator step's path)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, wp_fwd, wp_bwd, scale):
         x = x.contiguous()
         B, C, H, W = x.shape
-        cout = weight.shape[0]
+        cout, k = weight.shape[0], weight.shape[-1]
         out = torch.empty(B, cout, H, W, dtype=x.dtype, device=x.device)
         with _lib.on_device(x):
-            _lib.call("cagc_modconv_fwd", _lib.ptr(out), _lib.ptr(x), _lib.ptr(wp_fwd), None, B, C, cout, H, W, 1, EPI_STYLED,
+            _lib.call("cagc_modconv_fwd", _lib.ptr(out), _lib.ptr(x), _lib.ptr(wp_fwd), None, B, C, cout, H, W, k, EPI_STYLED,
                       None, None, 0, None, _lib.ptr(bias.detach().contiguous()), 0.2, SQRT2)
         ctx.save_for_backward(x if weight.requires_grad else x.new_empty(0), weight, out, wp_bwd)
         ctx.scale = scale
@@ -347,7 +347,7 @@ class _Conv1x1Act(Function):
     def backward(ctx, gout):
         x, weight, out, wp_bwd = ctx.saved_tensors
         B, C, H, W = ctx.x_shape
-        cout = weight.shape[0]
+        cout, k = weight.shape[0], weight.shape[-1]
         gout = gout.contiguous()
         gz = torch.empty_like(gout)
         gbias = torch.zeros(cout, dtype=gout.dtype, device=gout.device) if ctx.needs_input_grad[2] else None
@@ -357,11 +357,14 @@ class _Conv1x1Act(Function):
                       0.2, SQRT2)
             if ctx.needs_input_grad[0]:
                 if wp_bwd is None:
-                    raise RuntimeError("conv1x1_act: backward requested but the weights were packed forward-only")
+                    raise RuntimeError("conv_act: backward requested but the weights were packed forward-only")
                 gx = torch.empty(B, C, H, W, dtype=gout.dtype, device=gout.device)
-                _lib.call("cagc_modconv_dgrad", _lib.ptr(gx), None, _lib.ptr(gz), _lib.ptr(wp_bwd), None, None, B, C, cout, H, W, 1)
-            if ctx.needs_input_grad[1]:
-                gweight = (torch.einsum("bop,bip->oi", gz.reshape(B, cout, -1), x.reshape(B, C, -1)) * ctx.scale).reshape(weight.shape)
+                _lib.call("cagc_modconv_dgrad", _lib.ptr(gx), None, _lib.ptr(gz), _lib.ptr(wp_bwd), None, None, B, C, cout, H, W, k)
+            if ctx.needs_input_grad[1]:   # D training step (not on the KD generator step): stock kernels
+                if k == 1:
+                    gweight = (torch.einsum("bop,bip->oi", gz.reshape(B, cout, -1), x.reshape(B, C, -1)) * ctx.scale).reshape(weight.shape)
+                else:
+                    gweight = torch.nn.grad.conv2d_weight(x, weight.shape, gz, padding=k // 2) * ctx.scale
         return gx, gweight, gbias, None, None, None
 
 
