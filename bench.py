@@ -59,6 +59,22 @@ def conv_flops(name, a):
     return 0.0
 
 
+def stream_bytes(name, a):
+    """Algorithmic HBM bytes (each element read / written once) of one launch of the streaming entry points."""
+    if name == "cagc_fused_bias_act_bwd":     # (gx,gbias,gout,out,outer,C,inner,...): read gout + out, write gx
+        return 12.0 * a[4] * a[5] * a[6]
+    if name == "cagc_fused_bias_act_fwd":     # (out,x,bias,outer,C,inner,...)
+        return 8.0 * a[3] * a[4] * a[5]
+    if name == "cagc_fir4x4_pitched":         # (out,x,k,planes,in_h,in_w,in_pitch,out_h,out_w,out_pitch,...)
+        return 4.0 * a[3] * (a[4] * a[5] + a[7] * a[8])
+    if name == "cagc_upfirdn2d":              # (out,x,k,planes,in_h,in_w,out_h,out_w,...)
+        return 4.0 * a[3] * (a[4] * a[5] + a[6] * a[7])
+    if name == "cagc_blur_up_fwd":            # (out,t,fir,d,noise,nb,nw,bias,B,C,H,W,...): 4 phase planes in, 2Hx2W out
+        B, C, H, W = a[8:12]
+        return 4.0 * B * C * (4 * (H + 1) * (W + 1) + 4 * H * W)
+    return 0.0
+
+
 # dominant-entry-point -> device symbol (for the PMC traffic lookup) and MFMA instruction
 KERNEL_OF = {"cagc_wino_conv3x3": "k_wino<4>", "cagc_modconv_fwd": "k_conv_igemm<8, 4, true, false, 1>",
              "cagc_modconv_up_fwd": "k_conv_igemm<8, 4, true, false, 1>",
@@ -104,7 +120,7 @@ class KernelTimer:
             s.record(st)
             self.orig(name, *args)
             e.record(st)
-            self.records.append((name, s, e, conv_flops(name, args)))
+            self.records.append((name, s, e, conv_flops(name, args), stream_bytes(name, args)))
         self.lib_mod.call = timed
         return self
 
@@ -114,11 +130,12 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, s, e, fl in self.records:
-            d = agg.setdefault(name, [0, 0.0, 0.0])
+        for name, s, e, fl, by in self.records:
+            d = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e)
             d[2] += fl
+            d[3] += by
         return agg
 
 
@@ -237,7 +254,7 @@ def main():
         agg = kt.summary()
         if rank == 0:
             mfma = {k: v for k, v in agg.items() if v[2] > 0}
-            name, (cnt, tot_ms, flops) = max(mfma.items(), key=lambda kv: kv[1][1])
+            name, (cnt, tot_ms, flops, _) = max(mfma.items(), key=lambda kv: kv[1][1])
             ach = flops / (tot_ms * 1e-3) / 1e12
             sym = KERNEL_OF.get(name, name)
             traffic, traffic_note = pmc_traffic(sym)
@@ -252,6 +269,12 @@ def main():
                     "all_mfma_entry_points": {k: {"ms_per_step": round(v[1] / 3, 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
                                               for k, v in sorted(mfma.items(), key=lambda kv: -kv[1][1])},
                     "cagc_kernel_ms_per_step": {k: round(v[1] / 3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+            hbm = {k: v for k, v in agg.items() if v[3] > 0}
+            if hbm:   # secondary: the HBM-bound streaming kernels against the 8 TB/s HBM3E peak (SURVEY 8-d "report both")
+                roof["hbm_bound_entry_points"] = {
+                    k: {"ms_per_step": round(v[1] / 3, 3), "achieved_GBps": round(v[3] / (v[1] * 1e-3) / 1e9, 1),
+                        "frac_of_8TBps": round(v[3] / (v[1] * 1e-3) / 8e12, 3)}
+                    for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])}
     full = None
     if world == 1 and args.full_iteration and not args.no_full_iteration:
         # secondary figure: the WHOLE training iteration of train.py:371-398 — D step + G/KD step + lazy
