@@ -265,13 +265,14 @@ __global__ __launch_bounds__(256) void k_fir4_vec(float* __restrict__ out, const
                                                   const float* __restrict__ kern, int in_h, int in_w, int in_pitch,
                                                   int out_h, int out_w, int out_pitch, int pad_x0, int pad_y0,
                                                   int tiles_x, int tiles_y) {
-  constexpr int IH = FT + 3, Q = (FT + 8) / 4, LW = FT + 8 + 1;   // 35 rows x 10 float4; odd row stride
+  constexpr int FTH = 2 * FT;                                      // 64 output rows per workgroup: more loads in flight
+  constexpr int IH = FTH + 3, Q = (FT + 8) / 4, LW = FT + 8 + 1;   // 67 rows x 10 float4; odd row stride
   __shared__ float tile[IH * LW];
   __shared__ float kf[16];
   int bid = blockIdx.x;
   const int tx0 = (bid % tiles_x) * FT;
   bid /= tiles_x;
-  const int ty0 = (bid % tiles_y) * FT;
+  const int ty0 = (bid % tiles_y) * FTH;
   const int64_t p = bid / tiles_y;
   const float* xp = x + p * (int64_t)in_h * in_pitch;
   if (threadIdx.x < 16) kf[threadIdx.x] = kern[(3 - threadIdx.x / 4) * 4 + (3 - threadIdx.x % 4)];
@@ -291,24 +292,30 @@ __global__ __launch_bounds__(256) void k_fir4_vec(float* __restrict__ out, const
     t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
   }
   __syncthreads();
-  const int cg = threadIdx.x & 7, row = threadIdx.x >> 3;
-  const int oy = ty0 + row, ox = tx0 + 4 * cg;
-  if (oy >= out_h || ox >= out_pitch) return;
-  const float* w0 = tile + row * LW + (4 - pad_x0) + 4 * cg;   // LDS col 0 <-> global col tx0 - 4
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int cg = threadIdx.x & 7;
+  const int ox = tx0 + 4 * cg;
+  if (ox >= out_pitch) return;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float w[7];
+  for (int half = 0; half < 2; ++half) {
+    const int row = (threadIdx.x >> 3) + 32 * half;
+    const int oy = ty0 + row;
+    if (oy >= out_h) continue;
+    const float* w0 = tile + row * LW + (4 - pad_x0) + 4 * cg;   // LDS col 0 <-> global col tx0 - 4
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) w[j] = w0[i * LW + j];
+    for (int i = 0; i < 4; ++i) {
+      float w[7];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float k = kf[i * 4 + j];
-      a0 += w[j] * k; a1 += w[j + 1] * k; a2 += w[j + 2] * k; a3 += w[j + 3] * k;
+      for (int j = 0; j < 7; ++j) w[j] = w0[i * LW + j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float k = kf[i * 4 + j];
+        a0 += w[j] * k; a1 += w[j + 1] * k; a2 += w[j + 2] * k; a3 += w[j + 3] * k;
+      }
     }
+    float4 o = make_float4(ox < out_w ? a0 : 0.f, ox + 1 < out_w ? a1 : 0.f, ox + 2 < out_w ? a2 : 0.f, ox + 3 < out_w ? a3 : 0.f);
+    *reinterpret_cast<float4*>(out + (p * out_h + oy) * (int64_t)out_pitch + ox) = o;   // pitch padding written as zero
   }
-  float4 o = make_float4(ox < out_w ? a0 : 0.f, ox + 1 < out_w ? a1 : 0.f, ox + 2 < out_w ? a2 : 0.f, ox + 3 < out_w ? a3 : 0.f);
-  *reinterpret_cast<float4*>(out + (p * out_h + oy) * (int64_t)out_pitch + ox) = o;   // pitch padding written as zero
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -521,9 +528,11 @@ extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, i
     const int tx = cdiv(out_w, FT), ty = cdiv(out_h, FT);
     const int64_t nb = planes * tx * ty;
     CAGC_REQUIRE(nb < (1ll << 31), "cagc_upfirdn2d: too large");
-    if (in_w % 4 == 0 && out_w % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0)
-      hipLaunchKernelGGL(k_fir4_vec, dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w, out_h, out_w, out_w,
-                         pad_x0, pad_y0, tx, ty);
+    if (in_w % 4 == 0 && out_w % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0) {
+      const int ty2 = cdiv(out_h, 2 * FT);
+      hipLaunchKernelGGL(k_fir4_vec, dim3((unsigned)(planes * tx * ty2)), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w, out_h,
+                         out_w, out_w, pad_x0, pad_y0, tx, ty2);
+    }
     else
       hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w, out_h, out_w,
                          out_w, pad_x0, pad_y0, tx, ty);
@@ -594,9 +603,11 @@ extern "C" int cagc_fir4x4_pitched(float* out, const float* x, const float* kern
   const int tx = cdiv(out_pitch, FT), ty = cdiv(out_h, FT);
   const int64_t nb = planes * tx * ty;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_fir4x4_pitched: too large");
-  if (in_pitch % 4 == 0 && out_pitch % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0)
-    hipLaunchKernelGGL(k_fir4_vec, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, x, kernel, in_h, in_w, in_pitch,
-                       out_h, out_w, out_pitch, pad_x0, pad_y0, tx, ty);
+  if (in_pitch % 4 == 0 && out_pitch % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0) {
+    const int ty2 = cdiv(out_h, 2 * FT);
+    hipLaunchKernelGGL(k_fir4_vec, dim3((unsigned)(planes * tx * ty2)), dim3(256), 0, as_stream(stream), out, x, kernel, in_h,
+                       in_w, in_pitch, out_h, out_w, out_pitch, pad_x0, pad_y0, tx, ty2);
+  }
   else
     hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, x, kernel, in_h, in_w,
                        in_pitch, out_h, out_w, out_pitch, pad_x0, pad_y0, tx, ty);
