@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--no-full-iteration", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--sweep", type=int, default=0, help="also time N bs-64 batches of the prune.py saliency sweep (config 5)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches + DDP instead of HIP-graph replay")
+    ap.add_argument("--graph", action="store_true", help="force HIP-graph replay (default: calibrate — a few untimed steps "
+                                                         "of each mode on copies of the models, keep the faster)")
     args = ap.parse_args()
 
     from cagc import _lib, distributed as cd, kd
@@ -211,6 +213,37 @@ def main():
     torch.cuda.manual_seed(1234 + rank)
     mode = "graph"
     step = None
+    calib = None
+    if not args.no_graph and not args.graph:
+        # Launch-mode calibration (untimed, before the warm-up): the same step either replayed as HIP graphs or launched
+        # eagerly (teacher on its own stream, DDP buckets overlapping backward).  Which one wins depends on the per-GPU
+        # batch and on the host CPU; both compute the same thing (tests/test_gpu_parity.py::test_graphed_kd_step...).
+        import copy
+        try:
+            tg = {}
+            for m in ("graph", "eager"):
+                s2 = copy.deepcopy(student)
+                if m == "graph":
+                    st2 = kd.GraphedKDStep(s2, teacher, disc, bs, mask, random_noise=True, world_size=world)
+                else:
+                    st2 = kd.KDStep(cd.wrap_student(s2, dev), teacher, disc)
+                for _ in range(3):
+                    st2.sample_and_step(bs, mask, rng, gen)
+                cd.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(8):
+                    st2.sample_and_step(bs, mask, rng, gen)
+                torch.cuda.synchronize()
+                tg[m] = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+                if world > 1:
+                    dist.all_reduce(tg[m], op=dist.ReduceOp.MAX)
+                del st2, s2
+            calib = {m: round(v.item() / 8 * 1e3, 3) for m, v in tg.items()}
+            args.no_graph = calib["eager"] < calib["graph"]      # identical on every rank (MAX-reduced)
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001 — calibration is an optimisation only
+            print(f"[bench] launch-mode calibration failed ({type(e).__name__}: {e}); using HIP-graph replay", file=sys.stderr)
     if not args.no_graph:
         try:     # HIP-graph replay of the step; gradients all-reduced as one flat RCCL collective between graphs
             step = kd.GraphedKDStep(student, teacher, disc, bs, mask, random_noise=True, world_size=world)
@@ -246,12 +279,14 @@ def main():
     if not args.no_roofline:
         # per-kernel HIP-event timing needs individual launches: same models, eager launches (no graph), no DDP
         prof_step = step if mode == "eager" else kd.KDStep(student, teacher, disc)
+        overlap_saved, kd.OVERLAP_TEACHER = kd.OVERLAP_TEACHER, False   # one stream: kernels are timed in isolation
         for _ in range(2):
             prof_step.sample_and_step(bs, mask, rng, None)
         with KernelTimer(_lib) as kt:
             for _ in range(3):
                 prof_step.sample_and_step(bs, mask, rng, None)
         agg = kt.summary()
+        kd.OVERLAP_TEACHER = overlap_saved
         if rank == 0:
             mfma = {k: v for k, v in agg.items() if v[2] > 0}
             name, (cnt, tot_ms, flops, _) = max(mfma.items(), key=lambda kv: kv[1][1])
@@ -327,7 +362,7 @@ def main():
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "256px StyleGAN2 70%-pruned student [154x10,77,77,39,39] + full teacher KD generator step, "
                                       "global bs16 (configs[1]); frozen D fwd+dgrad, masked-L1 KD, Adam; LPIPS/BiSeNet off",
-                          "global_batch": GLOBAL_BATCH, "per_gpu_batch": bs, "parallelism": f"dp{world}", "launch_mode": mode,
+                          "global_batch": GLOBAL_BATCH, "per_gpu_batch": bs, "parallelism": f"dp{world}", "launch_mode": mode, "launch_mode_calibration_ms": calib,
                           "student_params": n_params},
                "roofline": roof, "cpu_baseline": cpu, "full_iteration": full, "saliency_sweep": sweep}
         print(json.dumps(out))

@@ -7,6 +7,7 @@ all-reduce over RCCL is the path's only collective.  The content mask is supplie
 (the reference derives it from BiSeNet, whose weights are not available offline) and
 LPIPS is off (`kd_lpips_lambda = 0`, weights unobtainable offline) — both stated in DESIGN.md."""
 import math
+import os
 import random
 
 import torch
@@ -45,6 +46,9 @@ def ellipse_mask(batch, size, device, coverage=0.6):
     return m.reshape(1, 1, size, size).repeat(batch, 1, 1, 1).to(device)
 
 
+OVERLAP_TEACHER = os.environ.get("CAGC_OVERLAP_TEACHER", "1") == "1"
+
+
 class KDStep:
     """student / teacher / discriminator + Adam, with `g_step` = one G_Loss_BackProp."""
 
@@ -66,11 +70,28 @@ class KDStep:
         self.n_latent = (student.module if hasattr(student, "module") else student).n_latent
 
     def g_losses(self, zs, inject_index, mask, student_noise=None, teacher_noise=None):
+        # The frozen teacher's forward is independent of the student / discriminator chain until the distillation loss:
+        # on the GPU it runs on its own HIP stream, so its launches fill the CUs that the student's narrow (154/77/39
+        # channel) and low-resolution layers leave idle, and kernel tails of one chain overlap the other.  Works eagerly
+        # and under HIP-graph capture (fork / join become graph dependencies).
+        overlap = mask.is_cuda and OVERLAP_TEACHER
+        if overlap:
+            main = torch.cuda.current_stream()
+            if getattr(self, "_teacher_stream", None) is None:
+                self._teacher_stream = torch.cuda.Stream()
+            side = self._teacher_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                teacher_img = self.teacher(zs, return_rgb_list=True, inject_index=inject_index, noise=teacher_noise)[-1]
         fake_list = self.student(zs, return_rgb_list=True, inject_index=inject_index, noise=student_noise)
         fake_img = fake_list[-1]
         g_loss = g_nonsaturating_loss(self.disc(fake_img))
-        with torch.no_grad():
-            teacher_img = self.teacher(zs, return_rgb_list=True, inject_index=inject_index, noise=teacher_noise)[-1]
+        if overlap:
+            main.wait_stream(side)
+            teacher_img.record_stream(main)
+        else:
+            with torch.no_grad():
+                teacher_img = self.teacher(zs, return_rgb_list=True, inject_index=inject_index, noise=teacher_noise)[-1]
         kd_l1 = self.kd_l1_lambda * mc.masked_l1(fake_img, teacher_img, mask)
         return g_loss, kd_l1, fake_img
 
