@@ -49,6 +49,9 @@ _PROTOS = {
     "cagc_masked_l1": [_p, _p, _p, _p, _p, _i, _i, _i64, _f, _p],
     "cagc_add_scale": [_p, _p, _p, _i64, _f, _p],
     "cagc_scale_reduce": [_p, _p, _p, _p, _i, _i, _i64, _p],
+    "cagc_parsing_input": [_p, _p, _i, _i, _i, _f, _p, _p, _p],
+    "cagc_content_mask_workspace": [_i, _i],
+    "cagc_content_mask": [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
 }
 _RESTYPES = {
     "cagc_last_error": ctypes.c_char_p,
@@ -56,6 +59,7 @@ _RESTYPES = {
     "cagc_modconv_packed_elems": _i64,
     "cagc_modconv_wgrad_workspace": _i64,
     "cagc_wino_packed_elems": _i64,
+    "cagc_content_mask_workspace": _i64,
 }
 EXPORTS = tuple(_PROTOS)
 

@@ -13,6 +13,7 @@ import random
 import torch
 from torch.nn import functional as F
 
+from . import content_mask
 from . import model as M
 from . import prune
 from .op import modconv as mc
@@ -53,9 +54,18 @@ class KDStep:
     """student / teacher / discriminator + Adam, with `g_step` = one G_Loss_BackProp."""
 
     def __init__(self, student, teacher, discriminator, lr=0.002, g_reg_every=4, kd_l1_lambda=3.0, mixing=0.9,
-                 latent=512, fused_adam=None):
+                 latent=512, fused_adam=None, parsing_net=None, kd_mode="Output_Only", percept_loss=None,
+                 kd_lpips_lambda=3.0, lpips_image_size=256):
+        """parsing_net: callable image-batch -> 19-class logits [B,19,512,512] (or a tuple starting with them, BiSeNet's
+        convention).  When given, the content mask is derived on device from the TEACHER's image every step
+        (cagc.content_mask, reference train.py:155-158) and the `mask` argument of the step functions may be None.
+        kd_mode: 'Output_Only' | 'Intermediate' (train.py:163-169).  percept_loss: optional callable (LPIPS in the
+        reference, train.py:173-182; its weights are not obtainable offline, so it is a hook, off by default)."""
+        assert kd_mode in ("Output_Only", "Intermediate")
         self.student, self.teacher, self.disc = student, teacher, discriminator
         self.kd_l1_lambda, self.mixing, self.latent = kd_l1_lambda, mixing, latent
+        self.parsing_net, self.kd_mode = parsing_net, kd_mode
+        self.percept_loss, self.kd_lpips_lambda, self.lpips_image_size = percept_loss, kd_lpips_lambda, lpips_image_size
         self.teacher.eval()
         requires_grad(self.teacher, False)
         c = g_reg_every / (g_reg_every + 1)                      # lazy-regularisation correction, train.py:528-532
@@ -74,25 +84,53 @@ class KDStep:
         # on the GPU it runs on its own HIP stream, so its launches fill the CUs that the student's narrow (154/77/39
         # channel) and low-resolution layers leave idle, and kernel tails of one chain overlap the other.  Works eagerly
         # and under HIP-graph capture (fork / join become graph dependencies).
-        overlap = mask.is_cuda and OVERLAP_TEACHER
+        overlap = zs[0].is_cuda and OVERLAP_TEACHER
+
+        def run_teacher():
+            with torch.no_grad():
+                t_list = self.teacher(zs, return_rgb_list=True, inject_index=inject_index, noise=teacher_noise)
+                m = mask
+                if self.parsing_net is not None:     # on-device content mask from the teacher's image (train.py:155-158)
+                    m = content_mask.teacher_content_mask(t_list[-1], self.parsing_net)
+            return t_list, m
+
         if overlap:
             main = torch.cuda.current_stream()
             if getattr(self, "_teacher_stream", None) is None:
                 self._teacher_stream = torch.cuda.Stream()
             side = self._teacher_stream
             side.wait_stream(main)
-            with torch.cuda.stream(side), torch.no_grad():
-                teacher_img = self.teacher(zs, return_rgb_list=True, inject_index=inject_index, noise=teacher_noise)[-1]
+            with torch.cuda.stream(side):
+                teacher_list, mask = run_teacher()
         fake_list = self.student(zs, return_rgb_list=True, inject_index=inject_index, noise=student_noise)
         fake_img = fake_list[-1]
         g_loss = g_nonsaturating_loss(self.disc(fake_img))
         if overlap:
             main.wait_stream(side)
-            teacher_img.record_stream(main)
+            for t in teacher_list:
+                t.record_stream(main)
+            if torch.is_tensor(mask):
+                mask.record_stream(main)
         else:
-            with torch.no_grad():
-                teacher_img = self.teacher(zs, return_rgb_list=True, inject_index=inject_index, noise=teacher_noise)[-1]
-        kd_l1 = self.kd_l1_lambda * mc.masked_l1(fake_img, teacher_img, mask)
+            teacher_list, mask = run_teacher()
+        teacher_img = teacher_list[-1]
+        if self.kd_mode == "Output_Only":
+            kd_l1 = self.kd_l1_lambda * mc.masked_l1(fake_img, teacher_img, mask)
+        else:
+            # 'Intermediate' (train.py:165-169): L1 over EVERY resolution's RGB output.  As in the reference the lists hold
+            # the un-masked images — its masked copies only feed the Output_Only and LPIPS terms.
+            kd_l1 = self.kd_l1_lambda * sum(torch.mean(torch.abs(t - s)) for t, s in zip(teacher_list, fake_list))
+        if self.percept_loss is not None:
+            # LPIPS hook (train.py:173-182): masked student vs masked teacher, pooled to `lpips_image_size` above it.  (In
+            # 'Intermediate' mode the reference's loop variable leaves the teacher un-masked here; reproduced.)
+            s_in = fake_img * mask if mask is not None else fake_img
+            t_in = teacher_img if (self.kd_mode == "Intermediate" or mask is None) else teacher_img * mask
+            if fake_img.shape[-1] > self.lpips_image_size:
+                size = (self.lpips_image_size, self.lpips_image_size)
+                s_in = F.interpolate(s_in, size=size, mode="bilinear", align_corners=False)
+                t_in = F.interpolate(t_in, size=size, mode="bilinear", align_corners=False)
+            self.last_kd_lpips = self.kd_lpips_lambda * torch.mean(self.percept_loss(s_in, t_in))
+            kd_l1 = kd_l1 + self.last_kd_lpips          # second return value = the whole distillation term
         return g_loss, kd_l1, fake_img
 
     def g_step(self, zs, inject_index, mask, student_noise=None, teacher_noise=None):
@@ -103,6 +141,9 @@ class KDStep:
         self.optim.zero_grad(set_to_none=True)
         total.backward()
         self.optim.step()
+        if self.percept_loss is not None:
+            lp = self.last_kd_lpips.detach()
+            return {"g": g_loss.detach(), "kd_l1_loss": kd_l1.detach() - lp, "kd_lpips_loss": lp}
         return {"g": g_loss.detach(), "kd_l1_loss": kd_l1.detach()}
 
     def sample_and_step(self, batch, mask, rng=random, generator=None):
@@ -129,6 +170,7 @@ def accumulate(model_ema, model, decay=0.999):
     with torch.no_grad():
         torch._foreach_mul_(list(pe.values()), decay)
         torch._foreach_add_(list(pe.values()), [pm[k].detach() for k in pe], alpha=1 - decay)
+    M.invalidate_caches(model_ema)
 
 
 class TrainIteration(KDStep):
@@ -260,14 +302,31 @@ class GraphedKDStep(KDStep):
     def _capture(self):
         requires_grad(self.student, True)
         requires_grad(self.disc, False)
+        # The warm-up (allocator pools, lazy inits, Adam state creation) takes real optimiser steps: snapshot the
+        # student and restore it afterwards, so that capture leaves the weights / Adam moments / step counters exactly
+        # as it found them (and replicas that started identical stay identical — no collective runs in the warm-up).
+        params = [p for p in self.student.parameters()]
+        snap = [p.detach().clone() for p in params]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):          # warm-up: allocator pools, MIOpen solution selection, lazy inits
+        with torch.cuda.stream(side):
             for _ in range(3):
                 self._fwd_bwd()
                 self.optim.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            for p, s in zip(params, snap):
+                p.copy_(s)
+            for st in self.optim.state.values():     # in place: the captured Adam graph keeps these tensors
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            self.flat_grad.zero_()
+        if self.world > 1:                            # belt and braces: every replica starts from rank 0's weights
+            import torch.distributed as dist
+            for p in params:
+                dist.broadcast(p.data, src=0)
         self.graph_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_fb):
             self.losses = self._fwd_bwd()

@@ -87,7 +87,9 @@ class Blur(nn.Module):
 
 
 class EqualConv2d(nn.Module):
-    """reference model.py:99-134 (discriminator convs; stock F.conv2d -> MIOpen on the GPU)."""
+    """reference model.py:99-134.  Inside the discriminator's ConvLayer the convolution runs on the hand-written kernels
+    (ConvLayer.forward dispatches on the layer pattern); this module's own forward is the composed formulation used for
+    CPU tensors and for layer shapes no kernel covers."""
 
     def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
         super().__init__()
@@ -134,8 +136,11 @@ class EqualLinear(nn.Module):
 
     def forward(self, input):
         w, b = self.weight, self.bias
-        trainable = torch.is_grad_enabled() and (w.requires_grad or (b is not None and b.requires_grad))
-        if not trainable and not torch.jit.is_tracing():
+        # the cache is only for FROZEN layers (requires_grad False: teacher, D on the generator step).  A layer that
+        # merely runs under no_grad (g_ema sampling) is not cached: the reference's EMA updates weights through `.data`
+        # (train.py:129), which does not bump the version counter the cache is validated against.
+        frozen = not (w.requires_grad or (b is not None and b.requires_grad))
+        if frozen and not torch.jit.is_tracing():
             ws, bs = self._frozen_scaled()
             if self.activation:
                 return fused_leaky_relu(F.linear(input, ws), bs)
@@ -153,6 +158,17 @@ class EqualLinear(nn.Module):
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})"
+
+
+def invalidate_caches(module):
+    """Drop every cached packed / scaled weight below `module`.  The caches of FROZEN layers are validated against the
+    weight tensor's version counter and storage; an update that bypasses the counter (`param.data.mul_()`, a raw-pointer
+    write, a HIP-graph replay that rewrites a frozen weight) must be followed by this call.  `cagc.kd.accumulate` and
+    `load_checkpoint` call it; `load_state_dict` / optimiser steps bump the counter themselves."""
+    for m in module.modules():
+        for attr in ("_scaled", "_packed", "_wino", "_packed_wino"):
+            if getattr(m, attr, None) is not None:
+                setattr(m, attr, None)
 
 
 class ScaledLeakyReLU(nn.Module):
@@ -211,8 +227,8 @@ class ModulatedConv2d(nn.Module):
         use) are cached and re-validated against the tensor's version counter and storage."""
         w = self.weight
         need_bwd = torch.is_grad_enabled()
-        if w.requires_grad and need_bwd:
-            return mc.pack_weights(w, True)
+        if w.requires_grad:     # never cached, also under no_grad: `.data` updates (reference EMA) bypass `_version`
+            return mc.pack_weights(w, need_bwd)
         key = (w._version, w.data_ptr(), w.device)
         if self._packed is None or self._packed[0] != key or (need_bwd and self._packed[1][1] is None):
             self._packed = (key, mc.pack_weights(w, need_bwd))
@@ -224,7 +240,7 @@ class ModulatedConv2d(nn.Module):
         if self.upsample or self.downsample or self.kernel_size != 3 or not mc.wino_ok(H, W):
             return None
         w = self.weight
-        if w.requires_grad and torch.is_grad_enabled():
+        if w.requires_grad:
             return mc.pack_wino(w[0], self.scale, False)
         key = (w._version, w.data_ptr(), w.device)
         if getattr(self, "_wino", None) is None or self._wino[0] != key:
@@ -488,8 +504,9 @@ class Generator(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------------
-# Discriminator (reference model.py:670-798).  Its convolutions are stock F.conv2d (MIOpen); every Blur and
-# FusedLeakyReLU inside goes through the HIP upfirdn2d / fused-bias-act kernels.
+# Discriminator (reference model.py:670-798).  On the GPU every ConvLayer pattern the network uses is one fused op on
+# libcagc: 3x3 + FusedLeakyReLU (Winograd / direct MFMA), Blur -> 3x3 stride 2 (pitched FIR + stride-2 MFMA conv),
+# Blur -> 1x1 stride 2 skip (decimating FIR + 1x1 MFMA GEMM), from-RGB 1x1 + FusedLeakyReLU.
 # ---------------------------------------------------------------------------------------------------
 class ConvLayer(nn.Sequential):
     def __init__(self, in_channel, out_channel, kernel_size, downsample=False, blur_kernel=[1, 3, 3, 1], bias=True,
@@ -517,8 +534,8 @@ class ConvLayer(nn.Sequential):
     def _packed_weights(self, conv):
         w = conv.weight
         need_bwd = torch.is_grad_enabled()
-        if w.requires_grad and need_bwd:
-            return mc.pack_plain_weights(w, conv.scale, True)
+        if w.requires_grad:
+            return mc.pack_plain_weights(w, conv.scale, need_bwd)
         key = (w._version, w.data_ptr(), w.device)
         if self._packed is None or self._packed[0] != key or (need_bwd and self._packed[1][1] is None):
             self._packed = (key, mc.pack_plain_weights(w, conv.scale, need_bwd))
@@ -534,8 +551,8 @@ class ConvLayer(nn.Sequential):
         need_bwd = torch.is_grad_enabled()
         def bwd_pack():
             return mc.pack_wino(w, conv.scale, True) if mc.WINO_DGRAD else mc.pack_plain_weights(w, conv.scale, True)[1]
-        if w.requires_grad and need_bwd:
-            return mc.pack_wino(w, conv.scale, False), bwd_pack()
+        if w.requires_grad:
+            return mc.pack_wino(w, conv.scale, False), (bwd_pack() if need_bwd else None)
         key = (w._version, w.data_ptr(), w.device)
         c = getattr(self, "_packed_wino", None)   # own slot: the same layer may see Winograd-eligible and other sizes
         if c is None or c[0] != key or (need_bwd and c[1][1] is None):

@@ -31,17 +31,21 @@ SQRT2 = 2 ** 0.5
 # (F.conv2d, upfirdn2d, fused_leaky_relu) is twice differentiable.  Generator.forward(PPL_regularize=True)
 # enters it; the KD step (first order) never does.
 # ---------------------------------------------------------------------------------------------------
-_composed_depth = 0
+import threading
+
+_tls = threading.local()   # per thread: the reference's DataParallel drives one worker thread per device
 
 
 class composed_autograd:
     def __enter__(self):
-        global _composed_depth
-        _composed_depth += 1
+        _tls.depth = getattr(_tls, "depth", 0) + 1
 
     def __exit__(self, *a):
-        global _composed_depth
-        _composed_depth -= 1
+        _tls.depth -= 1
+
+
+def composed_active():
+    return getattr(_tls, "depth", 0) > 0
 
 
 _flip_cache = {}
@@ -60,7 +64,7 @@ def _flipped(fir):
 
 
 def use_hip(t):
-    return t.is_cuda and _composed_depth == 0
+    return t.is_cuda and not composed_active()
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -239,7 +243,16 @@ class _ModConv(Function):
                 gweight = torch.empty(1, cout, cin, k, k, dtype=x.dtype, device=dev)
                 _lib.call("cagc_modconv_wgrad", _lib.ptr(gweight), _lib.ptr(ws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(s), B, cin,
                           cout, H, W, k, up, 1.0 / math.sqrt(cin * k * k))
-        return (gx if need_x else None, gweight, gs, gd, None, g_nw, g_bias, None, None, None, None, None, None, None)
+        g_noise = None
+        if styled and noise is not None and ctx.needs_input_grad[4]:
+            # d out / d noise = noise_weight * gpre, summed over channels (and over the batch for a shared [1,1,H,W] map);
+            # gz = d * gpre, so gpre is recovered per channel.  Only a caller that optimises the noise maps (a projector)
+            # ever asks for it — not on the KD step.
+            gpre = gz / d[:, :, None, None] if d is not None else gz
+            g_noise = noise_w * gpre.sum(1, keepdim=True)
+            if noise.shape[0] == 1 and B > 1:
+                g_noise = g_noise.sum(0, keepdim=True)
+        return (gx if need_x else None, gweight, gs, gd, g_noise, g_nw, g_bias, None, None, None, None, None, None, None)
 
 
 def modconv_composed(x, weight, s, demodulate, upsample, downsample, blur_kernel, blur_pad):
@@ -570,8 +583,16 @@ class _MaskedL1(Function):
     def forward(ctx, student, teacher, mask):
         s = student.contiguous()
         t = teacher.contiguous()
-        m = mask.contiguous()
         B, C, H, W = s.shape
+        # the kernel indexes the mask as [B,1,H,W]; anything broadcastable to that is expanded first
+        m = mask.to(device=s.device, dtype=s.dtype)
+        if m.dim() == 3:
+            m = m.unsqueeze(1)
+        if tuple(m.shape) != (B, 1, H, W):
+            if m.dim() != 4 or m.shape[1] != 1:
+                raise ValueError(f"masked_l1: mask must broadcast to [B,1,H,W] = {(B, 1, H, W)}, got {tuple(mask.shape)}")
+            m = m.expand(B, 1, H, W)
+        m = m.contiguous()
         acc = torch.zeros(1, dtype=s.dtype, device=s.device)
         gs = torch.empty_like(s)
         n = s.numel()
@@ -588,6 +609,7 @@ class _MaskedL1(Function):
 
 
 def masked_l1(student, teacher, mask):
-    if use_hip(student) and student.dtype == torch.float32:
+    one_channel = (mask.dim() == 3) or (mask.dim() == 4 and mask.shape[1] == 1)
+    if use_hip(student) and student.dtype == torch.float32 and one_channel and not mask.requires_grad:
         return _MaskedL1.apply(student, teacher.detach(), mask)
     return torch.mean(torch.abs(teacher.detach() * mask - student * mask))

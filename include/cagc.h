@@ -239,6 +239,24 @@ int cagc_torgb_bwd(float* gx, float* gws, const float* g, const float* x, const 
 int cagc_masked_l1(float* loss_sum, float* gs, const float* t, const float* s, const float* mask, int B,
                    int C, int64_t HW, float coef, cagc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * On-device content mask            replaces Batch_Img_Parsing + the mask half of Get_Masked_Tensor
+ *                                   (Util/content_aware_pruning.py:61-88 and :102-107), which go through
+ *                                   the host (`.type(torch.FloatTensor)`) every step.
+ * cagc_parsing_input: img [B,3,S,S] in [-1,1] -> out [B,3,P,P] = (resize(clamp((img+1)/2,0,1)) - mean[c]) / std[c],
+ *   bilinear, align_corners = False, `scale` = 1/scale_factor = S/P as torch computes it (:74-82).  mean3 / std3 are
+ *   HOST pointers to 3 floats (the ImageNet constants of :70-71).
+ * cagc_content_mask: parsing logits [B,NC,P,P] -> argmax over classes (first maximum wins, :87) ->
+ *   keep = (cls > 0) && (cls != excl_class) (:102; excl_class = 16) -> bilinear resize to SxS (`scale` = P/S, :104-106)
+ *   -> > 0.5 -> mask [B,1,S,S] of {0,1} floats (:107).  Integer / dyadic arithmetic: bit-identical to the reference.
+ *   workspace: cagc_content_mask_workspace(B,P) floats (one byte per parsing pixel), caller-allocated.
+ * ---------------------------------------------------------------------------------------------- */
+int cagc_parsing_input(float* out, const float* img, int B, int S, int P, float scale, const float* mean3,
+                       const float* std3, cagc_stream_t stream);
+int64_t cagc_content_mask_workspace(int B, int P);
+int cagc_content_mask(float* mask, float* workspace, const float* logits, int B, int NC, int P, int S, float scale,
+                      int excl_class, cagc_stream_t stream);
+
 /* Close a modulated conv's data gradient computed WITHOUT the style scaling (e.g. by cagc_wino_conv3x3 on dgrad-packed
  * weights): gs[b,c] += sum_p gx[b,c,p] * x[b,c,p]  (gs nullable), then gx[b,c,p] *= s[b,c]  (s nullable).  One pass. */
 int cagc_scale_reduce(float* gx, const float* x, const float* s, float* gs, int B, int C, int64_t HW,

@@ -633,8 +633,108 @@ def gold_saliency():
     save("saliency_tiny", **out)
 
 
+# ----------------------------------------------------------------------------------------------
+# 10. content mask: the reference's own Batch_Img_Parsing + Get_Masked_Tensor (Util/content_aware_pruning.py:61-117)
+#     around a stand-in parsing net (BiSeNet's weights are not obtainable offline).  The logits are regenerated on the
+#     test side from oracle/synth.py (integer hashing: machine independent); only their checksum is stored.
+# ----------------------------------------------------------------------------------------------
+def gold_content_mask():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import synth
+    out = {}
+    B = 2
+    logits = torch.from_numpy(synth.parsing_logits(B, 512, 19, seed=1))
+    out["logits_checksum"] = np.array([float(logits.double().sum()), float(logits.double().abs().sum())])
+    for S in (32, 256, 1024):
+        img = torch.from_numpy(synth.hash01((B, 3, S, S), seed=100 + S) * np.float32(2.6) - np.float32(1.3))   # exceeds [-1,1]: clamp matters
+        seen = {}
+
+        def net(x):
+            seen["x"] = x.detach().clone()
+            return (logits,)
+
+        parsing = Batch_Img_Parsing(img, net, "cpu")                        # :61-88
+        ones = torch.ones(B, 3, S, S)
+        masked = Get_Masked_Tensor(ones, parsing, "cpu", mask_grad=False)    # :90-117  (img * mask, img = 1)
+        mask = masked[:, 0]
+        assert torch.equal(masked[:, 1], mask) and set(np.unique(mask.numpy())) <= {0.0, 1.0}
+        out[f"S{S}/parse_in_sub"] = seen["x"][:, :, ::7, ::5]
+        out[f"S{S}/parse_in_sum"] = np.array([float(seen["x"].double().sum()), float(seen["x"].double().abs().sum())])
+        out[f"S{S}/mask_bits"] = np.packbits(mask.numpy().astype(np.uint8).reshape(-1))
+        out[f"S{S}/mask_sum"] = np.int64(mask.sum().item())
+    out["parsing_sum"] = np.array([int(parsing.sum()), int((parsing * torch.arange(512)[None, None, :]).sum())], dtype=np.int64)
+    # the batch-1 case Get_Masked_Tensor cannot run (its .squeeze() drops the batch axis, App. D-5) is covered by
+    # batch independence on the test side
+    save("content_mask", **out)
+
+
+# ----------------------------------------------------------------------------------------------
+# 11. KD loss variants: kd_mode='Intermediate' (train.py:165-169) and the LPIPS term's data flow (train.py:173-182) with a
+#     stand-in perceptual distance (LPIPS weights are not obtainable offline) — same models as gold_kd_step
+# ----------------------------------------------------------------------------------------------
+def gold_kd_modes():
+    B = 4
+    yy, xx = torch.meshgrid(torch.arange(512), torch.arange(512), indexing="ij")
+    cls = torch.zeros(B, 512, 512, dtype=torch.long)
+    for i in range(B):
+        r = ((yy - 256 - 10 * i) / 200.0) ** 2 + ((xx - 256 + 7 * i) / 150.0) ** 2
+        cls[i][r < 1.0] = 1 + i
+        cls[i][(yy > 440)] = 16
+    logits = F.one_hot(cls, 19).permute(0, 3, 1, 2).float()
+    percept = lambda a, b: ((a - b) ** 2).mean(dim=[1, 2, 3])     # stand-in for lpips.PerceptualLoss: [B] distances
+    out = {}
+    for mode, with_percept in (("Intermediate", False), ("Intermediate", True), ("Output_Only", True)):
+        student = make_tiny_generator(300, shape=[5, 5, 4, 4, 3, 3, 2, 2])
+        teacher = make_tiny_generator(301)
+        teacher.eval()
+        for p in teacher.parameters():
+            p.requires_grad = False
+        torch.manual_seed(302)
+        disc = ref_model.Discriminator(TINY["size"])
+        ns = dict(torch=torch, F=F, autograd=autograd, random=random, device="cpu",
+                  Batch_Img_Parsing=Batch_Img_Parsing, Get_Masked_Tensor=Get_Masked_Tensor,
+                  train_hyperparams=types.SimpleNamespace(LPIPS_IMAGE_SIZE=256))
+        lift_train_functions(["requires_grad", "KD_loss", "g_nonsaturating_loss", "make_noise",
+                              "index_aware_mixing_noise", "G_Loss_BackProp", "Downsample_Image_256"], ns)
+        args = types.SimpleNamespace(batch_size=B, latent=TINY["style_dim"], mixing=0.9, n_latent=student.n_latent,
+                                     kd_mode=mode, kd_l1_lambda=3, kd_lpips_lambda=3, size=TINY["size"])
+        lr, c = 0.002, 4 / 5
+        g_optim = torch.optim.Adam(student.parameters(), lr=lr * c, betas=(0.0 ** c, 0.99 ** c))
+        rec = RecordingNoise()
+        captured = {}
+        orig_fwd = ref_model.Generator.forward
+
+        def capturing_forward(self, noise_z, *a, **k):
+            captured.setdefault("calls", []).append(([t.detach().clone() for t in noise_z], k.get("inject_index")))
+            return orig_fwd(self, noise_z, *a, **k)
+
+        tag = f"{mode}{'_percept' if with_percept else ''}/"
+        with mock.patch.object(ref_model.NoiseInjection, "forward", lambda self, image, noise=None: rec(self, image, noise)), \
+                mock.patch.object(ref_model.Generator, "forward", capturing_forward):
+            random.seed(400)
+            torch.manual_seed(500)
+            loss_dict = {}
+            ns["G_Loss_BackProp"](student, disc, args, "cpu", loss_dict, g_optim, teacher, percept if with_percept else None,
+                                  lambda x: (logits,))
+        (zs, inj), _ = captured["calls"]
+        nl = student.num_layers
+        out[tag + "n_z"] = np.int64(len(zs))
+        for i, z in enumerate(zs):
+            out[tag + f"z{i}"] = z
+        out[tag + "inject_index"] = np.int64(-1 if inj is None else inj)
+        for i in range(nl):
+            out[tag + f"student_noise{i}"] = rec.log[i]
+            out[tag + f"teacher_noise{i}"] = rec.log[nl + i]
+        for k in ("g", "kd_l1_loss", "kd_lpips_loss"):
+            out[tag + k] = loss_dict[k]
+        for n, prm in student.named_parameters():
+            out[tag + "grad/" + n] = prm.grad.detach().clone()
+    out["d_seed"] = np.int64(302)
+    save("kd_modes_tiny", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fused_act", "upfirdn2d", "modconv", "generator", "kd_step", "discriminator", "contract", "train_iter", "saliency"]
+    which = sys.argv[1:] or ["kd_modes", "fused_act", "upfirdn2d", "modconv", "generator", "kd_step", "discriminator", "contract", "train_iter", "saliency", "content_mask"]
     for w in which:
         print("==", w)
         globals()["gold_" + w]()

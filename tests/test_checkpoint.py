@@ -1,0 +1,139 @@
+"""checkpoint dict / filename convention (train.py:443-452,538-543) and — in the build container,
+where the reference is mounted — its FID / PPL generator loops (Evaluation/fid.py:19-38, Evaluation/ppl.py:33-70) and
+`Build_Generator_From_Dict` driving the PRODUCT classes unchanged."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cagc.model as M
+from cagc import checkpoint as ck
+from cagc import kd
+
+REF = "/root/reference"
+
+
+def _tiny():
+    torch.manual_seed(0)
+    g = M.Generator(32, 24, 2, generator_net_shape=[5, 5, 4, 4, 3, 3, 2, 2])
+    g_ema = M.Generator(32, 24, 2, generator_net_shape=[5, 5, 4, 4, 3, 3, 2, 2])
+    t = M.Generator(32, 24, 2, generator_net_shape=[11, 11, 7, 7, 5, 5, 3, 3])
+    d = M.Discriminator(32)
+    return g, g_ema, t, d
+
+
+def test_save_resume_round_trip(tmp_path):
+    g, g_ema, t, d = _tiny()
+    kd.accumulate(g_ema, g, 0)
+    it = kd.TrainIteration(g, t, d, g_ema=g_ema, latent=24)
+    real = torch.rand(2, 3, 32, 32) * 2 - 1
+    mask = kd.ellipse_mask(2, 32, "cpu")
+    rng = __import__("random").Random(1)
+    gen = torch.Generator().manual_seed(2)
+    it.iteration(1, real, mask, rng, gen)
+    path = ck.save_checkpoint(str(tmp_path), 1234, g, d, g_ema, it.optim, it.d_optim)
+    assert os.path.basename(path) == "001234.pt" and ck.iteration_from_filename(path) == 1234
+    raw = torch.load(path)
+    assert tuple(raw) == ck.KEYS                                            # train.py:443-452 key set and order
+    assert list(raw["g"]) == list(g.state_dict()) and list(raw["d"]) == list(d.state_dict())
+    # resume (train.py:484-489, 538-543)
+    st = ck.load_checkpoint(path, size=32, latent=24, n_mlp=2)
+    assert st["generator"].load_report == {"missing": [], "unexpected": []}
+    it2 = kd.TrainIteration(st["generator"], t, st["discriminator"], g_ema=st["g_ema"], latent=24)
+    st2 = ck.load_checkpoint(path, size=32, latent=24, n_mlp=2, g_optim=it2.optim, d_optim=it2.d_optim, load_train_state=True)
+    assert st2["start_iter"] == 1235
+    for a, b in zip(g.state_dict().values(), st["generator"].state_dict().values()):
+        assert torch.equal(a, b)
+    # the next iteration from the resumed state == the next iteration of the uninterrupted run
+    for trainer in (it, it2):
+        trainer_rng = __import__("random").Random(7)
+        trainer_gen = torch.Generator().manual_seed(8)
+        torch.manual_seed(9)
+        trainer.iteration(2, real, mask, trainer_rng, trainer_gen)
+    for (k, a), b in zip(it.student.state_dict().items(), it2.student.state_dict().values()):
+        assert torch.allclose(a, b, rtol=0, atol=0), k
+    for a, b in zip(it.disc.state_dict().values(), it2.disc.state_dict().values()):
+        assert torch.equal(a, b)
+    for a, b in zip(it.g_ema.state_dict().values(), it2.g_ema.state_dict().values()):
+        assert torch.equal(a, b)
+
+
+def test_prune_style_checkpoint_without_optimizer_state(tmp_path):
+    g, g_ema, t, d = _tiny()
+    path = str(tmp_path / "content_aware_pruned.pth")
+    torch.save({"g": g.state_dict(), "d": d.state_dict(), "g_ema": g.state_dict()}, path)     # prune.py:60-64
+    st = ck.load_checkpoint(path, size=32, latent=24, n_mlp=2)
+    assert st["start_iter"] == 0 and isinstance(st["generator"], M.Generator)
+
+
+def test_ema_through_data_updates_is_seen_by_the_next_forward():
+    """The reference's EMA writes through `.data` (train.py:129), which bypasses the version counter: g_ema (trainable
+    flags on, run under no_grad) must never serve stale cached weights."""
+    torch.manual_seed(1)
+    lin = M.EqualLinear(8, 8)
+    x = torch.randn(2, 8)
+    with torch.no_grad():
+        a = lin(x)
+        lin.weight.data.mul_(0.5)
+        b = lin(x)
+    assert not torch.allclose(a, b)
+    for p in lin.parameters():
+        p.requires_grad = False
+    with torch.no_grad():
+        a = lin(x)
+        lin.weight.data.mul_(0.5)          # frozen layer + .data write: documented to need invalidate_caches
+        M.invalidate_caches(lin)
+        b = lin(x)
+    assert not torch.allclose(a, b)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "Evaluation")), reason="reference checkout not mounted")
+def test_reference_fid_and_ppl_generator_loops_drive_the_product(tmp_path):
+    import model as product_model
+    assert "content-aware-gan-compression_amd" in product_model.__file__
+    saved = dict(sys.modules)
+    stubs = {}
+    for name in ("torchvision", "torchvision.utils", "torchvision.transforms", "torchvision.models", "PIL", "PIL.Image", "lpips",
+                 "tqdm", "scipy", "scipy.linalg"):
+        if name not in sys.modules:
+            stubs[name] = types.ModuleType(name)
+    if "tqdm" in stubs:
+        stubs["tqdm"].tqdm = lambda x, *a, **k: x
+    calc = types.ModuleType("Evaluation.calc_inception")      # needs torchvision's inception: not part of the generator loop
+    calc.load_patched_inception_v3 = lambda: None
+    sys.modules.update(stubs)
+    sys.path.append(REF)
+    try:
+        import Evaluation
+        sys.modules["Evaluation.calc_inception"] = calc
+        from Evaluation import fid, ppl
+        from Util import network_util
+        g, g_ema, t, d = _tiny()
+        path = ck.save_checkpoint(str(tmp_path), 7, g, d, g_ema)
+        raw = torch.load(path)
+        ref_built = network_util.Build_Generator_From_Dict(raw["g_ema"], size=32, latent=24, n_mlp=2)   # reference code, product class
+        assert isinstance(ref_built, M.Generator)
+
+        class FakeInception(torch.nn.Module):
+            def forward(self, img):
+                return (img.mean([2, 3]),)
+
+        torch.manual_seed(3)
+        # fid.py:19-38 draws latents of width 512 — use a style_dim-512 tiny generator for this loop
+        g512 = M.Generator(32, 512, 2, generator_net_shape=[5, 5, 4, 4, 3, 3, 2, 2])
+        feats = fid.extract_feature_from_samples(g512, FakeInception(), 1, None, 3, 7, "cpu")
+        assert tuple(feats.shape) == (7, 3) and torch.isfinite(feats).all()
+        mean_latent = g512.mean_latent(16)
+        feats_t = fid.extract_feature_from_samples(g512, FakeInception(), 0.7, mean_latent, 4, 8, "cpu")
+        assert tuple(feats_t.shape) == (8, 3)
+        # ppl.py:33-70
+        img = ppl.Generate_Interpolated_Image(ref_built, batch_size=3, eps=1e-4, device="cpu", latent_dim=24)
+        assert tuple(img.shape) == (6, 3, 32, 32) and torch.isfinite(img).all()
+    finally:
+        sys.path.remove(REF)
+        for k in list(sys.modules):
+            if k not in saved:
+                del sys.modules[k]

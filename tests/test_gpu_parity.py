@@ -430,13 +430,13 @@ def test_graphed_kd_step_matches_eager_step():
     eager = kd.KDStep(se, te, de, latent=24)
     B = g["mask"].shape[0]
     graphed = kd.GraphedKDStep(sg, tg, dg, B, cu(g["mask"]), random_noise=False, latent=24)
-    with torch.no_grad():                                      # undo the capture warm-up steps
-        for k, v in sub(g, "student_sd/").items():
-            dict(sg.state_dict())[k].copy_(cu(v))
-        for st_ in graphed.optim.state.values():
-            for v in st_.values():
-                if torch.is_tensor(v):
-                    v.zero_()
+    # capture (incl. its warm-up steps) must leave the student and the Adam state untouched
+    for k, v in sub(g, "student_sd/").items():
+        assert torch.equal(dict(sg.state_dict())[k].cpu(), v), f"capture changed {k}"
+    for st_ in graphed.optim.state.values():
+        for v in st_.values():
+            if torch.is_tensor(v):
+                assert float(v.abs().sum()) == 0.0
     nl = se.num_layers
     for st in meta["steps"]:
         p = f"step{st['step']}/"

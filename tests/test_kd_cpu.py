@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -99,6 +100,42 @@ def _ddp_inputs(g, meta):
                 mask=(torch.rand(8, 1, 32, 32, generator=gen) > 0.4).float(),
                 sn=[torch.randn(8, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), generator=gen) for i in range(nl)],
                 tn=[torch.randn(8, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), generator=gen) for i in range(nl)])
+
+
+@pytest.mark.parametrize("tag", ["Intermediate", "Intermediate_percept", "Output_Only_percept"])
+def test_kd_modes_match_reference(tag):
+    """kd_mode='Intermediate' (train.py:165-169) and the LPIPS term's data flow (train.py:173-182, stand-in distance) vs
+    the reference's own G_Loss_BackProp / KD_loss, with the content mask derived by cagc.content_mask from the same
+    stand-in parsing logits the reference's Batch_Img_Parsing saw."""
+    import torch.nn.functional as F
+    g = load_npz("kd_modes_tiny")
+    base = load_npz("kd_step_tiny")
+    meta = load_json("kd_step_tiny_meta")
+    student, teacher, disc = _kd_objects(base, meta)
+    B = 4
+    yy, xx = torch.meshgrid(torch.arange(512), torch.arange(512), indexing="ij")
+    cls = torch.zeros(B, 512, 512, dtype=torch.long)
+    for i in range(B):
+        cls[i][((yy - 256 - 10 * i) / 200.0) ** 2 + ((xx - 256 + 7 * i) / 150.0) ** 2 < 1.0] = 1 + i
+        cls[i][(yy > 440)] = 16
+    logits = F.one_hot(cls, 19).permute(0, 3, 1, 2).float()
+    mode = "Intermediate" if tag.startswith("Intermediate") else "Output_Only"
+    percept = (lambda a, b: ((a - b) ** 2).mean(dim=[1, 2, 3])) if tag.endswith("percept") else None
+    step = kd.KDStep(student, teacher, disc, latent=24, parsing_net=lambda x: (logits,), kd_mode=mode, percept_loss=percept)
+    p = tag + "/"
+    nl = student.num_layers
+    n_z = int(g[p + "n_z"])
+    inj = int(g[p + "inject_index"])
+    losses = step.g_step([g[p + f"z{i}"] for i in range(n_z)], None if inj < 0 else inj, None,
+                         student_noise=[g[p + f"student_noise{i}"] for i in range(nl)],
+                         teacher_noise=[g[p + f"teacher_noise{i}"] for i in range(nl)])
+    assert abs(losses["g"].item() - float(g[p + "g"])) < 3e-5
+    assert abs(losses["kd_l1_loss"].item() - float(g[p + "kd_l1_loss"])) < 3e-5 * max(1.0, abs(float(g[p + "kd_l1_loss"])))
+    if percept is not None:
+        assert abs(losses["kd_lpips_loss"].item() - float(g[p + "kd_lpips_loss"])) < 3e-5
+    params = dict(student.named_parameters())
+    for k, v in sub(g, p + "grad/").items():
+        assert_close(params[k].grad, v, 3e-4 if v.numel() > 1 else 3e-3, f"{tag} grad {k}")
 
 
 def _ddp_worker(rank, world, port, tmp):
