@@ -49,6 +49,7 @@ _PROTOS = {
     "cagc_masked_l1": [_p, _p, _p, _p, _p, _i, _i, _i64, _f, _p],
     "cagc_add_scale": [_p, _p, _p, _i64, _f, _p],
     "cagc_scale_reduce": [_p, _p, _p, _p, _i, _i, _i64, _p],
+    "cagc_to_phase_planar": [_p, _p, _i64, _i, _i, _i, _p],
     "cagc_parsing_input": [_p, _p, _i, _i, _i, _f, _p, _p, _p],
     "cagc_content_mask_workspace": [_i, _i],
     "cagc_content_mask": [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p],

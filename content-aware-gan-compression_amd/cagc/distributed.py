@@ -49,6 +49,19 @@ def wrap_student(student, device, bucket_cap_mb=4):
     return DDP(student, **kw)
 
 
+def wrap_discriminator(disc, device, bucket_cap_mb=25):
+    """DDP around D for the D step / R1 (28.9 M parameters = 115 MB all-reduce per D step; the
+    reference intended this at Miscellaneous/distributed.py:57-66).  Larger buckets than the student's: D's backward is
+    long enough to hide 25 MB rings, and fewer collectives matter more than early start."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return disc
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    kw = dict(broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+    if device.type == "cuda":
+        return DDP(disc, device_ids=[device.index], output_device=device.index, **kw)
+    return DDP(disc, **kw)
+
+
 def reduce_loss_dict(loss_dict):
     """Mean of each scalar over ranks, for logging (intent of Miscellaneous/distributed.py:104-126)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

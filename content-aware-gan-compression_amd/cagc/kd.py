@@ -63,6 +63,9 @@ class KDStep:
         reference, train.py:173-182; its weights are not obtainable offline, so it is a hook, off by default)."""
         assert kd_mode in ("Output_Only", "Intermediate")
         self.student, self.teacher, self.disc = student, teacher, discriminator
+        # frozen use of D (generator step): bypass a DistributedDataParallel wrapper — its reducer expects a gradient for
+        # every parameter of a forward it has seen, and D's parameters get none while frozen
+        self.disc_frozen = discriminator.module if hasattr(discriminator, "module") else discriminator
         self.kd_l1_lambda, self.mixing, self.latent = kd_l1_lambda, mixing, latent
         self.parsing_net, self.kd_mode = parsing_net, kd_mode
         self.percept_loss, self.kd_lpips_lambda, self.lpips_image_size = percept_loss, kd_lpips_lambda, lpips_image_size
@@ -104,7 +107,7 @@ class KDStep:
                 teacher_list, mask = run_teacher()
         fake_list = self.student(zs, return_rgb_list=True, inject_index=inject_index, noise=student_noise)
         fake_img = fake_list[-1]
-        g_loss = g_nonsaturating_loss(self.disc(fake_img))
+        g_loss = g_nonsaturating_loss(self.disc_frozen(fake_img))
         if overlap:
             main.wait_stream(side)
             for t in teacher_list:
@@ -196,7 +199,9 @@ class TrainIteration(KDStep):
     def d_step(self, real_img, zs, inject_index=None, noise=None):
         requires_grad(self.student, False)
         requires_grad(self.disc, True)
-        fake_img = self.student(zs, inject_index=inject_index, noise=noise)
+        with torch.no_grad():      # G is frozen here: nothing of its graph is needed (same values as the reference's :251)
+            fake_img = (self.student.module if hasattr(self.student, "module") else self.student)(
+                zs, inject_index=inject_index, noise=noise)
         fake_pred = self.disc(fake_img)
         real_pred = self.disc(real_img)
         d_loss = d_logistic_loss(real_pred, fake_pred)
@@ -208,11 +213,12 @@ class TrainIteration(KDStep):
     def d_reg(self, real_img):
         requires_grad(self.disc, True)
         real_img = real_img.detach().requires_grad_(True)
-        with mc.composed_autograd():
-            real_pred = self.disc(real_img)
-            r1_loss = d_r1_loss(real_pred, real_img)
-            self.d_optim.zero_grad(set_to_none=True)
-            (self.r1 / 2 * r1_loss * self.d_reg_every + 0 * real_pred[0]).backward()
+        # double backward through D: its fused ops build a differentiable backward under create_graph=True (closed conv
+        # family of op/conv_closure.py + the twice-differentiable upfirdn2d / fused-act ops) — all on libcagc
+        real_pred = self.disc(real_img)
+        r1_loss = d_r1_loss(real_pred, real_img)
+        self.d_optim.zero_grad(set_to_none=True)
+        (self.r1 / 2 * r1_loss * self.d_reg_every + 0 * real_pred[0]).backward()
         self.d_optim.step()
         return r1_loss.detach()
 

@@ -100,6 +100,11 @@ class EqualConv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
     def forward(self, input):
+        if input.is_cuda:
+            from .op import conv_closure as cc
+            if cc.supported(input, self.weight, self.stride, self.padding):
+                out = cc.conv2d(input, self.weight, self.scale, self.stride, self.padding)
+                return out if self.bias is None else out + self.bias.view(1, -1, 1, 1)
         return F.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
 
     def __repr__(self):
@@ -561,6 +566,11 @@ class ConvLayer(nn.Sequential):
         return c[1]
 
     def forward(self, input):
+        # Every fused op below builds a differentiable backward when autograd asks for one (create_graph=True — the
+        # reference's R1 step, train.py:194-200, runs on this class unchanged); `composed_autograd()` forces the composed
+        # formulation, whose convolution is the closed ConvF/ConvD/ConvW family on the same kernels.
+        if input.is_cuda and mc.composed_active():
+            return super().forward(input)
         # 3x3 stride-1 conv + FusedLeakyReLU as one Winograd MFMA kernel (>= 32 px feature maps)
         if (self._fused_s1 and mc.use_hip(input) and input.dtype == torch.float32 and mc.wino_ok(input.shape[2], input.shape[3])
                 and self[1].bias is not None and self[1].negative_slope == 0.2):

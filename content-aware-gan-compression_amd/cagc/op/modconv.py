@@ -258,9 +258,24 @@ class _ModConv(Function):
 def modconv_composed(x, weight, s, demodulate, upsample, downsample, blur_kernel, blur_pad):
     """Same mathematics from stock differentiable ops (CPU tensors; second-order mode on GPU)."""
     _, cout, cin, k, _ = weight.shape
-    w = weight[0] * (1.0 / math.sqrt(cin * k * k))
+    scale = 1.0 / math.sqrt(cin * k * k)
+    w = weight[0] * scale
     xs = x * s[:, :, None, None]
-    if upsample:
+    if x.is_cuda and x.dtype == torch.float32 and k in (1, 3):
+        # GPU tensors in composed mode (second-order autograd; ModulatedConv2d(downsample=True)): the convolution itself is
+        # the closed ConvF / ConvD / ConvW family on the MFMA kernels — differentiable to any order, no MIOpen
+        from . import conv_closure as cc
+        if upsample and k == 3:
+            y = upfirdn2d(cc.conv_transpose2d_s2(xs, weight[0].transpose(0, 1), scale), blur_kernel, pad=blur_pad)
+        elif downsample and k == 3:
+            xb = upfirdn2d(xs, blur_kernel, pad=blur_pad)
+            y = cc.conv2d(xb, weight[0], scale, stride=2, padding=0) if cc.supported(xb, weight[0], 2, 0) \
+                else F.conv2d(xb, w, stride=2, padding=0)
+        elif not upsample and not downsample:
+            y = cc.conv2d(xs, weight[0], scale, stride=1, padding=k // 2)
+        else:
+            raise RuntimeError("modulated conv: up/down-sampling needs a 3x3 kernel")
+    elif upsample:
         y = F.conv_transpose2d(xs, w.transpose(0, 1), stride=2, padding=0)
         y = upfirdn2d(y, blur_kernel, pad=blur_pad)
     elif downsample:
@@ -289,6 +304,19 @@ def pack_plain_weights(weight, scale, need_bwd):
     return wp_fwd, wp_bwd
 
 
+def _conv_act_graph_backward(ctx, gout, x, weight, out, mode, in_hw):
+    """Backward of conv(x, scale*w) -> + bias -> LeakyReLU*sqrt2 built from differentiable ops (create_graph=True):
+    the fused-act backward of op/fused_act.py and the closed conv family of op/conv_closure.py.  Returns (gx, gw, gbias)."""
+    from . import conv_closure as cc
+    from .fused_act import _LReLUBackward
+    gz, gbias = _LReLUBackward.apply(gout, out, True, 0.2, SQRT2)
+    gx = cc.ConvD.apply(gz, weight, mode, ctx.scale, in_hw) if ctx.needs_input_grad[0] else None
+    gw = None
+    if ctx.needs_input_grad[1]:
+        gw = cc.ConvW.apply(gz, x, mode, ctx.scale, weight.shape[-1])
+    return gx, gw, (gbias if ctx.needs_input_grad[2] else None)
+
+
 class _Conv3x3Act(Function):
     """Discriminator ConvLayer without down-sampling (reference model.py:694-716): EqualConv2d(3x3, padding 1, no
     conv bias) -> FusedLeakyReLU, as ONE Winograd MFMA kernel with the bias + LeakyReLU epilogue; backward = the fused
@@ -309,11 +337,12 @@ class _Conv3x3Act(Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gout):
         x, weight, out, up_bwd = ctx.saved_tensors
         B, C, H, W = ctx.x_shape
         cout = weight.shape[0]
+        if torch.is_grad_enabled():     # create_graph=True (R1, train.py:194-200): differentiable backward
+            return _conv_act_graph_backward(ctx, gout, x, weight, out, "s1", (H, W)) + (None, None, None)
         gout = gout.contiguous()
         gz = torch.empty_like(gout)
         gbias = torch.zeros(cout, dtype=gout.dtype, device=gout.device) if ctx.needs_input_grad[2] else None
@@ -331,8 +360,9 @@ class _Conv3x3Act(Function):
                 else:   # direct implicit GEMM (exact fp32 FMA chain) with the [tap][Cout][Cin] packing
                     _lib.call("cagc_modconv_dgrad", _lib.ptr(gx), None, _lib.ptr(gz), _lib.ptr(up_bwd), None, None, B, C, cout,
                               H, W, 3)
-            if ctx.needs_input_grad[1]:
-                gweight = torch.nn.grad.conv2d_weight(x, weight.shape, gz, padding=1) * ctx.scale   # D training: stock kernel
+            if ctx.needs_input_grad[1]:     # D training step: the un-modulated MFMA weight-gradient kernel
+                from . import conv_closure as cc
+                gweight = cc.wgrad_s1(gz, x, 3, ctx.scale)
         return gx, gweight, gbias, None, None, None
 
 
@@ -356,11 +386,12 @@ class _ConvActDirect(Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gout):
         x, weight, out, wp_bwd = ctx.saved_tensors
         B, C, H, W = ctx.x_shape
         cout, k = weight.shape[0], weight.shape[-1]
+        if torch.is_grad_enabled():
+            return _conv_act_graph_backward(ctx, gout, x, weight, out, "s1", (H, W)) + (None, None, None)
         gout = gout.contiguous()
         gz = torch.empty_like(gout)
         gbias = torch.zeros(cout, dtype=gout.dtype, device=gout.device) if ctx.needs_input_grad[2] else None
@@ -373,11 +404,9 @@ class _ConvActDirect(Function):
                     raise RuntimeError("conv_act: backward requested but the weights were packed forward-only")
                 gx = torch.empty(B, C, H, W, dtype=gout.dtype, device=gout.device)
                 _lib.call("cagc_modconv_dgrad", _lib.ptr(gx), None, _lib.ptr(gz), _lib.ptr(wp_bwd), None, None, B, C, cout, H, W, k)
-            if ctx.needs_input_grad[1]:   # D training step (not on the KD generator step): stock kernels
-                if k == 1:
-                    gweight = (torch.einsum("bop,bip->oi", gz.reshape(B, cout, -1), x.reshape(B, C, -1)) * ctx.scale).reshape(weight.shape)
-                else:
-                    gweight = torch.nn.grad.conv2d_weight(x, weight.shape, gz, padding=k // 2) * ctx.scale
+            if ctx.needs_input_grad[1]:   # D training step (not on the KD generator step)
+                from . import conv_closure as cc
+                gweight = cc.wgrad_s1(gz, x, k, ctx.scale)
         return gx, gweight, gbias, None, None, None
 
 
@@ -404,12 +433,21 @@ class _BlurConvS2(Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gout):
         x, weight, fir, wp_bwd = ctx.saved_tensors
         pad, scale, hb, wb, pitch = ctx.cfg
         B, C, H, W = ctx.x_shape
         cout = weight.shape[0]
+        if torch.is_grad_enabled():     # create_graph=True: the same maps as differentiable ops
+            from . import conv_closure as cc
+            gx = gweight = None
+            if ctx.needs_input_grad[0]:
+                gtmp = cc.ConvD.apply(gout, weight, "s2", scale, (hb, wb))
+                gp = 4 - pad[0] - 1
+                gx = upfirdn2d(gtmp, _flipped(fir), pad=(gp, gp))
+            if ctx.needs_input_grad[1]:
+                gweight = cc.ConvW.apply(gout, upfirdn2d(x, fir, pad=pad), "s2", scale, 3)
+            return gx, gweight, None, None, None, None, None
         gout = gout.contiguous()
         gx = gweight = None
         with _lib.on_device(gout):
@@ -423,9 +461,12 @@ class _BlurConvS2(Function):
                 _lib.call("cagc_fir4x4_pitched", _lib.ptr(gx), _lib.ptr(gtmp), _lib.ptr(_flipped(fir)),
                           B * C, hb, wb, pitch, H, W, W, gp, gp)
             if ctx.needs_input_grad[1]:
-                # weight gradient (discriminator training step — not on the KD generator step): stock kernel
-                xb = upfirdn2d(x, fir, pad=pad)
-                gweight = torch.nn.grad.conv2d_weight(xb, weight.shape, gout, stride=2) * scale
+                # weight gradient (discriminator training step — not on the KD generator step): re-blur into the pitched
+                # operand (cheaper than keeping it alive since forward), then the role-swapped transposed-conv wgrad
+                from . import conv_closure as cc
+                tmp = torch.empty(B, C, hb, pitch, dtype=gout.dtype, device=gout.device)
+                _lib.call("cagc_fir4x4_pitched", _lib.ptr(tmp), _lib.ptr(x), _lib.ptr(fir), B * C, H, W, W, hb, wb, pitch, pad[0], pad[0])
+                gweight = cc.wgrad_s2(gout, tmp, scale, in_pitch=pitch)
         return gx, gweight, None, None, None, None, None
 
 
@@ -448,18 +489,29 @@ class _BlurDownConv1x1(Function):
             _lib.call("cagc_modconv_fwd", _lib.ptr(out), _lib.ptr(y), _lib.ptr(wp_fwd), None, B, C, cout, ho, wo, 1, EPI_LINEAR,
                       None, None, 0, None, None, 0.2, 1.0)
         ctx.cfg = (pad, scale, ho, wo)
-        ctx.save_for_backward(y if weight.requires_grad else x.new_empty(0), weight, fir, wp_bwd)
+        # x (not the decimated y) is kept for the weight gradient: it is the ResBlock input that conv1 keeps alive anyway
+        ctx.save_for_backward(x if weight.requires_grad else x.new_empty(0), weight, fir, wp_bwd)
         ctx.x_shape = tuple(x.shape)
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gout):
-        from .upfirdn2d import _launch
-        y, weight, fir, wp_bwd = ctx.saved_tensors
+        from .upfirdn2d import _UpFirDn2d, _launch
+        x, weight, fir, wp_bwd = ctx.saved_tensors
         pad, scale, ho, wo = ctx.cfg
         B, C, H, W = ctx.x_shape
         cout = weight.shape[0]
+        p4 = (pad[0], pad[1], pad[0], pad[1])
+        gp = (4 - pad[0] - 1, W - 2 * wo + pad[0], 4 - pad[0] - 1, H - 2 * ho + pad[0])   # adjoint padding (x0, x1, y0, y1)
+        if torch.is_grad_enabled():     # create_graph=True
+            from . import conv_closure as cc
+            gx = gweight = None
+            if ctx.needs_input_grad[0]:
+                gy = cc.ConvD.apply(gout, weight, "s1", scale, (ho, wo))
+                gx = _UpFirDn2d.apply(gy, _flipped(fir), (2, 2), (1, 1), gp)
+            if ctx.needs_input_grad[1]:
+                gweight = cc.ConvW.apply(gout, _UpFirDn2d.apply(x, fir, (1, 1), (2, 2), p4), "s1", scale, 1)
+            return gx, gweight, None, None, None, None, None
         gout = gout.contiguous()
         gx = gweight = None
         if ctx.needs_input_grad[0]:
@@ -470,10 +522,11 @@ class _BlurDownConv1x1(Function):
                 _lib.call("cagc_modconv_dgrad", _lib.ptr(gy), None, _lib.ptr(gout), _lib.ptr(wp_bwd), None, None, B, C, cout,
                           ho, wo, 1)
             # adjoint of (up 1, down 2, pad p): up 2, down 1 with the flipped kernel (reference op/upfirdn2d.py:111-116)
-            gp = (4 - pad[0] - 1, W - 2 * wo + pad[0], 4 - pad[0] - 1, H - 2 * ho + pad[0])   # (x0, x1, y0, y1)
-            gx = _launch(gy, _flipped(fir), (2, 2), (1, 1), (gp[0], gp[1], gp[2], gp[3]), (H, W))
+            gx = _launch(gy, _flipped(fir), (2, 2), (1, 1), gp, (H, W))
         if ctx.needs_input_grad[1]:
-            gweight = (torch.einsum("bop,bip->oi", gout.reshape(B, cout, -1), y.reshape(B, C, -1)) * scale).reshape(weight.shape)
+            from . import conv_closure as cc
+            y = _launch(x, fir, (1, 1), (2, 2), p4, (ho, wo))
+            gweight = cc.wgrad_s1(gout, y, 1, scale)
         return gx, gweight, None, None, None, None, None
 
 

@@ -490,3 +490,39 @@ extern "C" int cagc_masked_l1(float* loss_sum, float* gs, const float* t, const 
                      HW, nchunk, coef);
   return check_launch("cagc_masked_l1");
 }
+
+// Phase-planar re-layout of an odd-sized plane stack: x [planes, 2H+1, 2W+1] (row pitch in_pitch) ->
+// t [planes, 4, H+1, P], t[pl, 2py+px, m, n] = x[pl, 2m+py, 2n+px] (zero outside; P = cagc_phase_pitch(W)).  Lets the
+// weight gradient of a stride-2 conv reuse the transposed-conv geometry of cagc_modconv_wgrad (operand roles swapped).
+namespace cagc {
+__global__ __launch_bounds__(256) void k_to_phase_planar(float* __restrict__ t, const float* __restrict__ x, int H, int W,
+                                                         int in_pitch, int P) {
+  const int n = blockIdx.x * 256 + threadIdx.x;      // column of the phase plane (incl. pitch padding)
+  const int m = blockIdx.y;                          // 0 .. H
+  const int64_t pl = blockIdx.z;
+  if (n >= P) return;
+  const float* src = x + pl * (int64_t)(2 * H + 1) * in_pitch;
+  float* dst = t + pl * 4 * (int64_t)(H + 1) * P + (int64_t)m * P + n;
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) {
+    const int Y = 2 * m + (ph >> 1), X = 2 * n + (ph & 1);
+    float v = 0.f;
+    if (Y <= 2 * H && X <= 2 * W && n <= W) v = src[(int64_t)Y * in_pitch + X];
+    dst[(int64_t)ph * (H + 1) * P] = v;
+  }
+}
+}  // namespace cagc
+extern "C" int cagc_to_phase_planar(float* t, const float* x, int64_t planes, int H, int W, int in_pitch,
+                                    cagc_stream_t stream) {
+  if (planes == 0) return CAGC_OK;
+  CAGC_REQUIRE(t && x && planes > 0 && H > 0 && W > 0 && in_pitch >= 2 * W + 1, "cagc_to_phase_planar: bad argument");
+  CAGC_REQUIRE(planes <= 65535 * 32 && H + 1 <= 65535, "cagc_to_phase_planar: grid too large");
+  const int P = cagc::round_up(W + 1, 4);
+  // blockIdx.z is limited to 65535: fold the plane count over several launches if needed
+  for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
+    const int np = (int)((planes - p0) < 65535 ? (planes - p0) : 65535);
+    hipLaunchKernelGGL(cagc::k_to_phase_planar, dim3(cagc::cdiv(P, 256), H + 1, np), dim3(256), 0, cagc::as_stream(stream),
+                       t + p0 * 4 * (int64_t)(H + 1) * P, x + p0 * (int64_t)(2 * H + 1) * in_pitch, H, W, in_pitch, P);
+  }
+  return cagc::check_launch("cagc_to_phase_planar");
+}

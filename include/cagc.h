@@ -262,6 +262,12 @@ int cagc_content_mask(float* mask, float* workspace, const float* logits, int B,
 int cagc_scale_reduce(float* gx, const float* x, const float* s, float* gs, int B, int C, int64_t HW,
                       cagc_stream_t stream);
 
+/* x [planes, 2H+1, 2W+1] (row pitch in_pitch floats) -> phase-planar t [planes, 4, H+1, cagc_phase_pitch(W)]:
+ * t[pl, 2*py+px, m, n] = x[pl, 2m+py, 2n+px], zero where that is outside x.  With it, the weight gradient of the
+ * discriminator's stride-2 3x3 conv (model.py:683-706; reference: cuDNN wgrad) is cagc_modconv_wgrad(up = 1) with the
+ * operand roles swapped: g := phase-planar blurred input, x := output gradient, result transposed [Cin,Cout,3,3]. */
+int cagc_to_phase_planar(float* t, const float* x, int64_t planes, int H, int W, int in_pitch, cagc_stream_t stream);
+
 /* out[i] = (a[i] + b[i]) * scale — ResBlock merge (conv path + skip) / sqrt(2) (model.py:736) in one pass. */
 int cagc_add_scale(float* out, const float* a, const float* b, int64_t n, float scale, cagc_stream_t stream);
 

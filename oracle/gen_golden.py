@@ -733,8 +733,112 @@ def gold_kd_modes():
     save("kd_modes_tiny", **out)
 
 
+# ----------------------------------------------------------------------------------------------
+# 12. float64 evaluations of the REFERENCE on the same inputs as the fp32 goldens above (discriminator32, generator_tiny
+#     case (b), kd_step_tiny step 0).  They settle whether a deviation of the HIP path from an fp32 golden is the HIP
+#     path's error or the fp32 reference's own rounding (LeakyReLU gate flips on random nets): tests assert
+#     HIP-vs-float64 <= max(1e-3, 3 x fp32-reference-vs-float64), the latter number stored here.
+# ----------------------------------------------------------------------------------------------
+def _rel(a, b):
+    den = b.abs().max().item()
+    return (a.double() - b).abs().max().item() / (den if den > 0 else 1.0)
+
+
+def gold_float64():
+    out = {}
+    # --- Discriminator(32): same seeds as gold_discriminator
+    torch.manual_seed(600)
+    disc = ref_model.Discriminator(TINY["size"])
+    g = torch.Generator().manual_seed(601)
+    x = torch.randn(4, 3, TINY["size"], TINY["size"], generator=g)
+    x32 = x.clone().requires_grad_(True)
+    y32 = disc(x32)
+    (gx32,) = autograd.grad(F.softplus(-y32).mean(), x32)
+    disc64 = ref_model.Discriminator(TINY["size"]).double()
+    disc64.load_state_dict({k: v.double() for k, v in disc.state_dict().items()})
+    x64 = x.double().requires_grad_(True)
+    y64 = disc64(x64)
+    (gx64,) = autograd.grad(F.softplus(-y64).mean(), x64)
+    out["d32/y"], out["d32/gx"] = y64, gx64
+    out["d32/fp32_err_y"], out["d32/fp32_err_gx"] = np.float64(_rel(y32, y64)), np.float64(_rel(gx32, gx64))
+    # --- tiny generator case (b): every parameter gradient of |img|.mean()
+    gnet = make_tiny_generator(200)
+    gtor = torch.Generator().manual_seed(201)
+    z0 = torch.randn(3, TINY["style_dim"], generator=gtor)
+    img32 = gnet([z0], randomize_noise=False)
+    gnet.zero_grad()
+    img32.abs().mean().backward()
+    g32 = {n: p.grad.clone() for n, p in gnet.named_parameters()}
+    gnet64 = make_tiny_generator(200).double()
+    gnet64.load_state_dict({k: v.double() for k, v in gnet.state_dict().items()})
+    img64 = gnet64([z0.double()], randomize_noise=False)
+    img64.abs().mean().backward()
+    out["gen/img"] = img64
+    out["gen/fp32_err_img"] = np.float64(_rel(img32, img64))
+    for n, p in gnet64.named_parameters():
+        out["gen/grad/" + n] = p.grad.clone()
+        out["gen/fp32_err/" + n] = np.float64(_rel(g32[n], p.grad))
+    # --- KD step 0 of gold_kd_step, replayed in float64 through the reference's own G_Loss_BackProp
+    with np.load(os.path.join(OUT, "kd_step_tiny.npz")) as z:
+        kd = {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
+    B = 4
+    student = make_tiny_generator(300, shape=[5, 5, 4, 4, 3, 3, 2, 2]).double()
+    teacher = make_tiny_generator(301).double()
+    teacher.eval()
+    for p in teacher.parameters():
+        p.requires_grad = False
+    for k, v in student.state_dict().items():
+        assert torch.equal(v.float(), kd["student_sd/" + k].float()), k
+    torch.manual_seed(302)
+    disc = ref_model.Discriminator(TINY["size"]).double()   # randn in float64 differs from the fp32 draw: copy the fp32 weights
+    torch.manual_seed(302)
+    d32 = ref_model.Discriminator(TINY["size"])
+    disc.load_state_dict({k: v.double() for k, v in d32.state_dict().items()})
+    yy, xx = torch.meshgrid(torch.arange(512), torch.arange(512), indexing="ij")
+    cls = torch.zeros(B, 512, 512, dtype=torch.long)
+    for i in range(B):
+        r = ((yy - 256 - 10 * i) / 200.0) ** 2 + ((xx - 256 + 7 * i) / 150.0) ** 2
+        cls[i][r < 1.0] = 1 + i
+        cls[i][(yy > 440)] = 16
+    logits = F.one_hot(cls, 19).permute(0, 3, 1, 2).double()
+    ns = dict(torch=torch, F=F, autograd=autograd, random=random, device="cpu",
+              Batch_Img_Parsing=Batch_Img_Parsing, Get_Masked_Tensor=_get_masked_tensor_any_dtype,
+              train_hyperparams=types.SimpleNamespace(LPIPS_IMAGE_SIZE=256))
+    lift_train_functions(["requires_grad", "KD_loss", "g_nonsaturating_loss", "make_noise",
+                          "index_aware_mixing_noise", "G_Loss_BackProp"], ns)
+    n_z = int(kd["step0/n_z"])
+    zs = [kd[f"step0/z{i}"].double() for i in range(n_z)]
+    inj = int(kd["step0/inject_index"])
+    ns["index_aware_mixing_noise"] = lambda *a, **k: (zs, None if inj < 0 else inj)     # replay the recorded draw
+    nl = student.num_layers
+    replay = [kd[f"step0/student_noise{i}"].double() for i in range(nl)] + [kd[f"step0/teacher_noise{i}"].double() for i in range(nl)]
+    it = iter(replay)
+    args = types.SimpleNamespace(batch_size=B, latent=TINY["style_dim"], mixing=0.9, n_latent=student.n_latent,
+                                 kd_mode="Output_Only", kd_l1_lambda=3, kd_lpips_lambda=3, size=TINY["size"])
+    c = 4 / 5
+    g_optim = torch.optim.SGD(student.parameters(), lr=0.0)     # gradients only: the update is not part of this fixture
+    loss_dict = {}
+    with mock.patch.object(ref_model.NoiseInjection, "forward", lambda self, image, noise=None: image + self.weight * next(it)):
+        ns["G_Loss_BackProp"](student, disc, args, "cpu", loss_dict, g_optim, teacher, None, lambda x: (logits,))
+    out["kd/g_loss"], out["kd/kd_l1_loss"] = loss_dict["g"], loss_dict["kd_l1_loss"]
+    out["kd/fp32_err_g_loss"] = np.float64(abs(float(kd["step0/g_loss"]) - loss_dict["g"].item()))
+    for n, prm in student.named_parameters():
+        out["kd/grad/" + n] = prm.grad.detach().clone()
+        out["kd/fp32_err/" + n] = np.float64(_rel(kd["step0/grad/" + n], prm.grad))
+    save("float64_refs", **out)
+    worst = max(float(v) for k, v in out.items() if "fp32_err" in k)
+    print("worst fp32-reference vs float64 deviation:", worst, "| D input grad:", float(out["d32/fp32_err_gx"]))
+
+
+def _get_masked_tensor_any_dtype(img_tensor, batch_parsing, device, mask_grad=False):
+    """Get_Masked_Tensor hard-codes torch.FloatTensor (Util/content_aware_pruning.py:104,107), which cannot multiply a
+    float64 image in place of `masked_img_tensor[i] = ...`'s dtype; same arithmetic, image dtype."""
+    masked = Get_Masked_Tensor(torch.ones_like(img_tensor, dtype=torch.float32), batch_parsing, device, mask_grad=False)
+    return img_tensor * masked.to(img_tensor.dtype)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kd_modes", "fused_act", "upfirdn2d", "modconv", "generator", "kd_step", "discriminator", "contract", "train_iter", "saliency", "content_mask"]
+    which = sys.argv[1:] or ["float64", "kd_modes", "fused_act", "upfirdn2d", "modconv", "generator", "kd_step", "discriminator", "contract", "train_iter", "saliency", "content_mask"]
     for w in which:
         print("==", w)
         globals()["gold_" + w]()

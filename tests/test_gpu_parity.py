@@ -241,6 +241,63 @@ def test_discriminator_golden():
     assert_close(gx, g["gx"], 3e-3, "D input grad")
 
 
+def _f64_bar(f64, key):
+    """Parity bar against a float64 evaluation of the REFERENCE (tests/golden/float64_refs.npz): the north-star 1e-3, or
+    three times the fp32 reference's own deviation from float64 where that is larger."""
+    return max(TOL, 3.0 * float(f64[key]))
+
+
+@pytest.mark.parametrize("wino_dgrad", [True, False])
+def test_discriminator_vs_float64_reference(wino_dgrad, monkeypatch):
+    """D(32) output and input gradient vs the reference evaluated in float64, with the stride-1 3x3 data gradients on
+    the Winograd kernel and on the direct implicit GEMM."""
+    from cagc.op import modconv as mc
+    monkeypatch.setattr(mc, "WINO_DGRAD", wino_dgrad)
+    g, f64 = load_npz("discriminator32"), load_npz("float64_refs")
+    d = M.Discriminator(32)
+    d.load_state_dict(ref_model.regenerate_state_dict(load_json("discriminator32_keys"), g["seed"]), strict=True)
+    d = d.to(DEV)
+    x = cu(g["x"]).requires_grad_(True)
+    y = d(x)
+    (gx,) = torch.autograd.grad(torch.nn.functional.softplus(-y).mean(), x)
+    assert_close(y, f64["d32/y"], _f64_bar(f64, "d32/fp32_err_y"), "D out vs float64")
+    assert_close(gx, f64["d32/gx"], _f64_bar(f64, "d32/fp32_err_gx"), f"D input grad vs float64 (wino_dgrad={wino_dgrad})")
+
+
+def test_tiny_generator_and_kd_step_vs_float64_reference():
+    f64 = load_npz("float64_refs")
+    g = load_npz("generator_tiny")
+    cfg = load_json("generator_tiny_keys")["config"]
+    gen = M.Generator(cfg["size"], cfg["style_dim"], cfg["n_mlp"], generator_net_shape=cfg["shape"])
+    gen.load_state_dict(sub(g, "sd/"), strict=True)
+    gen = gen.to(DEV)
+    img = gen([cu(g["z0"])], randomize_noise=False)
+    img.abs().mean().backward()
+    assert_close(img, f64["gen/img"], _f64_bar(f64, "gen/fp32_err_img"), "tiny G image vs float64")
+    for n, p in gen.named_parameters():
+        assert_close(p.grad, f64["gen/grad/" + n], _f64_bar(f64, "gen/fp32_err/" + n), "tiny G grad vs float64 " + n)
+    # KD step 0 (the reference's own G_Loss_BackProp replayed in float64)
+    kg = load_npz("kd_step_tiny")
+    meta = load_json("kd_step_tiny_meta")
+    student = M.Generator(32, 24, 2, generator_net_shape=meta["student_shape"])
+    student.load_state_dict(sub(kg, "student_sd/"), strict=True)
+    teacher = M.Generator(32, 24, 2, generator_net_shape=meta["teacher_shape"])
+    teacher.load_state_dict(sub(kg, "teacher_sd/"), strict=True)
+    disc = M.Discriminator(32)
+    disc.load_state_dict(ref_model.regenerate_state_dict(load_json("discriminator32_keys"), kg["d_seed"]), strict=True)
+    student, teacher, disc = student.to(DEV), teacher.to(DEV), disc.to(DEV)
+    step = kd.KDStep(student, teacher, disc, latent=24)
+    st = meta["steps"][0]
+    nl = student.num_layers
+    g_loss, kd_l1, _ = step.g_losses([cu(kg[f"step0/z{i}"]) for i in range(st["n_z"])], st["inject_index"], cu(kg["mask"]),
+                                     [cu(kg[f"step0/student_noise{i}"]) for i in range(nl)],
+                                     [cu(kg[f"step0/teacher_noise{i}"]) for i in range(nl)])
+    (g_loss + kd_l1).backward()
+    assert abs(g_loss.item() - float(f64["kd/g_loss"])) < 1e-4 and abs(kd_l1.item() - float(f64["kd/kd_l1_loss"])) < 1e-4
+    for n, p in student.named_parameters():
+        assert_close(p.grad, f64["kd/grad/" + n], _f64_bar(f64, "kd/fp32_err/" + n), "KD grad vs float64 " + n)
+
+
 def test_kd_step_golden_losses_grads_adam():
     g = load_npz("kd_step_tiny")
     meta = load_json("kd_step_tiny_meta")

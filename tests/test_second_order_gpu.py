@@ -1,0 +1,178 @@
+"""-m gpu: SURVEY §8-f row 1 on libcagc — the closed convolution family (op/conv_closure.py) that carries the second-order
+passes (R1, path length), the differentiable backward of the discriminator's fused ops, the discriminator's weight
+gradients on the MFMA wgrad kernel, ModulatedConv2d(downsample=True) (§8-a row 5), and the guarantee that a full training
+iteration never reaches a stock (MIOpen) convolution.  Truth = float64 PyTorch on the CPU / the oracle in float64."""
+from unittest import mock
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cagc.model as M
+from cagc import kd
+from cagc.op import conv_closure as cc
+from oracle import ref_model, ref_ops
+from _util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-3
+
+
+def cu(t):
+    return t.to(DEV)
+
+
+def _ref_conv(x, w, mode, scale):
+    if mode == "s1":
+        return F.conv2d(x, w * scale, padding=w.shape[-1] // 2)
+    return F.conv2d(x, w * scale, stride=2)
+
+
+@pytest.mark.parametrize("cfg", [("s1", 3, 2, 20, 36, 18, 20), ("s1", 1, 3, 7, 5, 9, 12), ("s2", 3, 2, 20, 36, 17, 21),
+                                 ("s1", 3, 2, 128, 256, 32, 32), ("s2", 3, 2, 128, 256, 65, 65), ("s1", 1, 2, 256, 128, 32, 32)])
+def test_conv_closure_family_to_second_order(cfg):
+    """F, its first derivatives (D, W) and the derivatives of those (F/W from D, F/D from W) against float64 autograd."""
+    mode, k, B, cin, cout, H, W = cfg
+    torch.manual_seed(1)
+    scale = 1.0 / (cin * k * k) ** 0.5
+    x, w = torch.randn(B, cin, H, W), torch.randn(cout, cin, k, k)
+    yr0 = _ref_conv(x.double(), w.double(), mode, scale)
+    r, u, v = torch.randn(yr0.shape), torch.randn(x.shape), torch.randn(w.shape)
+
+    def run(x, w, r, u, v, conv):
+        x, w, r = x.requires_grad_(True), w.requires_grad_(True), r.requires_grad_(True)
+        y = conv(x, w)
+        gx, gw = torch.autograd.grad((y * r).sum(), [x, w], create_graph=True)
+        second = torch.autograd.grad((gx * u).sum() + (gw * v).sum(), [x, w, r])
+        return [y, gx, gw] + list(second)
+
+    ref = run(x.double(), w.double(), r.double(), u.double(), v.double(), lambda a, b: _ref_conv(a, b, mode, scale))
+    got = run(cu(x), cu(w), cu(r), cu(u), cu(v), lambda a, b: cc.ConvF.apply(a, b, mode, scale))
+    for nm, a, b in zip(("y", "gx", "gw", "d2/dx", "d2/dw", "d2/dr"), got, ref):
+        assert_close(a, b, 2e-5, f"{cfg} {nm}")
+
+
+def test_transposed_conv_is_the_stride2_data_gradient():
+    torch.manual_seed(2)
+    x, wt = torch.randn(2, 12, 9, 11), torch.randn(12, 7, 3, 3)
+    ref = F.conv_transpose2d(x.double(), wt.double() * 0.3, stride=2)
+    assert_close(cc.conv_transpose2d_s2(cu(x), cu(wt), 0.3), ref, 2e-5, "conv_transpose2d")
+
+
+def _double_sd(m):
+    return {k: v.detach().double().cpu().clone() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("size,B", [(32, 4), (64, 2)])
+def test_discriminator_r1_double_backward_vs_float64_oracle(size, B):
+    """R1 (train.py:194-200, 264-278) through the product Discriminator's FUSED ops (differentiable backward under
+    create_graph=True) vs the oracle in float64: penalty value and the gradient of every parameter."""
+    torch.manual_seed(3)
+    disc = M.Discriminator(size)
+    with torch.no_grad():
+        for n, p in disc.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(0.1 * torch.randn_like(p))
+    sd = _double_sd(disc)
+    names = [n for n, _ in disc.named_parameters()]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    real = torch.rand(B, 3, size, size) * 2 - 1
+    xr = real.double().requires_grad_(True)
+    pred = ref_model.discriminator_forward_ref(sdr, xr)
+    (g,) = torch.autograd.grad(pred.sum(), xr, create_graph=True)
+    r1_ref = g.pow(2).reshape(B, -1).sum(1).mean()
+    gref = torch.autograd.grad(r1_ref, [leaves[k] for k in names], allow_unused=True)
+    dg = disc.to(DEV)
+    xg = cu(real).requires_grad_(True)
+    with mock.patch.object(F, "conv2d", side_effect=AssertionError("stock conv2d reached")), \
+            mock.patch.object(F, "conv_transpose2d", side_effect=AssertionError("stock conv_transpose2d reached")):
+        r1 = kd.d_r1_loss(dg(xg), xg)
+        r1.backward()
+    assert abs(r1.item() - r1_ref.item()) <= 1e-4 * abs(r1_ref.item())
+    params = dict(dg.named_parameters())
+    gmax = max(float(b.abs().max()) for b in gref if b is not None)
+    for k, b in zip(names, gref):
+        a = params[k].grad
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0, k
+            continue
+        # per tensor at the parity bar; R1's bias gradients exist only through the minibatch-stddev channel (1e-5 of the
+        # weight gradients, cancelling sums): absolute floor relative to the largest gradient of the net
+        err = (a.double().cpu() - b).abs().max().item()
+        assert err <= TOL * max(float(b.abs().max()), 1e-3 * gmax), f"R1 grad {k}: {err:.3e} vs max {float(b.abs().max()):.3e}"
+
+
+def test_discriminator_training_step_weight_gradients_on_hip():
+    """D step (train.py:241-262): every parameter gradient of the logistic loss vs the float64 oracle, with the stock
+    convolution entry points patched to raise (the weight gradients run on cagc_modconv_wgrad)."""
+    torch.manual_seed(4)
+    size, B = 64, 4
+    disc = M.Discriminator(size)
+    sd = _double_sd(disc)
+    names = [n for n, _ in disc.named_parameters()]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in names}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    real, fake = torch.rand(B, 3, size, size) * 2 - 1, torch.randn(B, 3, size, size)
+    loss_ref = F.softplus(-ref_model.discriminator_forward_ref(sdr, real.double())).mean() + \
+        F.softplus(ref_model.discriminator_forward_ref(sdr, fake.double())).mean()
+    gref = torch.autograd.grad(loss_ref, [leaves[k] for k in names])
+    dg = disc.to(DEV)
+    with mock.patch.object(F, "conv2d", side_effect=AssertionError("stock conv2d reached")), \
+            mock.patch.object(torch.nn.grad, "conv2d_weight", side_effect=AssertionError("stock conv2d_weight reached")), \
+            mock.patch.object(torch, "einsum", side_effect=AssertionError("einsum reached")):
+        loss = kd.d_logistic_loss(dg(cu(real)), dg(cu(fake)))
+        loss.backward()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5 * abs(loss_ref.item())
+    params = dict(dg.named_parameters())
+    for k, b in zip(names, gref):
+        assert_close(params[k].grad, b, TOL, "D step grad " + k)
+
+
+@pytest.mark.parametrize("cfg", [(2, 7, 5, 8, 8), (2, 77, 39, 16, 16), (1, 128, 64, 32, 32)])
+def test_modulated_conv_downsample_on_hip(cfg):
+    """ModulatedConv2d(downsample=True) (model.py:272-278; unreachable from G / D, API surface): blur on the FIR kernel,
+    stride-2 conv on cagc_conv3x3s2_fwd, all gradients through the closed conv family — vs the float64 oracle."""
+    B, cin, cout, H, W = cfg
+    torch.manual_seed(5)
+    m = M.ModulatedConv2d(cin, cout, 3, 32, downsample=True)
+    x, style = torch.randn(B, cin, H, W), torch.randn(B, 32)
+    wr = m.weight.detach().double().requires_grad_(True)
+    xr, sr = x.double().requires_grad_(True), style.double().requires_grad_(True)
+    yr, _ = ref_ops.modulated_conv2d_ref(xr, sr, wr, m.modulation.weight.detach().double(), m.modulation.bias.detach().double(),
+                                      demodulate=True, downsample=True)
+    go = torch.randn(yr.shape)
+    gr = torch.autograd.grad(yr, [xr, sr, wr], go.double())
+    mg = m.to(DEV)
+    xg, sg = cu(x).requires_grad_(True), cu(style).requires_grad_(True)
+    with mock.patch.object(F, "conv2d", side_effect=AssertionError("stock conv2d reached")):
+        yg = mg(xg, sg)
+        gg = torch.autograd.grad(yg, [xg, sg, mg.weight], cu(go))
+    assert_close(yg, yr, 2e-5, f"{cfg} out")
+    for nm, a, b in zip(("x", "style", "weight"), gg, gr):
+        assert_close(a, b, 1e-4, f"{cfg} grad {nm}")
+
+
+def test_full_training_iteration_never_reaches_a_stock_convolution():
+    """D step + R1 + G/KD step + path-length regulariser + EMA (cagc.kd.TrainIteration.iteration at it = 0: every lazy
+    branch fires) with F.conv2d / F.conv_transpose2d / conv2d_weight patched to raise: every convolution of the iteration,
+    first and second order, is a libcagc launch."""
+    import random
+    torch.manual_seed(6)
+    student = M.Generator(64, 32, 2, generator_net_shape=[24, 24, 20, 20, 16, 16, 12, 12, 8, 8]).to(DEV)
+    teacher = M.Generator(64, 32, 2, generator_net_shape=[40, 40, 32, 32, 24, 24, 16, 16, 12, 12]).to(DEV)
+    ema = M.Generator(64, 32, 2, generator_net_shape=[24, 24, 20, 20, 16, 16, 12, 12, 8, 8]).to(DEV)
+    disc = M.Discriminator(64).to(DEV)
+    it = kd.TrainIteration(student, teacher, disc, g_ema=ema, latent=32)
+    real = torch.rand(4, 3, 64, 64, device=DEV) * 2 - 1
+    mask = kd.ellipse_mask(4, 64, DEV)
+    boom = lambda name: mock.MagicMock(side_effect=AssertionError(name + " reached"))
+    with mock.patch.object(F, "conv2d", boom("F.conv2d")), mock.patch.object(F, "conv_transpose2d", boom("F.conv_transpose2d")), \
+            mock.patch.object(torch.nn.grad, "conv2d_weight", boom("conv2d_weight")), \
+            mock.patch.object(torch, "conv2d", boom("torch.conv2d")):
+        out = it.iteration(0, real, mask, random.Random(0), None)
+    torch.cuda.synchronize()
+    assert set(out) >= {"d", "r1", "g", "kd_l1_loss", "path"} and all(torch.isfinite(v).all() for v in out.values())

@@ -115,3 +115,73 @@ def test_oracle_full_iteration_pieces_match_reference():
     pl_loss, pl, mean, _ = ref_kd.path_reg_ref(post, zs, int(g["pl/inject_index"]), [g[f"pl/noise{i}"] for i in range(nl)], g["pl_noise"])
     assert_close(pl, g["pl/path_lengths"], 1e-4, "oracle path lengths")
     assert abs(pl_loss.item() - float(g["pl/path_loss"])) < 1e-5 and abs(mean.item() - float(g["pl/mean_path_length"])) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# DDP on D: D step + R1 on 2 gloo ranks == 1 rank on the concatenated batch.  Rank r gets samples
+# r::2, which keeps D's minibatch-stddev groups identical (model.py:784-790 groups sample j with j + B/4 ...).
+# ---------------------------------------------------------------------------------------------------
+def _dd_inputs():
+    gen = torch.Generator().manual_seed(77)
+    B = 8
+    real = torch.rand(B, 3, 32, 32, generator=gen) * 2 - 1
+    zs = [torch.randn(B, 24, generator=gen), torch.randn(B, 24, generator=gen)]
+    noise = [torch.randn(B, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), generator=gen) for i in range(7)]
+    return real, zs, noise
+
+
+def _dd_worker(rank, world, port, tmp):
+    import os
+    import sys
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from cagc import distributed as cd
+    torch.set_num_threads(2)
+    cd.init_from_env(backend="gloo")
+    g = load_npz("train_iter_tiny")
+    meta = load_json("train_iter_tiny_meta")
+    student, teacher, disc, ema = _objects(g, meta, "cpu")
+    it = kd.TrainIteration(student, teacher, cd.wrap_discriminator(disc, torch.device("cpu")), g_ema=ema, latent=24)
+    real, zs, noise = _dd_inputs()
+    sl = slice(rank, None, world)
+    # R1 first, on the identical initial weights: its gradients are then comparable at rounding level (after an optimiser
+    # step the replicas' weights differ in the last bits, which flips LeakyReLU gates of this random net)
+    r1 = it.d_reg(real[sl])
+    r1 = cd.reduce_loss_dict({"r1": r1})["r1"]
+    snap_g = {k: v.grad.detach().clone() for k, v in disc.named_parameters()}      # R1 gradients, averaged by DDP
+    it.d_step(real[sl], [z[sl] for z in zs], 3, noise=[n[sl] for n in noise])
+    snap = {k: v.detach().clone() for k, v in disc.named_parameters()}
+    snap_g2 = {k: v.grad.detach().clone() for k, v in disc.named_parameters()}
+    # the frozen-D generator step must bypass the DDP wrapper (no gradient reaches D's parameters there)
+    it.g_step([z[sl] for z in zs], 3, kd.ellipse_mask(4, 32, "cpu"), student_noise=[n[sl] for n in noise], teacher_noise=[n[sl] for n in noise])
+    it.d_step(real[sl], [z[sl] for z in zs], 3, noise=[n[sl] for n in noise])      # and DDP still works afterwards
+    if rank == 0:
+        torch.save({"d": snap, "g": snap_g, "g2": snap_g2, "r1": r1.item()}, tmp)
+    cd.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_discriminator_two_ranks_equal_one_rank(tmp_path):
+    import os
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path / "dd.pt")
+    port = 29900 + (os.getpid() % 90)
+    mp.spawn(_dd_worker, args=(2, port, tmp), nprocs=2, join=True)
+    got = torch.load(tmp)
+    g = load_npz("train_iter_tiny")
+    meta = load_json("train_iter_tiny_meta")
+    student, teacher, disc, ema = _objects(g, meta, "cpu")
+    it = kd.TrainIteration(student, teacher, disc, g_ema=ema, latent=24)
+    real, zs, noise = _dd_inputs()
+    r1 = it.d_reg(real)
+    assert abs(r1.item() - got["r1"]) < 1e-5 * max(1.0, abs(r1.item()))
+    gmax = max(float(v.grad.abs().max()) for v in disc.parameters())
+    for k, v in disc.named_parameters():
+        # bias gradients of R1 exist only through the minibatch-stddev channel (1e-5 of the weight gradients): absolute bound
+        err = (got["g"][k] - v.grad).abs().max().item()
+        assert err <= 1e-4 * max(float(v.grad.abs().max()), 1e-3 * gmax), f"DDP R1 grad {k}: {err:.3e}"
+    it.d_step(real, zs, 3, noise=noise)
+    for k, v in disc.named_parameters():
+        assert_close(got["g2"][k], v.grad, 5e-3, "DDP D-step grad " + k)   # after one Adam step: last-bit weight differences flip gates
+        # two Adam steps with beta1 = 0 (update = lr * g / sqrt(v)) amplify rounding-level gradient differences
+        assert_close(got["d"][k], v.detach(), 2e-3, "DDP D param " + k)
