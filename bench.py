@@ -89,8 +89,8 @@ def pmc_traffic(symbol):
     FETCH_SIZE reads 0.50x, WRITE_SIZE 1.00x of the true bytes): bytes = 2*FETCH + WRITE."""
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(ROOT, "profiles", f"r01_pmc_{c}.md")
-        if not os.path.exists(path):
+        path = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_{c}.md") for r in ("r02", "r01")) if os.path.exists(q)), None)
+        if path is None:
             return None, "no committed PMC summary"
         for line in open(path):
             cols = [x.strip() for x in line.split("|")]
@@ -99,7 +99,7 @@ def pmc_traffic(symbol):
     if len(vals) != 2:
         return None, "kernel not found in PMC summary"
     return int(2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]), (
-        f"avg HBM bytes/launch of {symbol} from the committed rocprofv3 --pmc passes (profiles/r01_pmc_*.md): "
+        f"avg HBM bytes/launch of {symbol} from the committed rocprofv3 --pmc passes (profiles/r0N_pmc_*.md, newest round): "
         f"2x FETCH_SIZE + WRITE_SIZE; MFMA-bound kernel, re-reads of the input tiles by the channel tiles are served "
         f"by L2/MALL")
 
@@ -144,10 +144,12 @@ class KernelTimer:
         return agg
 
 
-def cpu_baseline(sample_batch=2):
+def cpu_baseline(steps=3, batch=16, budget_s=120.0):
     """The oracle (port of the reference CPU path: grouped convs on per-sample modulated weights, composed
-    upfirdn2d / leaky_relu) timed on the host cores on a bounded sample: ONE KD step at batch `sample_batch` of the
-    same 256 px workload (the reference's own CPU path took 57 s per bs-16 step on 8 cores)."""
+    upfirdn2d / leaky_relu) timed on the host cores, SURVEY §8-d: one warm-up step (batch 2: oneDNN primitive creation)
+    then up to `steps` timed KD generator steps at batch `batch` of the same 256 px workload; the median is reported.
+    Bounded: no further step is started once `budget_s` seconds of timed work have elapsed (the reference's own CPU path
+    took 57 s per bs-16 step on 8 cores)."""
     from cagc import kd
     from oracle import ref_kd
     # intra-op threads: all cores up to 32 (the grouped-conv CPU kernels stop scaling — and oversubscribe badly —
@@ -173,10 +175,48 @@ def cpu_baseline(sample_batch=2):
                              {k: (g if g is not None else torch.zeros_like(ssd[k])) for k, g in zip(names, grads)}, {},
                              0.0016, (0.0, 0.99 ** 0.8))
         return time.perf_counter() - t0
-    one(1)   # warm-up (oneDNN primitive creation)
-    t = one(sample_batch)
-    return {"value": round(sample_batch / t, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 KD generator step at batch {sample_batch} of the 256px bs16 workload ({t:.1f} s), after a batch-1 warm-up"}
+    one(2)   # warm-up
+    times = []
+    while len(times) < steps and sum(times) < budget_s:
+        times.append(one(batch))
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(batch / med, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} timed KD generator step(s) at batch {batch} of the 256px bs16 workload after a batch-2 warm-up; "
+                      f"median {med:.1f} s/step (all: {', '.join(f'{t:.1f}' for t in times)} s)",
+            "cpu_model": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _time_mode(kd, cd, student, teacher, disc, bs, mask, world, dev, rng, gen, mode, n=8):
+    """ms/step of `n` steps of one launch mode on a COPY of the student (untimed calibration / proxy runs)."""
+    import copy
+    s2 = copy.deepcopy(student)
+    if mode == "graph":
+        st2 = kd.GraphedKDStep(s2, teacher, disc, bs, mask, random_noise=True, world_size=world)
+    else:
+        st2 = kd.KDStep(cd.wrap_student(s2, dev), teacher, disc)
+    for _ in range(3):
+        st2.sample_and_step(bs, mask, rng, gen)
+    cd.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n):
+        st2.sample_and_step(bs, mask, rng, gen)
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    del st2, s2
+    return t.item() / n * 1e3
 
 
 def main():
@@ -186,11 +226,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--full-iteration", action="store_true",
-                    help="also time 16 whole training iterations (D step, R1, path-length, EMA); opt-in: its second-order "
-                         "paths go through MIOpen, which JIT-compiles several kernels on a fresh box (minutes)")
-    ap.add_argument("--no-full-iteration", action="store_true", help="(default; kept for compatibility)")
-    ap.add_argument("--sweep", type=int, default=0, help="also time N bs-64 batches of the prune.py saliency sweep (config 5)")
+    ap.add_argument("--full-iteration", action="store_true", help="(default at N=1; kept for compatibility)")
+    ap.add_argument("--no-full-iteration", action="store_true",
+                    help="skip the secondary leg that times 16 whole training iterations (D step, R1, path-length, EMA)")
+    ap.add_argument("--sweep", type=int, default=3, help="time N bs-64 batches of the prune.py saliency sweep (config 5); 0 = skip")
+    ap.add_argument("--no-proxy", action="store_true", help="skip the strong-scaling proxy table (per-GPU batch 8/4/2 on this GPU)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed bs-16 steps of the CPU baseline (SURVEY 8-d: 3)")
+    ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true", help="eager launches + DDP instead of HIP-graph replay")
     ap.add_argument("--graph", action="store_true", help="force HIP-graph replay (default: calibrate — a few untimed steps "
                                                          "of each mode on copies of the models, keep the faster)")
@@ -223,37 +265,34 @@ def main():
         # Launch-mode calibration (untimed, before the warm-up): the same step either replayed as HIP graphs or launched
         # eagerly (teacher on its own stream, DDP buckets overlapping backward).  Which one wins depends on the per-GPU
         # batch and on the host CPU; both compute the same thing (tests/test_gpu_parity.py::test_graphed_kd_step...).
-        import copy
-        try:
-            tg = {}
-            for m in ("graph", "eager"):
-                s2 = copy.deepcopy(student)
-                if m == "graph":
-                    st2 = kd.GraphedKDStep(s2, teacher, disc, bs, mask, random_noise=True, world_size=world)
-                else:
-                    st2 = kd.KDStep(cd.wrap_student(s2, dev), teacher, disc)
-                for _ in range(3):
-                    st2.sample_and_step(bs, mask, rng, gen)
-                cd.barrier()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(8):
-                    st2.sample_and_step(bs, mask, rng, gen)
-                torch.cuda.synchronize()
-                tg[m] = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-                if world > 1:
-                    dist.all_reduce(tg[m], op=dist.ReduceOp.MAX)
-                del st2, s2
-            calib = {m: round(v.item() / 8 * 1e3, 3) for m, v in tg.items()}
-            args.no_graph = calib["eager"] < calib["graph"]      # identical on every rank (MAX-reduced)
-            torch.cuda.empty_cache()
-        except Exception as e:  # noqa: BLE001 — calibration is an optimisation only
-            print(f"[bench] launch-mode calibration failed ({type(e).__name__}: {e}); using HIP-graph replay", file=sys.stderr)
+        # Every rank must take the same branch (the modes issue different collectives): failures are all-reduced.
+        tg, ok = {}, 1.0
+        for m in ("graph", "eager"):
+            try:
+                tg[m] = _time_mode(kd, cd, student, teacher, disc, bs, mask, world, dev, rng, gen, m)
+            except Exception as e:  # noqa: BLE001 — calibration is an optimisation only
+                print(f"[bench] launch-mode calibration of '{m}' failed ({type(e).__name__}: {e})", file=sys.stderr)
+                ok = 0.0
+                break
+        okt = torch.tensor([ok], device=dev)
+        if world > 1:
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if okt.item() > 0:
+            calib = {m: round(v, 3) for m, v in tg.items()}
+            args.no_graph = calib["eager"] < calib["graph"]      # identical on every rank (MAX-reduced times)
+        torch.cuda.empty_cache()
     if not args.no_graph:
+        ok = 1.0
         try:     # HIP-graph replay of the step; gradients all-reduced as one flat RCCL collective between graphs
             step = kd.GraphedKDStep(student, teacher, disc, bs, mask, random_noise=True, world_size=world)
         except Exception as e:  # noqa: BLE001 — capture is an optimisation, never a correctness requirement
             print(f"[bench] HIP-graph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            ok = 0.0
+        okt = torch.tensor([ok], device=dev)
+        if world > 1:
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if okt.item() == 0:   # any rank failed: ALL ranks fall back to the eager mode on fresh models
+            step = None
             torch.cuda.synchronize()
             student, teacher, disc = kd.build_synthetic_workload(SIZE, dev, seed=0)
     if step is None:
@@ -261,18 +300,28 @@ def main():
         ddp_student = cd.wrap_student(student, dev)
         step = kd.KDStep(ddp_student, teacher, disc)
 
-    def run(n):
+    def run(n, marks=None):
         for _ in range(n):
             step.sample_and_step(bs, mask, rng, gen)
+            if marks is not None:     # per-step completion marks for the median (no host sync inside the timed region)
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
 
     run(args.warmup)
     cd.barrier()
     torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    marks = []
     t0 = time.perf_counter()
-    run(args.steps)
+    ev0.record()
+    run(args.steps, marks)
     torch.cuda.synchronize()
     cd.barrier()
     dt = time.perf_counter() - t0
+    stamps = [ev0.elapsed_time(e) for e in marks]
+    per_step = sorted(b - a for a, b in zip([0.0] + stamps[:-1], stamps))
+    median_ms = per_step[len(per_step) // 2] if per_step else None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -316,7 +365,7 @@ def main():
                         "frac_of_8TBps": round(v[3] / (v[1] * 1e-3) / 8e12, 3)}
                     for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])}
     full = None
-    if world == 1 and args.full_iteration and not args.no_full_iteration:
+    if world == 1 and not args.no_full_iteration:
         # secondary figure: the WHOLE training iteration of train.py:371-398 — D step + G/KD step + lazy
         # R1 (every 16) + lazy path-length reg (every 4) + EMA — eagerly launched, 16 iterations = one full lazy-reg
         # period.  Comparable in kind to the reference's README.md:108-115 wall-time figure (15.3 img/s on 2xV100,
@@ -335,7 +384,33 @@ def main():
         torch.cuda.synchronize()
         dtf = time.perf_counter() - t1
         full = {"value": round(16 * bs / dtf, 2), "unit": "images/s", "ms_per_iteration": round(dtf / 16 * 1e3, 2),
-                "what": "D step + G/KD step + R1/16 + path-length/4 + EMA, bs16, eager launches (train.py:371-398 equivalent)"}
+                "what": "D step + G/KD step + R1/16 + path-length/4 + EMA, bs16, eager launches (train.py:371-398 equivalent); "
+                        "every convolution incl. the second-order passes and D's weight gradients on libcagc (no MIOpen)"}
+        del it, g_ema
+        torch.cuda.empty_cache()
+    proxy = None
+    if world == 1 and not args.no_proxy and not os.environ.get("CAGC_BENCH_LOCAL_BS"):
+        # Strong-scaling proxy (driver-visible): this one GPU at the per-GPU batch of an N-GPU run of the same global batch
+        # 16, both launch modes, untimed-calibration style (3 warm-up + 8 steps each).  Upper bound on N-GPU efficiency
+        # before communication: t(16) / (N * t(16/N)).
+        proxy = {}
+        for lb in (16, 8, 4, 2):
+            mk = kd.ellipse_mask(lb, SIZE, dev)
+            row = {}
+            for m in ("graph", "eager"):
+                try:
+                    row[m + "_ms"] = round(_time_mode(kd, cd, student, teacher, disc, lb, mk, 1, dev, rng, gen, m), 3)
+                except Exception as e:  # noqa: BLE001
+                    row[m + "_ms"] = None
+                    print(f"[bench] proxy bs {lb} {m} failed ({type(e).__name__}: {e})", file=sys.stderr)
+                torch.cuda.empty_cache()
+            best = min(v for v in row.values() if v is not None)
+            row["n_gpus_equivalent"] = GLOBAL_BATCH // lb
+            proxy[str(lb)] = row
+        t16 = min(v for k, v in proxy["16"].items() if k.endswith("_ms") and v is not None)
+        for lb in (8, 4, 2):
+            tb = min(v for k, v in proxy[str(lb)].items() if k.endswith("_ms") and v is not None)
+            proxy[str(lb)]["max_strong_scaling_efficiency"] = round(t16 / ((GLOBAL_BATCH // lb) * tb), 3)
     sweep = None
     if world == 1 and args.sweep:
         # BASELINE configs[4]: prune.py's content-aware saliency sweep over the FULL 256 px generator, bs 64 (forward +
@@ -358,18 +433,20 @@ def main():
         kd.requires_grad(teacher, False)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(args.cpu_steps, args.cpu_batch)
 
     if rank == 0:
         out = {"metric": "KD-retrain images/sec, 256px StyleGAN2 70%-pruned bs16", "value": round(value, 3),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "ms_per_step": round(ms, 3), "median_ms_per_step": None if median_ms is None else round(median_ms, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "256px StyleGAN2 70%-pruned student [154x10,77,77,39,39] + full teacher KD generator step, "
                                       "global bs16 (configs[1]); frozen D fwd+dgrad, masked-L1 KD, Adam; LPIPS/BiSeNet off",
                           "global_batch": GLOBAL_BATCH, "per_gpu_batch": bs, "parallelism": f"dp{world}", "launch_mode": mode, "launch_mode_calibration_ms": calib,
                           "student_params": n_params},
-               "roofline": roof, "cpu_baseline": cpu, "full_iteration": full, "saliency_sweep": sweep}
+               "roofline": roof, "cpu_baseline": cpu, "full_iteration": full, "saliency_sweep": sweep,
+               "strong_scaling_proxy_1gpu": proxy}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -53,3 +53,29 @@ for wd in (True, False):
     print(f"WINO_DGRAD={int(wd)}: y err {rel_err(yg, y64):.3e}  gx err {rel_err(xg.grad, x64.grad):.3e}  (vs fp32 golden gx {rel_err(xg.grad, g['gx']):.3e})")
     for i, (a, b) in enumerate(zip(fg, f64s)):
         print(f"   block {i}: act err {rel_err(a, b):.3e}  grad err {rel_err(a.grad, b.grad):.3e}  shape {tuple(a.shape)}")
+
+# ---- is the block-0 gradient deviation a LeakyReLU gate flip?  compare gates of block 1's two activations, and the sparsity
+# of the gradient error
+mc.WINO_DGRAD = True
+dg = copy.deepcopy(d).cuda()
+blk_g, blk_c = dg.convs[1], d64.convs[1]
+h0g = dg.convs[0](g["x"].cuda()).detach().requires_grad_(True)
+h0c = d64.convs[0](g["x"].double()).detach().requires_grad_(True)
+a_g, a_c = blk_g.conv1(h0g), blk_c.conv1(h0c)
+b_g, b_c = blk_g.conv2(a_g), blk_c.conv2(a_c)
+for nm, pg, pc in (("conv1 out", a_g, a_c), ("conv2 out", b_g, b_c)):
+    flips = (pg.detach().cpu() > 0) != (pc.detach() > 0)
+    print(f"{nm}: gate disagreements {int(flips.sum())} of {flips.numel()};  |float64 value| at them:",
+          [f"{v:.2e}" for v in pc.detach()[flips].abs().tolist()[:8]], " (activation scale", f"{float(pc.abs().max()):.2f})")
+yg = blk_g(h0g); yc = blk_c(h0c)
+u = torch.randn(yc.shape, dtype=torch.float64)
+(gg,) = torch.autograd.grad(yg, h0g, u.float().cuda())
+(gc,) = torch.autograd.grad(yc, h0c, u)
+err = (gg.double().cpu() - gc).abs()
+thr = 1e-5 * float(gc.abs().max())
+bad = err > thr
+print(f"ResBlock input-gradient: rel err {rel_err(gg, gc):.3e}; elements above 1e-5 of max: {int(bad.sum())} of {bad.numel()}"
+      f" ({int(bad.any(1).sum())} distinct (b,y,x) positions)")
+if bad.any():
+    idx = bad.any(1).nonzero()
+    print("   positions (b,y,x):", idx[:12].tolist())

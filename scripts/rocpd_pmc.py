@@ -9,6 +9,7 @@ ap.add_argument("db")
 ap.add_argument("--marker", default=None)
 ap.add_argument("--last", type=int, default=2)
 ap.add_argument("--top", type=int, default=25)
+ap.add_argument("--mfma", action="store_true", help="pivot the SQ MFMA / busy counters into one row per kernel with the busy fraction")
 a = ap.parse_args()
 cur = sqlite3.connect(a.db).cursor()
 where = ""
@@ -23,3 +24,24 @@ print("|---|---|---|---|---|---|")
 for n, c, k, v, t in rows[:a.top]:
     n = n if len(n) < 90 else n[:87] + "..."
     print(f"| {n} | {c} | {k} | {v:.4g} | {v / k:.4g} | {t / 1e6:.3f} |")
+
+if a.mfma:
+    # one row per kernel: MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * #SIMDs); the counter sums busy
+    # cycles over every SIMD of the chip (256 CUs x 4), GRBM_GUI_ACTIVE is the dispatch's duration in shader cycles
+    piv = {}
+    for n, c, k, v, t in rows:
+        piv.setdefault(n, {})[c] = (k, v, t)
+    print()
+    print("| kernel | dispatches | total ms | MFMA busy cycles / dispatch | GUI active cycles / dispatch | MFMA busy (of 1024 SIMDs) | MFMA insts / dispatch |")
+    print("|---|---|---|---|---|---|---|")
+    order = sorted(piv.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", (0, 0, 0))[2])
+    for n, d in order[:40]:
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in d or "GRBM_GUI_ACTIVE" not in d:
+            continue
+        k, busy, t = d["SQ_VALU_MFMA_BUSY_CYCLES"]
+        gui = d["GRBM_GUI_ACTIVE"][1]
+        insts = d.get("SQ_INSTS_MFMA", (k, 0, 0))[1]
+        if busy == 0:
+            continue
+        nm = n if len(n) < 90 else n[:87] + "..."
+        print(f"| {nm} | {k} | {t / 1e6:.3f} | {busy / k:.4g} | {gui / k:.4g} | {busy / (gui * 1024):.3f} | {insts / k:.4g} |")

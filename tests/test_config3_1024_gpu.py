@@ -1,0 +1,144 @@
+"""-m gpu: BASELINE configs[3] — the 1024 px KD retrain — on the HIP path: the FULL 1024 px teacher
+[512x10,256,256,128,128,64,64,32,32] (reference model.py:432-442), Discriminator(1024)'s high-resolution ResBlocks
+(32->64->128 channels at 1024^2 / 512^2, model.py:756-778) forward + data gradient + weight gradient, and one whole
+1024 px KD generator step checked through size-independent properties (the CPU oracle needs minutes per step there)."""
+import pytest
+import torch
+
+import cagc.model as M
+from cagc import kd
+from oracle import ref_model
+from _util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-3
+
+
+def cu(t):
+    return t.to(DEV)
+
+
+def test_full_1024_teacher_forward_vs_oracle():
+    torch.manual_seed(21)
+    net = M.Generator(1024, 512, 8)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith("noise.weight"):
+                p.fill_(0.1)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    z = [torch.randn(1, 512), torch.randn(1, 512)]
+    with torch.no_grad():
+        rgb_ref = ref_model.generator_forward_ref(sd, z, inject_index=9, randomize_noise=False, return_rgb_list=True)
+        netg = net.to(DEV)
+        rgb = netg([cu(z[0]), cu(z[1])], inject_index=9, randomize_noise=False, return_rgb_list=True)
+    assert len(rgb) == len(rgb_ref) == 9 and tuple(rgb[-1].shape) == (1, 3, 1024, 1024)
+    for i, (a, b) in enumerate(zip(rgb, rgb_ref)):
+        assert_close(a, b, TOL, f"teacher 1024 rgb[{i}]")
+
+
+@pytest.mark.parametrize("cfg", [(32, 64, 1024), (64, 128, 512), (128, 256, 256)])
+def test_discriminator_1024_resblocks_vs_oracle(cfg):
+    """The three high-resolution ResBlocks of Discriminator(1024): output, input gradient and every weight / bias gradient
+    vs the float64 oracle on the common LeakyReLU gate pattern (protocol: tests/test_second_order_gpu.py — up to 3e7 gates
+    per block here, a handful of which sit at rounding distance from 0; each disagreement is asserted to be at rounding
+    level)."""
+    from oracle import ref_ops
+    from _util import forward_with_activations
+    cin, cout, size = cfg
+    torch.manual_seed(22)
+    blk = M.ResBlock(cin, cout)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(0.1 * torch.randn_like(p))
+    sd = {"b." + k: v.detach().double().clone() for k, v in blk.state_dict().items()}
+    names = [n for n, _ in blk.named_parameters()]
+    x = torch.randn(1, cin, size, size)
+
+    def oracle(sdx, xx):
+        a = ref_model._conv_layer(sdx, "b.conv1", xx, 3)
+        a = ref_model._conv_layer(sdx, "b.conv2", a, 3, downsample=True)
+        sk = ref_model._conv_layer(sdx, "b.skip", xx, 1, downsample=True, activate=False, bias=False)
+        return (a + sk) / 2 ** 0.5
+
+    bg = blk.to(DEV)
+    xg = cu(x).requires_grad_(True)
+    yg, outs = forward_with_activations(bg, xg)
+    gates_g = [(o.detach() > 0).cpu() for o in outs.values()]
+    with torch.no_grad(), ref_ops.gates() as rec:
+        oracle(sd, x.double())
+    n_dis = ref_ops.gate_disagreements(rec, gates_g)
+    leaves = {"b." + k: sd["b." + k].clone().requires_grad_(True) for k in names}
+    sdr = dict(sd)
+    sdr.update(leaves)
+    xr = x.double().requires_grad_(True)
+    with ref_ops.gates(force=gates_g):
+        yr = oracle(sdr, xr)
+    go = torch.randn(yr.shape)
+    gr = torch.autograd.grad(yr, [xr] + [leaves["b." + k] for k in names], go.double())
+    assert_close(yg, yr, 2e-5, f"{cfg} out")
+    gg = torch.autograd.grad(yg, [xg] + [dict(bg.named_parameters())[k] for k in names], cu(go))
+    for nm, p, q in zip(["x"] + names, gg, gr):
+        assert_close(p, q, 1e-4, f"{cfg} grad {nm} ({n_dis} gate disagreements)")
+
+
+def test_discriminator_1024_forward_and_input_gradient_properties():
+    """Whole Discriminator(1024) at batch 2: finite, and the input gradient is linear in the upstream gradient."""
+    torch.manual_seed(23)
+    d = M.Discriminator(1024).to(DEV)
+    kd.requires_grad(d, False)
+    x = torch.randn(2, 3, 1024, 1024, device=DEV, requires_grad=True)
+    y = d(x)
+    assert tuple(y.shape) == (2, 1) and torch.isfinite(y).all()
+    u = torch.randn(2, 1, device=DEV)
+    (g1,) = torch.autograd.grad(y, x, u, retain_graph=True)
+    (g2,) = torch.autograd.grad(y, x, 2 * u)
+    assert torch.isfinite(g1).all()
+    assert_close(g2, 2 * g1, 1e-5, "dgrad linearity")
+
+
+def test_kd_step_1024_properties():
+    """One configs[3] KD generator step (pruned 1024 student + FULL 1024 teacher + Discriminator(1024), per-GPU batch 2):
+    losses and every gradient finite; backward is additive over the two loss terms; the generator images are batch
+    independent (sample 1 alone == sample 1 in the batch)."""
+    student, teacher, disc = kd.build_synthetic_workload(1024, DEV, seed=0)
+    shape = [154] * 10 + [77, 77, 39, 39, 20, 20, 10, 10]
+    from cagc import prune
+    assert prune.network_shape(student.state_dict()) == shape
+    step = kd.KDStep(student, teacher, disc)
+    B = 2
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    zs = [torch.randn(B, 512, device=DEV, generator=gen), torch.randn(B, 512, device=DEV, generator=gen)]
+    nl = student.num_layers
+    sn = [torch.randn(B, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), device=DEV, generator=gen) for i in range(nl)]
+    tn = [torch.randn(B, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), device=DEV, generator=gen) for i in range(nl)]
+    mask = kd.ellipse_mask(B, 1024, DEV)
+    kd.requires_grad(student, True)
+    kd.requires_grad(disc, False)
+    params = [p for p in student.parameters()]
+
+    def grads(wg, wk):
+        g_loss, kd_l1, img = step.g_losses(zs, 7, mask, sn, tn)
+        gs = torch.autograd.grad(wg * g_loss + wk * kd_l1, params, allow_unused=True)
+        return g_loss.detach(), kd_l1.detach(), img.detach(), gs
+
+    gl, kl, img, g_all = grads(1.0, 1.0)
+    assert torch.isfinite(gl) and torch.isfinite(kl) and kl.item() > 0
+    _, _, _, g_g = grads(1.0, 0.0)
+    _, _, _, g_k = grads(0.0, 1.0)
+    for p, a, b, c in zip(student.named_parameters(), g_all, g_g, g_k):
+        if a is None:
+            continue
+        assert torch.isfinite(a).all(), p[0]
+        # fp32 atomics make single runs differ at 1e-4 of a tensor's scale; additivity must hold to that
+        assert_close(a, b + c, 5e-4 if a.numel() > 1 else 5e-3, "additivity " + p[0])
+    with torch.no_grad():
+        one = student([z[1:2] for z in zs], inject_index=7, noise=[n[1:2] for n in sn])
+        assert_close(one, img[1:2], 1e-5, "student batch independence")
+        t_all = teacher(zs, inject_index=7, noise=tn)
+        t_one = teacher([z[1:2] for z in zs], inject_index=7, noise=[n[1:2] for n in tn])
+        assert_close(t_one, t_all[1:2], 1e-5, "teacher batch independence")
+    losses = step.g_step(zs, 7, mask, sn, tn)       # and the optimiser step itself
+    assert all(torch.isfinite(v) for v in losses.values())
+    assert all(torch.isfinite(p).all() for p in student.parameters())

@@ -236,8 +236,9 @@ def test_discriminator_golden():
     y = d(x)
     assert_close(y, g["y"], TOL, "D out")
     (gx,) = torch.autograd.grad(torch.nn.functional.softplus(-y).mean(), x)
-    # the 32-px conv runs on the Winograd kernel; its ~1e-6 forward differences flip a few LeakyReLU gates of this
-    # random 512-channel net, which the input gradient amplifies (1.3e-3): looser bound for this derived quantity only
+    # one LeakyReLU gate of 2,097,152 sits at a float64 pre-activation of 7e-7 and lands on the other side of 0 here
+    # (test_discriminator_vs_float64_reference pins that: everything outside its 3x3 field agrees to the 1e-3 bar);
+    # this fp32-golden comparison therefore keeps the looser whole-tensor bound
     assert_close(gx, g["gx"], 3e-3, "D input grad")
 
 
@@ -249,19 +250,43 @@ def _f64_bar(f64, key):
 
 @pytest.mark.parametrize("wino_dgrad", [True, False])
 def test_discriminator_vs_float64_reference(wino_dgrad, monkeypatch):
-    """D(32) output and input gradient vs the reference evaluated in float64, with the stride-1 3x3 data gradients on
-    the Winograd kernel and on the direct implicit GEMM."""
+    """D(32) output and input gradient vs the REFERENCE evaluated in float64 (tests/golden/float64_refs.npz), with the
+    stride-1 3x3 data gradients on the Winograd kernel and on the direct implicit GEMM.
+
+    Measured (gpurun_out/run2.log, scripts/d32_diag.py): the whole deviation of the input gradient from the golden
+    (1.34e-3, identical for both data-gradient kernels) comes from ONE LeakyReLU gate out of 2,097,152 in the first
+    ResBlock whose float64 pre-activation is 7.3e-7 (activation scale 7.8): fp32 rounding puts it on the other side of
+    0, and the error is confined to the 3x3 input positions that element reaches; every other position agrees to
+    ~5e-7.  So the test (a) requires every gate disagreement to be at rounding level and few, and (b) holds the
+    gradient to the 1e-3 bar everywhere, excluding only the receptive field of a disagreeing gate — where it still must
+    stay within the magnitude one flipped gate can cause."""
+    import copy
     from cagc.op import modconv as mc
+    from _util import forward_with_activations, gate_flips, reach_mask
     monkeypatch.setattr(mc, "WINO_DGRAD", wino_dgrad)
     g, f64 = load_npz("discriminator32"), load_npz("float64_refs")
     d = M.Discriminator(32)
     d.load_state_dict(ref_model.regenerate_state_dict(load_json("discriminator32_keys"), g["seed"]), strict=True)
-    d = d.to(DEV)
+    d64 = copy.deepcopy(d).double()                      # the product's composed CPU path in float64 ...
+    x64 = g["x"].double().requires_grad_(True)
+    y64, outs64 = forward_with_activations(d64, x64)
+    (gx64,) = torch.autograd.grad(torch.nn.functional.softplus(-y64).mean(), x64, retain_graph=True)
+    assert_close(y64, f64["d32/y"], 1e-12, "float64 product == float64 reference (out)")     # ... IS the reference
+    assert_close(gx64, f64["d32/gx"], 1e-12, "float64 product == float64 reference (gx)")
+    dg = d.to(DEV)
     x = cu(g["x"]).requires_grad_(True)
-    y = d(x)
+    y, outs = forward_with_activations(dg, x)
     (gx,) = torch.autograd.grad(torch.nn.functional.softplus(-y).mean(), x)
     assert_close(y, f64["d32/y"], _f64_bar(f64, "d32/fp32_err_y"), "D out vs float64")
-    assert_close(gx, f64["d32/gx"], _f64_bar(f64, "d32/fp32_err_gx"), f"D input grad vs float64 (wino_dgrad={wino_dgrad})")
+    flips = gate_flips(outs, outs64)
+    assert len(flips) <= 4, f"{len(flips)} LeakyReLU gates disagree with float64"
+    assert all(rel < 1e-5 for _, _, rel in flips), f"gate disagreement above rounding level: {flips}"
+    excl = reach_mask(outs64, flips, x64) if flips else torch.zeros(4, 1, 32, 32, dtype=torch.bool)
+    assert int(excl.sum()) <= 9 * 16 * max(1, len(flips))
+    err = (gx.detach().double().cpu() - f64["d32/gx"]).abs() / f64["d32/gx"].abs().max()
+    bar = _f64_bar(f64, "d32/fp32_err_gx")
+    assert float(err.masked_fill(excl, 0).max()) <= bar, f"D input grad outside flipped-gate fields: {float(err.masked_fill(excl, 0).max()):.3e}"
+    assert float(err.max()) <= 5e-3, f"D input grad inside a flipped gate's field: {float(err.max()):.3e}"
 
 
 def test_tiny_generator_and_kd_step_vs_float64_reference():
