@@ -12,6 +12,7 @@ rocprofv3 --kernel-trace -d /tmp/prof_kt -o kt -- $CMD > gpurun_out/${TAG}_kt.lo
 DB=$(find /tmp/prof_kt -name '*.db' | head -1)
 { echo "command: rocprofv3 --kernel-trace -- $CMD  (CAGC_OVERLAP_TEACHER=0: eager launches on one stream, per-kernel view of the step bench.py times)"; echo;
   python scripts/rocpd_stats.py "$DB" --marker k_masked_l1 --last 4 --top 45; } > gpurun_out/${TAG}_kernel_stats.md
+if [ -n "$PROFILE_KT_ONLY" ]; then head -60 gpurun_out/${TAG}_kernel_stats.md; exit 0; fi
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_pmc
   rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_pmc -o pmc -- $CMD > gpurun_out/${TAG}_pmc_$C.log 2>&1

@@ -118,7 +118,7 @@ def test_discriminator_r1_double_backward_vs_float64_oracle(size, B):
         # R1's bias gradients exist only through the minibatch-stddev channel (1e-5 of the weight gradients, cancelling
         # sums): absolute floor relative to the largest gradient of the net
         err = (a.double().cpu() - b).abs().max().item()
-        assert err <= 2e-4 * max(float(b.abs().max()), 1e-2 * gmax), f"R1 grad {k}: {err:.3e} vs max {float(b.abs().max()):.3e} ({n_dis} gate disagreements)"
+        assert err <= 2e-4 * float(b.abs().max()) + 1e-5 * gmax, f"R1 grad {k}: {err:.3e} vs max {float(b.abs().max()):.3e} ({n_dis} gate disagreements)"
 
 
 def test_discriminator_training_step_weight_gradients_on_hip():
