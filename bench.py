@@ -53,6 +53,9 @@ def conv_flops(name, a):
     if name == "cagc_wino_conv3x3":      # (out,x,up,s,B,Cin,Cout,H,W,...): Winograd F(2x2,3x3) — count the flops the
         B, cin, cout, H, W = a[4:9]      # MFMA pipe EXECUTES (16 GEMMs over H/2*W/2 tiles = 4 MACs per output pixel
         return 2.0 * B * cin * cout * 4 * H * W   # and channel pair), not the 9 of the direct conv it replaces
+    if name == "cagc_wino_conv3x3_act_dgrad":   # (gx,gout,act_out,up,B,Cin,Cout,H,W,...)
+        B, cin, cout, H, W = a[4:9]
+        return 2.0 * B * cin * cout * 4 * H * W
     if name in ("cagc_conv3x3s2_fwd", "cagc_conv3x3s2_dgrad"):   # (out,x,wp,B,Cin,Cout,Hin,Win,pitch)
         B, cin, cout, hin, win = a[3:8]
         return 2.0 * B * cin * cout * 9 * ((hin - 3) // 2 + 1) * ((win - 3) // 2 + 1)
@@ -76,7 +79,8 @@ def stream_bytes(name, a):
 
 
 # dominant-entry-point -> device symbol (for the PMC traffic lookup) and MFMA instruction
-KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4>]": "k_wino<4>", "cagc_wino_conv3x3[k_wino<3>]": "k_wino<3>", "cagc_modconv_fwd": "k_conv_igemm<8, 4, true, false, 1>",
+KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false>", "cagc_wino_conv3x3[k_wino<3, false>]": "k_wino<3, false>",
+             "cagc_wino_conv3x3_act_dgrad[k_wino<4, true>]": "k_wino<4, true>", "cagc_modconv_fwd": "k_conv_igemm<8, 4, true, false, 1>",
              "cagc_modconv_up_fwd": "k_conv_igemm<8, 4, true, false, 1>",
              "cagc_modconv_dgrad": "k_conv_igemm<8, 12, true, false, 1>",
              "cagc_modconv_up_dgrad": "k_conv_igemm<8, 12, true, false, 1>", "cagc_modconv_wgrad": "k_wgrad2<5, 2>"}
@@ -121,10 +125,11 @@ class KernelTimer:
             self.orig(name, *args)
             e.record(st)
             key = name
-            if name == "cagc_wino_conv3x3":   # one record family per device kernel, so the average launch duration is
-                nblk = -(-args[6] // 16)      # comparable with the rocprofv3 per-symbol summary (csrc/conv_wino.hip wino_mb)
+            if name in ("cagc_wino_conv3x3", "cagc_wino_conv3x3_act_dgrad"):   # one record family per device kernel, so the
+                gated = name.endswith("act_dgrad")                              # average launch duration is comparable with the
+                nblk = -(-(args[5] if gated else args[6]) // 16)                # rocprofv3 per-symbol summary (conv_wino.hip wino_mb)
                 mb = nblk if nblk <= 3 else (3 if (nblk % 4 != 0 and nblk % 3 == 0) else 4)
-                key = f"cagc_wino_conv3x3[k_wino<{mb}>]"
+                key = f"{name}[k_wino<{mb}, {'true' if gated else 'false'}>]"
             self.records.append((key, s, e, conv_flops(name, args), stream_bytes(name, args)))
         self.lib_mod.call = timed
         return self

@@ -28,6 +28,7 @@ _PROTOS = {
     "cagc_phase_pitch": [_i],
     "cagc_modconv_packed_elems": [_i, _i, _i],
     "cagc_modconv_prep": [_p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "cagc_modconv_prep_all": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "cagc_modconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _f, _f, _p],
     "cagc_modconv_up_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "cagc_blur_up_fwd": [_p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _f, _p],
@@ -37,10 +38,14 @@ _PROTOS = {
     "cagc_modconv_up_dgrad": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "cagc_modconv_wgrad_workspace": [_i, _i, _i, _i, _i, _i, _i],
     "cagc_modconv_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "cagc_modconv_wgrad_demod": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "cagc_styled_bwd_finish": [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    "cagc_torgb_bwd_finish": [_p, _p, _p, _p, _p, _i, _i, _f, _p],
     "cagc_wino_eligible": [_i, _i],
     "cagc_wino_packed_elems": [_i, _i],
     "cagc_wino_prep": [_p, _p, _i, _i, _f, _i, _p],
     "cagc_wino_conv3x3": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _f, _f, _p],
+    "cagc_wino_conv3x3_act_dgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p],
     "cagc_fir4x4_pitched": [_p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "cagc_conv3x3s2_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "cagc_conv3x3s2_dgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

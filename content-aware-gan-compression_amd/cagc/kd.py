@@ -288,21 +288,28 @@ class GraphedKDStep(KDStep):
             self.t_noise = [torch.zeros(shp(i), device=dev) for i in range(base.num_layers)]
         else:
             self.s_noise = self.t_noise = None
-        params = [p for p in self.student.parameters()]
-        self.flat_grad = torch.zeros(sum(p.numel() for p in params), device=dev)
-        off = 0
-        for p in params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+        self._params = [p for p in self.student.parameters()]
+        self.flat_grad = torch.zeros(sum(p.numel() for p in self._params), device=dev)
+        self._grad_views, off = [], 0
+        for p in self._params:
+            self._grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.losses = None
         self._capture()
 
     def _fwd_bwd(self):
-        self.flat_grad.zero_()
         if self.random_noise:
             self.z.normal_()
         g_loss, kd_l1, _ = self.g_losses([self.z[0], self.z[1]], self.inj, self.mask, self.s_noise, self.t_noise)
+        # Gradients are produced into fresh tensors (grad = None: autograd assigns instead of launching one accumulate-add per
+        # parameter into a pre-zeroed buffer) and gathered into the flat all-reduce / Adam buffer by ONE concatenation.
+        for p in self._params:
+            p.grad = None
         (g_loss + kd_l1).backward()
+        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._params]
+        torch.cat(grads, out=self.flat_grad)
+        for p, v in zip(self._params, self._grad_views):
+            p.grad = v
         return torch.stack([g_loss.detach(), kd_l1.detach()])
 
     def _capture(self):
@@ -311,7 +318,7 @@ class GraphedKDStep(KDStep):
         # The warm-up (allocator pools, lazy inits, Adam state creation) takes real optimiser steps: snapshot the
         # student and restore it afterwards, so that capture leaves the weights / Adam moments / step counters exactly
         # as it found them (and replicas that started identical stay identical — no collective runs in the warm-up).
-        params = [p for p in self.student.parameters()]
+        params = self._params
         snap = [p.detach().clone() for p in params]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

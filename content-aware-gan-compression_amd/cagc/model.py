@@ -261,6 +261,17 @@ class ModulatedConv2d(nn.Module):
             return None
         return mc.pack_wino(w[0], self.scale, True)
 
+    def prepared(self, H, W):
+        """(wp_fwd, wp_bwd, wsq, up_wino, up_wino_bwd) for an input of H x W.  A trainable weight changes every optimiser
+        step: all five are rebuilt by one launch (mc.prep_all); frozen weights come from the caches above."""
+        w = self.weight
+        if w.requires_grad:
+            need_bwd = torch.is_grad_enabled()
+            wino = (not self.upsample and not self.downsample and self.kernel_size == 3 and mc.wino_ok(H, W))
+            return mc.prep_all(w, need_bwd, wino, wino and need_bwd and mc.WINO_DGRAD)
+        wp_fwd, wp_bwd, wsq = self.packed_weights()
+        return wp_fwd, wp_bwd, wsq, self.wino_weights(H, W), self.wino_weights_bwd(H, W)
+
     def invalidate_packed(self):
         self._packed = None
         self._wino = None
@@ -270,19 +281,13 @@ class ModulatedConv2d(nn.Module):
         self._wino = None
         return super()._apply(fn, *a, **k)
 
-    def _demod(self, s, wsq):
-        return mc._Demod.apply(s, self.weight, wsq) if self.demodulate else None
-
     def forward(self, input, style, return_style_scalars=False):
         batch, in_channel = input.shape[0], input.shape[1]
         s = self.modulation(style)                                        # [B, Cin]
         if self._hip_eligible(input):
-            wp_fwd, wp_bwd, wsq = self.packed_weights()
-            d = self._demod(s, wsq)
-            out = mc._ModConv.apply(input, self.weight, s, d, None, None, None, wp_fwd, wp_bwd,
-                                    self.blur.kernel if self.upsample else None, False, self.upsample,
-                                    self.wino_weights(input.shape[2], input.shape[3]),
-                                    self.wino_weights_bwd(input.shape[2], input.shape[3]))
+            wp_fwd, wp_bwd, wsq, up_w, up_wb = self.prepared(input.shape[2], input.shape[3])
+            out = mc._ModConv.apply(input, self.weight, s, wsq if self.demodulate else None, None, None, None, wp_fwd, wp_bwd,
+                                    self.blur.kernel if self.upsample else None, False, self.upsample, up_w, up_wb)
         else:
             out = mc.modconv_composed(input, self.weight, s, self.demodulate, self.upsample, self.downsample,
                                       self.blur.kernel if (self.upsample or self.downsample) else None,
@@ -335,16 +340,14 @@ class StyledConv(nn.Module):
         if fused:
             batch, cin, h, w = input.shape
             s = conv.modulation(style)
-            wp_fwd, wp_bwd, wsq = conv.packed_weights()
-            d = conv._demod(s, wsq)
+            wp_fwd, wp_bwd, wsq, up_w, up_wb = conv.prepared(h, w)
             oh, ow = (2 * h, 2 * w) if conv.upsample else (h, w)
             if noise is None:
                 noise = input.new_empty(batch, 1, oh, ow).normal_()
             elif noise.shape[0] not in (1, batch) or tuple(noise.shape[1:]) != (1, oh, ow):
                 noise = noise.expand(batch, 1, oh, ow)
-            out = mc._ModConv.apply(input, conv.weight, s, d, noise, self.noise.weight, self.activate.bias, wp_fwd,
-                                    wp_bwd, conv.blur.kernel if conv.upsample else None, True, conv.upsample,
-                                    conv.wino_weights(h, w), conv.wino_weights_bwd(h, w))
+            out = mc._ModConv.apply(input, conv.weight, s, wsq if conv.demodulate else None, noise, self.noise.weight, self.activate.bias, wp_fwd,
+                                    wp_bwd, conv.blur.kernel if conv.upsample else None, True, conv.upsample, up_w, up_wb)
             styles = s.view(batch, 1, cin, 1, 1)
         else:
             if return_style_scalars:
@@ -456,7 +459,13 @@ class Generator(nn.Module):
 
     def _synthesize(self, noise_z, inject_index, truncation, truncation_latent, latent_styles, input_is_latent, noise,
                     randomize_noise, return_rgb_list, return_style_scalars, want_latent):
-        styles = latent_styles if input_is_latent else [self.style(z) for z in noise_z]
+        if input_is_latent:
+            styles = latent_styles
+        elif len(noise_z) > 1 and all(z.shape == noise_z[0].shape for z in noise_z):
+            # one pass of the mapping network over the stacked latents (row-wise ops: identical values, half the launches)
+            styles = list(self.style(torch.cat(list(noise_z), 0)).chunk(len(noise_z), 0))
+        else:
+            styles = [self.style(z) for z in noise_z]
         if noise is None:
             noise = ([None] * self.num_layers if randomize_noise
                      else [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)])

@@ -24,6 +24,8 @@ import os
 EPI_LINEAR, EPI_STYLED = 0, 1
 # data gradient of the discriminator's stride-1 3x3 convs: Winograd (1) or the direct implicit GEMM (0)
 WINO_DGRAD = os.environ.get("CAGC_WINO_DGRAD", "1") == "1"
+# frozen-D data gradient of conv3x3 + FusedLeakyReLU as ONE launch (activation backward fused into the conv's staging)
+FUSE_ACT_DGRAD = os.environ.get("CAGC_FUSE_ACT_DGRAD", "1") == "1"
 SQRT2 = 2 ** 0.5
 
 # ---------------------------------------------------------------------------------------------------
@@ -85,6 +87,25 @@ def pack_weights(weight, need_bwd):
     return wp_fwd, wp_bwd, wsq
 
 
+def prep_all(weight, need_bwd, want_wino, want_wino_bwd):
+    """Everything a trainable layer derives from its weight per step, in ONE launch (cagc_modconv_prep_all):
+    (wp_fwd, wp_bwd | None, wsq, up_wino | None, up_wino_bwd | None)."""
+    _, cout, cin, k, _ = weight.shape
+    scale = 1.0 / math.sqrt(cin * k * k)
+    w = weight.detach().contiguous()
+    dev = w.device
+    new = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+    wp_fwd = new(_lib.query("cagc_modconv_packed_elems", cin, cout, k))
+    wp_bwd = new(_lib.query("cagc_modconv_packed_elems", cout, cin, k)) if need_bwd else None
+    wsq = torch.empty(cout, cin, dtype=torch.float32, device=dev)
+    up_f = new(_lib.query("cagc_wino_packed_elems", cin, cout)) if (want_wino and k == 3) else None
+    up_b = new(_lib.query("cagc_wino_packed_elems", cout, cin)) if (want_wino_bwd and k == 3) else None
+    with _lib.on_device(w):
+        _lib.call("cagc_modconv_prep_all", _lib.ptr(wp_fwd), _lib.ptr(wp_bwd), _lib.ptr(wsq), _lib.ptr(up_f), _lib.ptr(up_b),
+                  _lib.ptr(w), cout, cin, k, scale)
+    return wp_fwd, wp_bwd, wsq, up_f, up_b
+
+
 def pack_wino(weight4, scale, dgrad):
     """weight [Cout,Cin,3,3] (contiguous view) -> Winograd-domain weights [16][Kp][Mp] (cagc_wino_prep)."""
     cout, cin = weight4.shape[0], weight4.shape[1]
@@ -100,61 +121,34 @@ def wino_ok(H, W):
     return bool(_lib.query("cagc_wino_eligible", H, W))
 
 
-class _Demod(Function):
-    """d[b,o] = rsqrt(sum_i s[b,i]^2 wsq[o,i] + 1e-8) — wavefront-shuffle reduction (cagc_demod_fwd)."""
-
-    @staticmethod
-    def forward(ctx, s, weight, wsq):
-        s = s.contiguous()
-        B, cin = s.shape
-        cout = wsq.shape[0]
-        d = torch.empty(B, cout, dtype=s.dtype, device=s.device)
-        with _lib.on_device(s):
-            _lib.call("cagc_demod_fwd", _lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq), B, cin, cout)
-        ctx.save_for_backward(s, weight, wsq, d)
-        return d
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, gd):
-        s, weight, wsq, d = ctx.saved_tensors
-        B, cin = s.shape
-        cout = wsq.shape[0]
-        gd = gd.contiguous()
-        gs = torch.zeros_like(s) if ctx.needs_input_grad[0] else None
-        gwsq = torch.empty_like(wsq) if ctx.needs_input_grad[1] else None
-        with _lib.on_device(s):
-            _lib.call("cagc_demod_bwd", _lib.ptr(gs), _lib.ptr(gwsq), _lib.ptr(gd), _lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq),
-                      B, cin, cout)
-        gweight = None
-        if gwsq is not None:
-            k = weight.shape[-1]
-            scale2 = 1.0 / (cin * k * k)
-            gweight = (2.0 * scale2) * gwsq[None, :, :, None, None] * weight
-        return gs, gweight, None
-
-
 # ---------------------------------------------------------------------------------------------------
-# the modulated conv (+ optional fused noise / bias / LeakyReLU epilogue)
+# the modulated conv (+ demodulation, + optional fused noise / bias / LeakyReLU epilogue) as ONE autograd node
 # ---------------------------------------------------------------------------------------------------
 class _ModConv(Function):
-    """x, weight, s, d, noise, noise_w, bias -> out.  `styled` selects the fused StyledConv epilogue
-    (reference model.py:351-367); `upsample` the transposed-conv + blur variant (model.py:259-270)."""
+    """x, weight, s, wsq, noise, noise_w, bias -> out.  `wsq` [Cout,Cin] (from cagc_modconv_prep; None = no demodulation)
+    makes the op compute d = rsqrt(sum_i s^2 wsq + 1e-8) itself (cagc_demod_fwd, wavefront-shuffle reduction) and close the
+    demodulation branch in its own backward: the style gradient of both branches accumulates in one buffer and the weight
+    gradient's demod term is folded into the wgrad reduction — no separate autograd node, no gradient-merging launches.
+    `styled` selects the fused StyledConv epilogue (reference model.py:351-367); `upsample` the transposed-conv + blur
+    variant (model.py:259-270)."""
 
     @staticmethod
-    def forward(ctx, x, weight, s, d, noise, noise_w, bias, wp_fwd, wp_bwd, fir, styled, upsample, up_wino=None,
+    def forward(ctx, x, weight, s, wsq, noise, noise_w, bias, wp_fwd, wp_bwd, fir, styled, upsample, up_wino=None,
                 up_wino_bwd=None):
         x = x.contiguous()
         s = s.contiguous()
         B, cin, H, W = x.shape
         cout, k = weight.shape[1], weight.shape[-1]
         dev = x.device
-        d_c = d.contiguous() if d is not None else None
         nb = 0
         if noise is not None:
             noise = noise.contiguous()
             nb = noise.shape[0]
         with _lib.on_device(x):
+            d_c = None
+            if wsq is not None:
+                d_c = torch.empty(B, cout, dtype=x.dtype, device=dev)
+                _lib.call("cagc_demod_fwd", _lib.ptr(d_c), _lib.ptr(s), _lib.ptr(wsq), B, cin, cout)
             if upsample:
                 t = torch.empty(B, cout, 4, H + 1, _lib.query("cagc_phase_pitch", W), dtype=x.dtype, device=dev)
                 _lib.call("cagc_modconv_up_fwd", _lib.ptr(t), _lib.ptr(x), _lib.ptr(wp_fwd), _lib.ptr(s), B, cin, cout, H, W)
@@ -175,13 +169,14 @@ class _ModConv(Function):
                           _lib.ptr(noise_w) if styled else None, _lib.ptr(bias) if styled else None, 0.2, SQRT2)
         ctx.styled, ctx.upsample, ctx.k = styled, upsample, k
         ctx.save_for_backward(x, s, d_c, noise, noise_w, bias, out, wp_bwd, fir,
-                              up_wino_bwd if (up_wino_bwd is not None and not upsample and k == 3 and wino_ok(H, W)) else None)
+                              up_wino_bwd if (up_wino_bwd is not None and not upsample and k == 3 and wino_ok(H, W)) else None,
+                              wsq, weight)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        x, s, d, noise, noise_w, bias, out, wp_bwd, fir, up_wino_bwd = ctx.saved_tensors
+        x, s, d, noise, noise_w, bias, out, wp_bwd, fir, up_wino_bwd, wsq, weight = ctx.saved_tensors
         styled, upsample, k = ctx.styled, ctx.upsample, ctx.k
         if wp_bwd is None:
             raise RuntimeError("modulated conv: backward requested but the weights were packed forward-only")
@@ -190,28 +185,30 @@ class _ModConv(Function):
         Ho, Wo = out.shape[2], out.shape[3]
         dev = x.device
         gout = gout.contiguous()
-        need_x, need_w, need_s, need_d = ctx.needs_input_grad[0:4]
+        need_x, need_w, need_s = ctx.needs_input_grad[0:3]
+        need_d = d is not None and (need_s or need_w)
         gd = g_nw = g_bias = None
+        gs = torch.empty_like(s) if need_s else None
         with _lib.on_device(x):
             if styled:
                 gz = torch.empty_like(gout)
                 red = torch.empty(3, B, cout, dtype=x.dtype, device=dev)
                 _lib.call("cagc_styled_act_bwd", _lib.ptr(gz), _lib.ptr(red), _lib.ptr(gout), _lib.ptr(out), _lib.ptr(d),
                           _lib.ptr(noise), noise.shape[0] if noise is not None else 0, B, cout, Ho * Wo, 0.2, SQRT2)
-                r0, r1, r2 = red[0], red[1], red[2]
-                g_bias = r0.sum(0)
-                if noise is not None:
-                    g_nw = r1.sum().reshape(1)
-                if d is not None and need_d:
-                    # z = (pre - nw*noise - bias) / d  ->  gd = sum_p gpre * z
-                    gd = r2 - bias[None, :] * r0
-                    if noise is not None:
-                        gd = gd - noise_w * r1
-                    gd = gd / d
+                # one launch: bias / noise-weight gradients, the gradient reaching d (z = (pre - nw*noise - bias) / d ->
+                # gd = sum_p gpre * z) and the zero-fill of the style-gradient accumulator
+                g_bias = torch.empty(cout, dtype=x.dtype, device=dev)
+                g_nw = torch.empty(1, dtype=x.dtype, device=dev) if noise is not None else None
+                gd = torch.empty(B, cout, dtype=x.dtype, device=dev) if need_d else None
+                _lib.call("cagc_styled_bwd_finish", _lib.ptr(g_bias), _lib.ptr(g_nw), _lib.ptr(gd), _lib.ptr(gs),
+                          gs.numel() if gs is not None else 0, _lib.ptr(red), _lib.ptr(bias), _lib.ptr(noise_w), _lib.ptr(d), B, cout,
+                          1 if noise is not None else 0)
             else:
+                if gs is not None:
+                    gs.zero_()
                 if d is not None:
                     if need_d:
-                        gd = (gout * out).sum([2, 3]) / d         # out = d*z  ->  sum_p gout*z = sum_p gout*out / d
+                        gd = ((gout * out).sum([2, 3]) / d).contiguous()   # out = d*z  ->  sum_p gout*z = sum_p gout*out / d
                     gz = gout * d[:, :, None, None]
                 else:
                     gz = gout
@@ -220,10 +217,9 @@ class _ModConv(Function):
                 _lib.call("cagc_blur_up_bwd", _lib.ptr(g), _lib.ptr(gz), _lib.ptr(fir), B, cout, H, W)
             else:
                 g = gz
-            gx = gs = gweight = None
+            gx = gweight = None
             if need_x or need_s:
                 gx = torch.empty_like(x)
-                gs = torch.zeros_like(s) if need_s else None
                 if upsample:
                     _lib.call("cagc_modconv_up_dgrad", _lib.ptr(gx), _lib.ptr(gs), _lib.ptr(g), _lib.ptr(wp_bwd), _lib.ptr(s),
                               _lib.ptr(x), B, cin, cout, H, W)
@@ -236,13 +232,19 @@ class _ModConv(Function):
                 else:
                     _lib.call("cagc_modconv_dgrad", _lib.ptr(gx), _lib.ptr(gs), _lib.ptr(g), _lib.ptr(wp_bwd), _lib.ptr(s),
                               _lib.ptr(x), B, cin, cout, H, W, k)
+            gwsq = None
+            if need_d:   # demodulation branch: gs += 2 s sum_o t wsq, gwsq = sum_b t s^2   (t = -gd d^3 / 2)
+                gwsq = torch.empty_like(wsq) if need_w else None
+                _lib.call("cagc_demod_bwd", _lib.ptr(gs), _lib.ptr(gwsq), _lib.ptr(gd), _lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq),
+                          B, cin, cout)
             if need_w:
                 up = 1 if upsample else 0
                 n_ws = _lib.query("cagc_modconv_wgrad_workspace", B, cin, cout, H, W, k, up)
                 ws = torch.empty(n_ws, dtype=x.dtype, device=dev)
                 gweight = torch.empty(1, cout, cin, k, k, dtype=x.dtype, device=dev)
-                _lib.call("cagc_modconv_wgrad", _lib.ptr(gweight), _lib.ptr(ws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(s), B, cin,
-                          cout, H, W, k, up, 1.0 / math.sqrt(cin * k * k))
+                wc = weight.detach().contiguous() if gwsq is not None else None
+                _lib.call("cagc_modconv_wgrad_demod", _lib.ptr(gweight), _lib.ptr(ws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(s),
+                          _lib.ptr(gwsq), _lib.ptr(wc), B, cin, cout, H, W, k, up, 1.0 / math.sqrt(cin * k * k))
         g_noise = None
         if styled and noise is not None and ctx.needs_input_grad[4]:
             # d out / d noise = noise_weight * gpre, summed over channels (and over the batch for a shared [1,1,H,W] map);
@@ -252,7 +254,7 @@ class _ModConv(Function):
             g_noise = noise_w * gpre.sum(1, keepdim=True)
             if noise.shape[0] == 1 and B > 1:
                 g_noise = g_noise.sum(0, keepdim=True)
-        return (gx if need_x else None, gweight, gs, gd, g_noise, g_nw, g_bias, None, None, None, None, None, None, None)
+        return (gx if need_x else None, gweight, gs, None, g_noise, g_nw, g_bias, None, None, None, None, None, None, None)
 
 
 def modconv_composed(x, weight, s, demodulate, upsample, downsample, blur_kernel, blur_pad):
@@ -344,6 +346,15 @@ class _Conv3x3Act(Function):
         if torch.is_grad_enabled():     # create_graph=True (R1, train.py:194-200): differentiable backward
             return _conv_act_graph_backward(ctx, gout, x, weight, out, "s1", (H, W)) + (None, None, None)
         gout = gout.contiguous()
+        if (WINO_DGRAD and FUSE_ACT_DGRAD and ctx.needs_input_grad[0] and not ctx.needs_input_grad[1] and not ctx.needs_input_grad[2]
+                and up_bwd is not None):
+            # frozen D (generator step): only the data gradient is wanted — LeakyReLU backward fused into the Winograd
+            # kernel's input staging, one launch instead of a streaming pass + a conv
+            gx = torch.empty(B, C, H, W, dtype=gout.dtype, device=gout.device)
+            with _lib.on_device(gout):
+                _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(gout), _lib.ptr(out), _lib.ptr(up_bwd), B, C, cout,
+                          H, W, 0.2, SQRT2)
+            return gx, None, None, None, None, None
         gz = torch.empty_like(gout)
         gbias = torch.zeros(cout, dtype=gout.dtype, device=gout.device) if ctx.needs_input_grad[2] else None
         gx = gweight = None
@@ -563,8 +574,10 @@ class _ToRGB(Function):
         with _lib.on_device(x):
             _lib.call("cagc_torgb_bwd", _lib.ptr(gx), _lib.ptr(gws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(w2), _lib.ptr(s), B, C,
                       H, W, scale)
-        gweight = (scale * torch.einsum("bc,boc->oc", s, gws)).reshape(1, 3, C, 1, 1)
-        gs = scale * torch.einsum("oc,boc->bc", w2, gws)
+        gweight = torch.empty(1, 3, C, 1, 1, dtype=x.dtype, device=x.device)
+        gs = torch.empty(B, C, dtype=x.dtype, device=x.device)
+        with _lib.on_device(x):
+            _lib.call("cagc_torgb_bwd_finish", _lib.ptr(gweight), _lib.ptr(gs), _lib.ptr(gws), _lib.ptr(s), _lib.ptr(w2), B, C, scale)
         gbias = g.sum([0, 2, 3]).reshape(1, 3, 1, 1)
         gskip = None
         if ctx.has_skip:

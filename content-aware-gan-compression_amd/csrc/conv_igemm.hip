@@ -27,6 +27,7 @@
 // Layers with too few pixel tiles to fill 256 CUs (4x4 .. 16x16) are split over K (channels) across
 // workgroups; partial sums are combined with fp32 atomics and the non-linear epilogue runs as a separate pass.
 #include "common.h"
+#include "prep_device.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -443,29 +444,15 @@ __global__ __launch_bounds__(256) void k_styled_epilogue(float* __restrict__ out
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_weights(float* __restrict__ wp, const float* __restrict__ w, int Cout,
                                                       int Cin, int kk, int Kp, int Mp, float scale, int transpose) {
-  // dest = MFMA A-operand order [t][Kp/4][Mp/16][k % 4][m % 16]: the 64 floats of one (tap, K-step, channel block) are the
-  // 64 lanes' operands of one v_mfma_f32_16x16x4_f32 (lane = (k % 4) * 16 + m % 16), contiguous in memory
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)kk * Kp * Mp;
-  if (idx >= total) return;
-  const int ln = (int)(idx & 63);
-  int64_t q = idx >> 6;
-  const int mblk = (int)(q % (Mp / 16)); q /= (Mp / 16);
-  const int kq = (int)(q % (Kp / 4));
-  const int t = (int)(q / (Kp / 4));
-  const int k = 4 * kq + (ln >> 4), m = 16 * mblk + (ln & 15);
-  const int o = transpose ? k : m, i = transpose ? m : k;
-  float v = 0.f;
-  if (o < Cout && i < Cin) v = w[((int64_t)o * Cin + i) * kk + t] * scale;
-  wp[idx] = v;
+  if (idx >= (int64_t)kk * Kp * Mp) return;
+  pack_weights_elem(wp, w, idx, Cout, Cin, kk, Kp, Mp, scale, transpose);
 }
 __global__ __launch_bounds__(256) void k_wsq(float* __restrict__ wsq, const float* __restrict__ w, int64_t n, int kk,
                                              float scale2) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
-  float a = 0.f;
-  for (int t = 0; t < kk; ++t) { const float v = w[idx * kk + t]; a += v * v; }
-  wsq[idx] = a * scale2;
+  wsq_elem(wsq, w, idx, kk, scale2);
 }
 
 // -------------------------------------------------------------------------------------------------

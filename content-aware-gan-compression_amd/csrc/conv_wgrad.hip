@@ -11,6 +11,7 @@
 // `scale` and writes the [Cout,Cin,k,k] layout.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace cagc {
 
@@ -153,7 +154,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs A) {
 }
 
 __global__ __launch_bounds__(256) void k_wgrad_reduce(float* __restrict__ gw, const float* __restrict__ ws, int Cout,
-                                                      int Cin, int ntaps, int Mp32, int Np32, int nsplit, float scale) {
+                                                      int Cin, int ntaps, int Mp32, int Np32, int nsplit, float scale,
+                                                      const float* __restrict__ gwsq, const float* __restrict__ w,
+                                                      float dscale) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over [ntaps][Cout][Cin]: slab order, coalesced reads
   if (idx >= (int64_t)Cout * Cin * ntaps) return;
   const int i = (int)(idx % Cin);
@@ -168,7 +171,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(float* __restrict__ gw, co
     a2 += p[(int64_t)(sidx + 2) * slab]; a3 += p[(int64_t)(sidx + 3) * slab];
   }
   for (; sidx < nsplit; ++sidx) a0 += p[(int64_t)sidx * slab];
-  gw[((int64_t)o * Cin + i) * ntaps + t] = ((a0 + a1) + (a2 + a3)) * scale;
+  float v = ((a0 + a1) + (a2 + a3)) * scale;
+  // demodulation branch of the weight gradient (model.py:252: d depends on W): dL/dW += 2 scale^2 * gwsq[o,i] * W[o,i,t]
+  if (gwsq) v += dscale * gwsq[(int64_t)o * Cin + i] * w[((int64_t)o * Cin + i) * ntaps + t];
+  gw[((int64_t)o * Cin + i) * ntaps + t] = v;
 }
 
 
@@ -323,6 +329,178 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)
   }
 }
 
+// ---- v2 with register-prefetched staging ("issue early, write late") -------------------------------------------------
+// Same tiles, MFMA schedule and slab output as k_wgrad2.  The global loads of the NEXT pixel tile are issued before the
+// MFMA phase of the current one and only written to LDS after it, so their latency (and the s[b,i] scale fetch) hides
+// behind ~TH*TW/4 K-steps of matrix work instead of sitting between two barriers.
+// Staging map: a thread owns ONE float4 position of the per-channel tile (plane, row, 4 columns) and walks over channels,
+// so every address is affine in the iteration (no descriptor registers, row / column masks evaluated once per tile).
+// Per-thread budget: at most 4*MB (A) + 4*NB (B) float4 — wgrad2_pf_ok() checks the geometry against it.
+template <int MB, int NB>
+__global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 + (4 * MB + 4 * NB) * 4 + 110 <= 256) ? 2 : 1)) void k_wgrad2_pf(const Wg2Args A) {
+  constexpr int MT = MB * 16, NT = NB * 16;
+  constexpr int PPW = (9 * NB + 3) / 4;
+  constexpr int MAXA = 4 * MB, MAXB = 4 * NB;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* a_lds = smem;
+  float* b_lds = smem + MT * A.ACS;
+  const int tid = threadIdx.x, lane = tid & 63, lm = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int o0 = blockIdx.x * MT, i0 = blockIdx.y * NT, sp = blockIdx.z;
+  const int TH = A.TH, TW = A.TW, QA = TW >> 2;
+
+  int p_aoff[PPW], p_boff[PPW], p_tap[PPW], p_nb[PPW];
+  bool p_ok[PPW], p_newa[PPW];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int tp = A.pair_tap[wave][q];
+    p_ok[q] = tp >= 0;
+    const int tap = p_ok[q] ? tp : 0;
+    const int nb = p_ok[q] ? A.pair_nb[wave][q] : 0;
+    p_newa[q] = A.pair_newa[wave][q] != 0;
+    p_tap[q] = tap; p_nb[q] = nb;
+    p_aoff[q] = A.a_off[tap];
+    p_boff[q] = A.b_off[tap] + nb * 16 * A.BCS;
+  }
+  f32x4 acc[PPW][MB];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q)
+#pragma unroll
+    for (int i = 0; i < MB; ++i) acc[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // A: PA = NPA*TH*QA float4 positions per channel, cpa = 256 / PA channels per pass
+  const int PA = A.NPA * TH * QA, cpa = 256 / PA;
+  const int a_pos = tid % PA, a_c0 = tid / PA;
+  const bool a_on = a_c0 < cpa;
+  const int a_q = a_pos % QA, a_row = a_pos / QA;            // a_row = pl * TH + iy
+  const int a_pl = a_row / TH, a_iy = a_row - a_pl * TH;
+  const int a_gpos = (a_pl * A.AHg + a_iy) * A.APitch + 4 * a_q;
+  const int a_lpos = a_row * TW + 4 * a_q;
+  const int a_cstride = A.NPA * A.AHg * A.APitch;
+  // B: PB = BH*QB positions per channel
+  const int PB = A.BH * A.QB, cpb = 256 / PB;
+  const int b_pos = tid % PB, b_c0 = tid / PB;
+  const bool b_on = b_c0 < cpb;
+  const int b_q = b_pos % A.QB, b_iy = b_pos / A.QB;
+  const int b_gpos = b_iy * A.W + 4 * b_q;
+  const int b_lpos = b_iy * A.BWp + 4 * b_q;
+  const int b_cstride = A.H * A.W;
+
+  float4 ra[MAXA], rb[MAXB];
+  const int64_t a_img = (int64_t)A.Cout * a_cstride, b_img = (int64_t)A.Cin * b_cstride;
+
+  auto load_tile = [&](int tile) {
+    int t2 = tile;
+    const int txi = t2 % A.tiles_x; t2 /= A.tiles_x;
+    const int tyi = t2 % A.tiles_y;
+    const int b = t2 / A.tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;
+    {
+      const int gy = y0 + a_iy, gx = x0 + 4 * a_q;
+      const bool ok = a_on && gy < A.Hk && gx + 4 <= A.APitch;
+      const bool m0 = gx + 0 >= A.Wk, m1 = gx + 1 >= A.Wk, m2 = gx + 2 >= A.Wk, m3 = gx + 3 >= A.Wk;
+      const float* src = A.ga + (int64_t)b * a_img + (int64_t)y0 * A.APitch + x0 + a_gpos + (int64_t)(o0 + a_c0) * a_cstride;
+#pragma unroll
+      for (int it = 0; it < MAXA; ++it) {
+        const int oc = a_c0 + it * cpa;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && oc < MT && o0 + oc < A.Cout) v = *reinterpret_cast<const float4*>(src + (int64_t)it * cpa * a_cstride);
+        if (m3) { v.w = 0.f; if (m2) v.z = 0.f; if (m1) v.y = 0.f; if (m0) v.x = 0.f; }
+        ra[it] = v;
+      }
+    }
+    {
+      const int gy = y0 + A.b_y0 + b_iy, gx = x0 - 4 + 4 * b_q;
+      const bool ok = b_on && gy >= 0 && gy < A.H && gx >= 0 && gx + 4 <= A.W;
+      const float* src = A.x + (int64_t)b * b_img + (int64_t)(y0 + A.b_y0) * A.W + x0 - 4 + b_gpos + (int64_t)(i0 + b_c0) * b_cstride;
+      const float* sp_ = A.s ? A.s + b * A.Cin + i0 + b_c0 : nullptr;
+#pragma unroll
+      for (int it = 0; it < MAXB; ++it) {
+        const int ic = b_c0 + it * cpb;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && ic < NT && i0 + ic < A.Cin) {
+          v = *reinterpret_cast<const float4*>(src + (int64_t)it * cpb * b_cstride);
+          const float sc = sp_ ? sp_[it * cpb] : 1.f;
+          v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        }
+        rb[it] = v;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+    if (a_on) {
+#pragma unroll
+      for (int it = 0; it < MAXA; ++it) {
+        const int oc = a_c0 + it * cpa;
+        if (oc < MT) {
+          float* dst = a_lds + oc * A.ACS + a_lpos;
+          *reinterpret_cast<float2*>(dst) = make_float2(ra[it].x, ra[it].y);
+          *reinterpret_cast<float2*>(dst + 2) = make_float2(ra[it].z, ra[it].w);
+        }
+      }
+    }
+    if (b_on) {
+#pragma unroll
+      for (int it = 0; it < MAXB; ++it) {
+        const int ic = b_c0 + it * cpb;
+        if (ic < NT) {
+          float* dst = b_lds + ic * A.BCS + b_lpos;
+          *reinterpret_cast<float2*>(dst) = make_float2(rb[it].x, rb[it].y);
+          *reinterpret_cast<float2*>(dst + 2) = make_float2(rb[it].z, rb[it].w);
+        }
+      }
+    }
+  };
+
+  if (sp < A.ntiles) load_tile(sp);
+  for (int tile = sp; tile < A.ntiles; tile += A.nsplit) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (tile + A.nsplit < A.ntiles) load_tile(tile + A.nsplit);   // in flight during the MFMA phase below
+    for (int row = 0; row < TH; ++row) {
+      for (int s4 = 0; s4 < QA; ++s4) {
+        const int px = 4 * s4 + g;
+        const int ao = row * TW + px, bo = row * A.BWp + px;
+        float av[MB];
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+          if (p_ok[q]) {
+            if (p_newa[q]) {
+#pragma unroll
+              for (int i = 0; i < MB; ++i) av[i] = a_lds[(i * 16 + lm) * A.ACS + p_aoff[q] + ao];
+            }
+            const float bv = b_lds[lm * A.BCS + p_boff[q] + bo];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[q][i], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  float* slab = A.ws + (int64_t)sp * A.ntaps * A.Mp * A.Np;
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    if (p_ok[q]) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + i * 16 + 4 * g + r, ii = i0 + p_nb[q] * 16 + lm;
+          slab[((int64_t)p_tap[q] * A.Mp + o) * A.Np + ii] = acc[q][i][r];
+        }
+    }
+  }
+}
+
+// the prefetching variant's static staging budget (4*MB A + 4*NB B float4 per thread) covers this geometry?
+static bool wgrad2_pf_ok(const Wg2Args& a, int mb, int nb) {
+  const int PA = a.NPA * a.TH * (a.TW / 4), PB = a.BH * a.QB;
+  if (PA > 256 || PB > 256) return false;
+  const int cpa = 256 / PA, cpb = 256 / PB;
+  return cdiv(mb * 16, cpa) <= 4 * mb && cdiv(nb * 16, cpb) <= 4 * nb && getenv("CAGC_WGRAD_NOPF") == nullptr;
+}
+
 struct Wg2Plan { int mb, nb; };
 static Wg2Plan wg2_plan(int Cout, int Cin) {
   // least padded work first; among equals prefer a plan that runs 2 waves / SIMD (<= 110 accumulator registers), then
@@ -428,7 +606,16 @@ static int launch_wgrad2(Wg2Args& a, hipStream_t st, const char* what) {
     attr[dev] = true;
   }
   dim3 grid(a.Mp / (16 * MB), a.Np / (16 * NB), a.nsplit);
-  hipLaunchKernelGGL((k_wgrad2<MB, NB>), grid, dim3(256), smem, st, a);
+  if (wgrad2_pf_ok(a, MB, NB)) {
+    static bool attr_pf[64] = {};
+    if (dev >= 0 && dev < 64 && !attr_pf[dev]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad2_pf<MB, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_pf[dev] = true;
+    }
+    hipLaunchKernelGGL((k_wgrad2_pf<MB, NB>), grid, dim3(256), smem, st, a);
+  } else {
+    hipLaunchKernelGGL((k_wgrad2<MB, NB>), grid, dim3(256), smem, st, a);
+  }
   return check_launch(what);
 }
 
@@ -504,7 +691,15 @@ extern "C" int64_t cagc_modconv_wgrad_workspace(int B, int Cin, int Cout, int H,
 extern "C" int cagc_modconv_wgrad(float* gweight, float* workspace, const float* g, const float* x, const float* s,
                                   int B, int Cin, int Cout, int H, int W, int ksize, int up, float scale,
                                   cagc_stream_t stream) {
+  return cagc_modconv_wgrad_demod(gweight, workspace, g, x, s, nullptr, nullptr, B, Cin, Cout, H, W, ksize, up, scale, stream);
+}
+
+extern "C" int cagc_modconv_wgrad_demod(float* gweight, float* workspace, const float* g, const float* x, const float* s,
+                                        const float* gwsq, const float* weight, int B, int Cin, int Cout, int H, int W,
+                                        int ksize, int up, float scale, cagc_stream_t stream) {
   const char* what = "cagc_modconv_wgrad";
+  CAGC_REQUIRE(!gwsq || weight, "%s: the demodulation term needs the weight tensor", what);
+  const float dscale = 2.f * scale * scale;
   CAGC_REQUIRE(gweight && workspace && g && x, "%s: null tensor", what);
   CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
   CAGC_REQUIRE(ksize == 3 || (ksize == 1 && !up), "%s: unsupported ksize/up", what);
@@ -528,7 +723,7 @@ extern "C" int cagc_modconv_wgrad(float* gweight, float* workspace, const float*
     if (rc2) return rc2;
     const int64_t n2 = (int64_t)Cout * Cin * b.ntaps;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n2, 256)), dim3(256), 0, st2, gweight, workspace, Cout, Cin, b.ntaps, b.Mp,
-                       b.Np, b.nsplit, scale);
+                       b.Np, b.nsplit, scale, gwsq, weight, dscale);
     return check_launch("cagc_modconv_wgrad(reduce)");
   }
   WgArgs a;
@@ -560,6 +755,6 @@ extern "C" int cagc_modconv_wgrad(float* gweight, float* workspace, const float*
   if (rc) return rc;
   const int64_t n = (int64_t)Cout * Cin * a.ntaps;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n, 256)), dim3(256), 0, st, gweight, workspace, Cout, Cin, a.ntaps, a.Mp32,
-                     a.Np32, a.nsplit, scale);
+                     a.Np32, a.nsplit, scale, gwsq, weight, dscale);
   return check_launch("cagc_modconv_wgrad(reduce)");
 }

@@ -25,6 +25,7 @@
 // epilogue — same contract as cagc_modconv_fwd.  The data gradient of such a conv is the same kernel on weights
 // packed with flipped taps and swapped channel roles (cagc_wino_prep(..., dgrad = 1)).
 #include "common.h"
+#include "prep_device.h"
 #include <string.h>
 
 namespace cagc {
@@ -41,6 +42,8 @@ struct WinoArgs {
   float* out;
   const float* up;         // [mtiles][16][Kp/4][64][4]  (k_wino_pack)
   const float* in_scale;   // [B,Cin] or null
+  const float* gate;       // [B,Cin,H,W] or null: the staged input is multiplied by lrelu'(gate) = (gate > 0 ? 1 : gate_alpha) * gate_scale
+  float gate_alpha, gate_scale;
   const float* out_scale;  // [B,Cout] or null
   const float* noise;
   const float* noise_w;
@@ -51,7 +54,7 @@ struct WinoArgs {
   float alpha, act_scale;
 };
 
-template <int MB>
+template <int MB, bool GATED>
 __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   constexpr int CK = WCK;
   constexpr int MT = MB * 16;
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
     e_goff[i] = goff; e_loff[i] = loff; e_meta[i] = meta;
   }
   float4 rin[2];
+  float4 rgt[GATED ? 2 : 1];
   float rsc[2];
   auto prefetch = [&](int j) {   // global -> registers, chunk j (no-op past the end)
     const int kc = j * CK;
@@ -116,8 +120,10 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
       const bool ok = (meta & 1) && (kc + c < A.Cin);
       rin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       rsc[i] = 1.f;
+      if (GATED) rgt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) {
         rin[i] = *reinterpret_cast<const float4*>(A.in + (int64_t)e_goff[i] + (int64_t)kc * HW);
+        if (GATED) rgt[i] = *reinterpret_cast<const float4*>(A.gate + (int64_t)e_goff[i] + (int64_t)kc * HW);
         if (A.in_scale) rsc[i] = A.in_scale[b * A.Cin + kc + c];
       }
     }
@@ -128,6 +134,11 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
       if (e_meta[i] & 0x40000000) {
         float4 v = rin[i];
         const float s = rsc[i];
+        if (GATED) {   // fused LeakyReLU backward: the conv input is gout * lrelu'(out)
+          const float4 gt = rgt[i];
+          const float hi = A.gate_scale, lo = A.gate_alpha * A.gate_scale;
+          v.x *= gt.x > 0.f ? hi : lo; v.y *= gt.y > 0.f ? hi : lo; v.z *= gt.z > 0.f ? hi : lo; v.w *= gt.w > 0.f ? hi : lo;
+        }
         v.x *= s; v.y *= s; v.z *= s; v.w *= s;
         *reinterpret_cast<float4*>(rbuf + e_loff[i]) = v;
       }
@@ -278,55 +289,14 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   }
 }
 
-// U[xi=(i,j)][k][m] = scale * sum_{a,b} G[i][a] g[a][b] G[j][b],  g = w[o][c] (fwd: k=c, m=o) or the flipped kernel with
-// swapped channel roles (dgrad: k=o, m=c, g[a][b] = w[o][c][2-a][2-b]);  stored in MFMA A-operand order
-//   up[mtile][xi][k/4][k%4][m%16][4]  with m = mtile*MT + blk*16 + m%16, blk < MB = MT/16 (zero beyond)
 __global__ __launch_bounds__(256) void k_wino_pack(float* __restrict__ up, const float* __restrict__ w, int Cout, int Cin,
                                                    int Kp, int mtiles, int MB, float scale, int dgrad) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over [mtiles][Kp/4][64][4]
   if (idx >= (int64_t)mtiles * Kp * 64) return;
-  const int blk = (int)(idx & 3), ln = (int)((idx >> 2) & 63);
-  const int kq = (int)((idx >> 8) % (Kp / 4)), mt = (int)((idx >> 8) / (Kp / 4));
-  const int k = 4 * kq + (ln >> 4), m = mt * MB * 16 + blk * 16 + (ln & 15);
-  const int o = dgrad ? k : m, c = dgrad ? m : k;
-  float gk[3][3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int bb = 0; bb < 3; ++bb) {
-      float v = 0.f;
-      if (blk < MB && o < Cout && c < Cin) v = w[((int64_t)o * Cin + c) * 9 + (dgrad ? (2 - a) * 3 + (2 - bb) : a * 3 + bb)] * scale;
-      gk[a][bb] = v;
-    }
-  float t[4][3];
-#pragma unroll
-  for (int bb = 0; bb < 3; ++bb) {
-    t[0][bb] = gk[0][bb];
-    t[1][bb] = 0.5f * (gk[0][bb] + gk[1][bb] + gk[2][bb]);
-    t[2][bb] = 0.5f * (gk[0][bb] - gk[1][bb] + gk[2][bb]);
-    t[3][bb] = gk[2][bb];
-  }
-  const int64_t xs = (int64_t)(Kp / 4) * 256;                                  // stride between positions xi
-  float* dst = up + ((int64_t)mt * 16 * (Kp / 4) + kq) * 256 + ln * 4 + blk;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
-    dst[(4 * i + 0) * xs] = u0;
-    dst[(4 * i + 1) * xs] = u1;
-    dst[(4 * i + 2) * xs] = u2;
-    dst[(4 * i + 3) * xs] = u3;
-  }
+  wino_pack_elem(up, w, idx, Cout, Cin, Kp, MB, scale, dgrad);
 }
 
-// channel blocks (of 16) per workgroup tile for M output channels: 4, or fewer when that wastes less of the last tile
-static int wino_mb(int M) {
-  const int nblk = cdiv(M, 16);
-  if (nblk <= 3) return nblk;
-  if (nblk % 4 != 0 && nblk % 3 == 0) return 3;
-  return 4;
-}
-
-template <int MB>
+template <int MB, bool GATED = false>
 static int launch_wino(WinoArgs& a, hipStream_t st, const char* what) {
   constexpr int MT = MB * 16;
   size_t smem = sizeof(float) * ((size_t)2 * 16 * WCK * W_VS + (size_t)2 * WCK * (W_IH * W_IWP + 16));
@@ -336,12 +306,12 @@ static int launch_wino(WinoArgs& a, hipStream_t st, const char* what) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino<MB, GATED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr[dev] = true;
   }
   a.mtiles = cdiv(a.Cout, MT);
   CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
-  hipLaunchKernelGGL((k_wino<MB>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(512), smem, st, a);
+  hipLaunchKernelGGL((k_wino<MB, GATED>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(512), smem, st, a);
   return check_launch(what);
 }
 
@@ -394,5 +364,33 @@ extern "C" int cagc_wino_conv3x3(float* out, const float* x, const float* up, co
     case 2: return launch_wino<2>(a, st, what);
     case 3: return launch_wino<3>(a, st, what);
     default: return launch_wino<4>(a, st, what);
+  }
+}
+
+// Data gradient of `conv3x3 -> + bias -> LeakyReLU * act_scale` (the discriminator's ConvLayer, model.py:694-716) in ONE
+// launch: the LeakyReLU backward gout * lrelu'(act_out) is applied while the input tile is staged, so the separate
+// cagc_fused_bias_act_bwd pass (12 B per element of HBM traffic) disappears when no bias / weight gradient is wanted
+// (D frozen on the generator step).  up = cagc_wino_prep(..., dgrad = 1) packing; channels: gout/act_out [B,Cout,H,W] ->
+// gx [B,Cin,H,W].
+extern "C" int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const float* act_out, const float* up, int B, int Cin,
+                                           int Cout, int H, int W, float alpha, float act_scale, cagc_stream_t stream) {
+  const char* what = "cagc_wino_conv3x3_act_dgrad";
+  CAGC_REQUIRE(gx && gout && act_out && up, "%s: null tensor", what);
+  CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
+  CAGC_REQUIRE(cagc_wino_eligible(H, W), "%s: needs H %% 8 == 0 and W %% 32 == 0 (got %dx%d)", what, H, W);
+  CAGC_REQUIRE(((uintptr_t)gout % 16) == 0 && ((uintptr_t)act_out % 16) == 0 && ((uintptr_t)gx % 8) == 0, "%s: unaligned tensor", what);
+  CAGC_REQUIRE((int64_t)B * Cout * H * W < (1ll << 31), "%s: input too large for 32-bit offsets", what);
+  WinoArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = gout; a.gate = act_out; a.gate_alpha = alpha; a.gate_scale = act_scale; a.out = gx; a.up = up;
+  a.B = B; a.Cin = Cout; a.Kp = round_up(Cout, WCK); a.Cout = Cin; a.Mp = round_up(Cin, 16); a.H = H; a.W = W;
+  a.tiles_x = W / WTW; a.tiles_y = H / WTH; a.nblocks = B * a.tiles_x * a.tiles_y;
+  a.epi = CAGC_EPI_LINEAR; a.alpha = alpha; a.act_scale = 1.f;
+  hipStream_t st = as_stream(stream);
+  switch (wino_mb(Cin)) {
+    case 1: return launch_wino<1, true>(a, st, what);
+    case 2: return launch_wino<2, true>(a, st, what);
+    case 3: return launch_wino<3, true>(a, st, what);
+    default: return launch_wino<4, true>(a, st, what);
   }
 }

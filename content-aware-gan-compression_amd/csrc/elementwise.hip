@@ -526,3 +526,71 @@ extern "C" int cagc_to_phase_planar(float* t, const float* x, int64_t planes, in
   }
   return cagc::check_launch("cagc_to_phase_planar");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small "finish" kernels of the styled-conv / ToRGB backward: the handful of [B,C]-sized reductions and products that
+// were a dozen PyTorch launches per layer (the step is launch-bound at small per-GPU batch).  One workgroup each.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace cagc {
+// red [3,B,C] from cagc_styled_act_bwd:  gbias[c] = sum_b red0;  gnw = sum red1;  gd[b,c] = (red2 - bias[c]*red0 - nw*red1) / d[b,c]
+// (z = (pre - nw*noise - bias) / d  =>  dL/dd = sum_p gpre * z);  also zero-fills `zero_ptr[0..zero_n)` (the style-gradient
+// accumulator the data-gradient kernel adds into).
+__global__ __launch_bounds__(256) void k_styled_bwd_finish(float* __restrict__ gbias, float* __restrict__ gnw, float* __restrict__ gd,
+                                                           float* __restrict__ zero_ptr, int zero_n, const float* __restrict__ red,
+                                                           const float* __restrict__ bias, const float* __restrict__ noise_w,
+                                                           const float* __restrict__ d, int B, int C, int has_noise) {
+  __shared__ float sm[4];
+  const int tid = threadIdx.x, n = B * C;
+  const float nw = (has_noise && noise_w) ? noise_w[0] : 0.f;
+  float acc1 = 0.f;
+  for (int idx = tid; idx < n; idx += 256) {
+    const float r0 = red[idx], r1 = red[n + idx], r2 = red[2 * n + idx];
+    if (has_noise) acc1 += r1;
+    if (gd) gd[idx] = (r2 - bias[idx % C] * r0 - nw * r1) / d[idx];
+  }
+  if (gbias)
+    for (int c = tid; c < C; c += 256) {
+      float a = 0.f;
+      for (int b = 0; b < B; ++b) a += red[b * C + c];
+      gbias[c] = a;
+    }
+  for (int i = tid; i < zero_n; i += 256) zero_ptr[i] = 0.f;
+  if (gnw) {
+    const float t = block_sum(acc1, sm);
+    if (tid == 0) gnw[0] = t;
+  }
+}
+// ToRGB backward tail: gws [B,3,C] (cagc_torgb_bwd) -> gw[o,c] = scale sum_b s[b,c] gws[b,o,c];  gs[b,c] = scale sum_o w[o,c] gws[b,o,c]
+__global__ __launch_bounds__(256) void k_torgb_bwd_finish(float* __restrict__ gw, float* __restrict__ gs, const float* __restrict__ gws,
+                                                          const float* __restrict__ s, const float* __restrict__ w, int B, int C,
+                                                          float scale) {
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < 3 * C; idx += 256) {
+    const int o = idx / C, c = idx - o * C;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += s[b * C + c] * gws[(b * 3 + o) * C + c];
+    gw[idx] = a * scale;
+  }
+  for (int idx = tid; idx < B * C; idx += 256) {
+    const int b = idx / C, c = idx - b * C;
+    const float* g = gws + (int64_t)b * 3 * C + c;
+    gs[idx] = scale * (w[c] * g[0] + w[C + c] * g[C] + w[2 * C + c] * g[2 * C]);
+  }
+}
+}  // namespace cagc
+extern "C" int cagc_styled_bwd_finish(float* gbias, float* gnw, float* gd, float* zero_ptr, int zero_n, const float* red,
+                                      const float* bias, const float* noise_w, const float* d, int B, int C, int has_noise,
+                                      cagc_stream_t stream) {
+  CAGC_REQUIRE(red && B > 0 && C > 0 && zero_n >= 0, "cagc_styled_bwd_finish: bad argument");
+  CAGC_REQUIRE(!gd || (d && bias), "cagc_styled_bwd_finish: gd needs d and bias");
+  CAGC_REQUIRE(!has_noise || noise_w, "cagc_styled_bwd_finish: noise weight missing");
+  hipLaunchKernelGGL(cagc::k_styled_bwd_finish, dim3(1), dim3(256), 0, cagc::as_stream(stream), gbias, gnw, gd, zero_ptr, zero_n,
+                     red, bias, noise_w, d, B, C, has_noise);
+  return cagc::check_launch("cagc_styled_bwd_finish");
+}
+extern "C" int cagc_torgb_bwd_finish(float* gw, float* gs, const float* gws, const float* s, const float* w, int B, int C,
+                                     float scale, cagc_stream_t stream) {
+  CAGC_REQUIRE(gw && gs && gws && s && w && B > 0 && C > 0, "cagc_torgb_bwd_finish: bad argument");
+  hipLaunchKernelGGL(cagc::k_torgb_bwd_finish, dim3(1), dim3(256), 0, cagc::as_stream(stream), gw, gs, gws, s, w, B, C, scale);
+  return cagc::check_launch("cagc_torgb_bwd_finish");
+}

@@ -1,0 +1,65 @@
+// One-launch weight preparation of a TRAINABLE layer (its weights change every optimiser step, so everything derived from
+// them is rebuilt every forward): MFMA-packed forward / backward operands, wsq for the demodulation, and the
+// Winograd-domain forward / data-gradient operands — five jobs that were five launches (cagc_modconv_prep x3 kernels,
+// cagc_wino_prep x2).  Blocks are dealt to the jobs by prefix sums; each job is the per-element body of prep_device.h.
+#include "common.h"
+#include "prep_device.h"
+
+namespace cagc {
+
+struct PrepAllArgs {
+  const float* w;
+  float* out[5];      // wp_fwd, wp_bwd, wsq, up_fwd, up_bwd (null = skipped)
+  int64_t n[5];       // elements of each job
+  int end[5];         // block prefix sums
+  int Cout, Cin, kk;
+  int Kp_f, Mp_f, Kp_b, Mp_b;           // packed dims fwd / bwd
+  int wKp_f, wMB_f, wKp_b, wMB_b;       // Winograd packing dims
+  float scale;
+};
+
+__global__ __launch_bounds__(256) void k_prep_all(const PrepAllArgs A) {
+  int job = 0;
+  while (job < 4 && (int)blockIdx.x >= A.end[job]) ++job;
+  const int b0 = job ? A.end[job - 1] : 0;
+  const int64_t idx = (int64_t)(blockIdx.x - b0) * 256 + threadIdx.x;
+  if (idx >= A.n[job]) return;
+  switch (job) {
+    case 0: pack_weights_elem(A.out[0], A.w, idx, A.Cout, A.Cin, A.kk, A.Kp_f, A.Mp_f, A.scale, 0); break;
+    case 1: pack_weights_elem(A.out[1], A.w, idx, A.Cout, A.Cin, A.kk, A.Kp_b, A.Mp_b, A.scale, 1); break;
+    case 2: wsq_elem(A.out[2], A.w, idx, A.kk, A.scale * A.scale); break;
+    case 3: wino_pack_elem(A.out[3], A.w, idx, A.Cout, A.Cin, A.wKp_f, A.wMB_f, A.scale, 0); break;
+    default: wino_pack_elem(A.out[4], A.w, idx, A.Cout, A.Cin, A.wKp_b, A.wMB_b, A.scale, 1); break;
+  }
+}
+
+}  // namespace cagc
+
+using namespace cagc;
+
+extern "C" int cagc_modconv_prep_all(float* wp_fwd, float* wp_bwd, float* wsq, float* up_fwd, float* up_bwd,
+                                     const float* weight, int Cout, int Cin, int ksize, float scale, cagc_stream_t stream) {
+  CAGC_REQUIRE(weight && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "cagc_modconv_prep_all: bad argument");
+  CAGC_REQUIRE(ksize == 3 || (!up_fwd && !up_bwd), "cagc_modconv_prep_all: Winograd operands need a 3x3 kernel");
+  PrepAllArgs a;
+  a.w = weight; a.Cout = Cout; a.Cin = Cin; a.kk = ksize * ksize; a.scale = scale;
+  a.Kp_f = round_up(Cin, 4); a.Mp_f = round_up(Cout, 16);
+  a.Kp_b = round_up(Cout, 4); a.Mp_b = round_up(Cin, 16);
+  a.wKp_f = round_up(Cin, 8); a.wMB_f = wino_mb(Cout);
+  a.wKp_b = round_up(Cout, 8); a.wMB_b = wino_mb(Cin);
+  a.out[0] = wp_fwd; a.out[1] = wp_bwd; a.out[2] = wsq; a.out[3] = up_fwd; a.out[4] = up_bwd;
+  a.n[0] = wp_fwd ? (int64_t)a.kk * a.Kp_f * a.Mp_f : 0;
+  a.n[1] = wp_bwd ? (int64_t)a.kk * a.Kp_b * a.Mp_b : 0;
+  a.n[2] = wsq ? (int64_t)Cout * Cin : 0;
+  a.n[3] = up_fwd ? (int64_t)cdiv(Cout, a.wMB_f * 16) * a.wKp_f * 64 : 0;
+  a.n[4] = up_bwd ? (int64_t)cdiv(Cin, a.wMB_b * 16) * a.wKp_b * 64 : 0;
+  int64_t blocks = 0;
+  for (int j = 0; j < 5; ++j) {
+    blocks += (a.n[j] + 255) / 256;
+    CAGC_REQUIRE(blocks < (1ll << 31), "cagc_modconv_prep_all: too large");
+    a.end[j] = (int)blocks;
+  }
+  if (blocks == 0) return CAGC_OK;
+  hipLaunchKernelGGL(k_prep_all, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+  return check_launch("cagc_modconv_prep_all");
+}

@@ -1,0 +1,77 @@
+// Per-element bodies of the weight-preparation kernels (MFMA A-operand packing, wsq, Winograd-domain weights), shared by
+// the stand-alone kernels (conv_igemm.hip k_pack_weights / k_wsq, conv_wino.hip k_wino_pack) and the one-launch
+// k_prep_all (prep.hip) that prepares everything a trainable layer needs per step.
+#pragma once
+#include "common.h"
+
+namespace cagc {
+
+// dest = MFMA A-operand order [t][Kp/4][Mp/16][k % 4][m % 16]: the 64 floats of one (tap, K-step, channel block) are the
+// 64 lanes' operands of one v_mfma_f32_16x16x4_f32 (lane = (k % 4) * 16 + m % 16), contiguous in memory
+__device__ __forceinline__ void pack_weights_elem(float* __restrict__ wp, const float* __restrict__ w, int64_t idx, int Cout,
+                                                  int Cin, int kk, int Kp, int Mp, float scale, int transpose) {
+  const int ln = (int)(idx & 63);
+  int64_t q = idx >> 6;
+  const int mblk = (int)(q % (Mp / 16)); q /= (Mp / 16);
+  const int kq = (int)(q % (Kp / 4));
+  const int t = (int)(q / (Kp / 4));
+  const int k = 4 * kq + (ln >> 4), m = 16 * mblk + (ln & 15);
+  const int o = transpose ? k : m, i = transpose ? m : k;
+  float v = 0.f;
+  if (o < Cout && i < Cin) v = w[((int64_t)o * Cin + i) * kk + t] * scale;
+  wp[idx] = v;
+}
+
+__device__ __forceinline__ void wsq_elem(float* __restrict__ wsq, const float* __restrict__ w, int64_t idx, int kk, float scale2) {
+  float a = 0.f;
+  for (int t = 0; t < kk; ++t) { const float v = w[idx * kk + t]; a += v * v; }
+  wsq[idx] = a * scale2;
+}
+
+// U[xi=(i,j)][k][m] = scale * sum_{a,b} G[i][a] g[a][b] G[j][b],  g = w[o][c] (fwd: k=c, m=o) or the flipped kernel with
+// swapped channel roles (dgrad: k=o, m=c, g[a][b] = w[o][c][2-a][2-b]);  stored in MFMA A-operand order
+//   up[mtile][xi][k/4][k%4][m%16][4]  with m = mtile*MT + blk*16 + m%16, blk < MB = MT/16 (zero beyond);  idx over [mtiles][Kp/4][64][4]
+__device__ __forceinline__ void wino_pack_elem(float* __restrict__ up, const float* __restrict__ w, int64_t idx, int Cout, int Cin,
+                                               int Kp, int MB, float scale, int dgrad) {
+  const int blk = (int)(idx & 3), ln = (int)((idx >> 2) & 63);
+  const int kq = (int)((idx >> 8) % (Kp / 4)), mt = (int)((idx >> 8) / (Kp / 4));
+  const int k = 4 * kq + (ln >> 4), m = mt * MB * 16 + blk * 16 + (ln & 15);
+  const int o = dgrad ? k : m, c = dgrad ? m : k;
+  float gk[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      float v = 0.f;
+      if (blk < MB && o < Cout && c < Cin) v = w[((int64_t)o * Cin + c) * 9 + (dgrad ? (2 - a) * 3 + (2 - bb) : a * 3 + bb)] * scale;
+      gk[a][bb] = v;
+    }
+  float t[4][3];
+#pragma unroll
+  for (int bb = 0; bb < 3; ++bb) {
+    t[0][bb] = gk[0][bb];
+    t[1][bb] = 0.5f * (gk[0][bb] + gk[1][bb] + gk[2][bb]);
+    t[2][bb] = 0.5f * (gk[0][bb] - gk[1][bb] + gk[2][bb]);
+    t[3][bb] = gk[2][bb];
+  }
+  const int64_t xs = (int64_t)(Kp / 4) * 256;                                  // stride between positions xi
+  float* dst = up + ((int64_t)mt * 16 * (Kp / 4) + kq) * 256 + ln * 4 + blk;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
+    dst[(4 * i + 0) * xs] = u0;
+    dst[(4 * i + 1) * xs] = u1;
+    dst[(4 * i + 2) * xs] = u2;
+    dst[(4 * i + 3) * xs] = u3;
+  }
+}
+
+// channel blocks (of 16) per Winograd workgroup tile for M output channels: 4, or fewer when that wastes less of the last tile
+inline int wino_mb(int M) {
+  const int nblk = cdiv(M, 16);
+  if (nblk <= 3) return nblk;
+  if (nblk % 4 != 0 && nblk % 3 == 0) return 3;
+  return 4;
+}
+
+}  // namespace cagc

@@ -120,6 +120,11 @@ int64_t cagc_modconv_packed_elems(int K, int M, int ksize); /* elements of a pac
 int cagc_modconv_prep(float* wp_fwd, float* wp_bwd, float* wsq, const float* weight, int Cout, int Cin,
                       int ksize, float scale, cagc_stream_t stream);
 
+/* Everything a TRAINABLE 3x3 / 1x1 layer needs per step in ONE launch: the three outputs of cagc_modconv_prep plus the
+ * Winograd-domain operands of cagc_wino_prep (dgrad = 0 -> up_fwd, dgrad = 1 -> up_bwd; 3x3 only).  Any output may be null. */
+int cagc_modconv_prep_all(float* wp_fwd, float* wp_bwd, float* wsq, float* up_fwd, float* up_bwd, const float* weight,
+                          int Cout, int Cin, int ksize, float scale, cagc_stream_t stream);
+
 /* epilogue selectors for cagc_modconv_fwd */
 #define CAGC_EPI_LINEAR 0 /* out = acc * (out_scale ? out_scale[b,o] : 1)                         */
 #define CAGC_EPI_STYLED 1 /* out = lrelu(acc*d[b,o] + noise_w[0]*noise[b?,y,x] + bias[o]) * act_scale
@@ -179,6 +184,25 @@ int cagc_modconv_wgrad(float* gweight, float* workspace, const float* g, const f
                        int B, int Cin, int Cout, int H, int W, int ksize, int up, float scale,
                        cagc_stream_t stream);
 
+/* Same, plus the demodulation branch of the weight gradient folded into the final reduction (model.py:252: d depends on
+ * W through wsq):  gweight += 2 scale^2 * gwsq[o,i] * weight[o,i,k]  with gwsq [Cout,Cin] from cagc_demod_bwd.
+ * gwsq [nullable] -> identical to cagc_modconv_wgrad. */
+int cagc_modconv_wgrad_demod(float* gweight, float* workspace, const float* g, const float* x, const float* s,
+                             const float* gwsq, const float* weight, int B, int Cin, int Cout, int H, int W, int ksize,
+                             int up, float scale, cagc_stream_t stream);
+
+/* Tail of the styled conv's backward (replaces a dozen [B,C]-sized PyTorch launches per layer): from the three
+ * reductions red [3,B,C] of cagc_styled_act_bwd:  gbias[c] = sum_b red0  (FusedLeakyReLU bias gradient, op/fused_act.py:33-39),
+ * gnw[0] = sum red1  (NoiseInjection.weight gradient, model.py:298-303),  gd[b,c] = (red2 - bias[c]*red0 - noise_w*red1) / d[b,c]
+ * (gradient reaching the demodulation factor).  gbias / gnw / gd [nullable].  Also zero-fills zero_ptr[0..zero_n) (the
+ * style-gradient accumulator handed to the data-gradient kernel next). */
+int cagc_styled_bwd_finish(float* gbias, float* gnw, float* gd, float* zero_ptr, int zero_n, const float* red,
+                           const float* bias, const float* noise_w, const float* d, int B, int C, int has_noise,
+                           cagc_stream_t stream);
+/* Tail of ToRGB's backward from gws [B,3,C] (cagc_torgb_bwd): gw [3,C] = scale sum_b s*gws, gs [B,C] = scale sum_o w*gws. */
+int cagc_torgb_bwd_finish(float* gw, float* gs, const float* gws, const float* s, const float* w, int B, int C,
+                          float scale, cagc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Winograd F(2x2,3x3) path          same contract as cagc_modconv_fwd (k = 3, stride 1, "same"), for layers with
  *                                   H % 8 == 0 and W % 32 == 0 (cagc_wino_eligible): 16 GEMMs on transformed 4x4
@@ -194,6 +218,13 @@ int cagc_wino_prep(float* up, const float* weight, int Cout, int Cin, float scal
 int cagc_wino_conv3x3(float* out, const float* x, const float* up, const float* s, int B, int Cin, int Cout, int H,
                       int W, int epi, const float* out_scale, const float* noise, int noise_batch,
                       const float* noise_w, const float* bias, float alpha, float act_scale, cagc_stream_t stream);
+
+/* Data gradient of the discriminator's `EqualConv2d(3x3, pad 1) -> FusedLeakyReLU` (model.py:694-716) with the
+ * activation's backward fused into the conv's input staging:  gx [B,Cin,H,W] = dgrad( gout * lrelu'(act_out) ), where
+ * lrelu'(v) = (v > 0 ? 1 : alpha) * act_scale and up = cagc_wino_prep(..., dgrad = 1).  Replaces fused_bias_act(grad=1)
+ * (op/fused_act.py:29-39) + cuDNN dgrad when neither grad_bias nor grad_weight is wanted (D frozen on the G step). */
+int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const float* act_out, const float* up, int B, int Cin,
+                                int Cout, int H, int W, float alpha, float act_scale, cagc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Discriminator down-sampling conv  replaces the reference's Blur(pad=(2,2)) -> EqualConv2d(3x3, stride 2,

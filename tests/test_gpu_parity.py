@@ -600,6 +600,31 @@ def test_discriminator_conv3x3_act_winograd_vs_oracle(cfg):
         assert_close(a, b, TOL, f"{cfg} grad {nm}")
 
 
+@pytest.mark.parametrize("cfg", [(2, 128, 128, 64, 64), (3, 20, 36, 32, 32), (2, 512, 512, 32, 32), (16, 128, 128, 256, 256)])
+def test_frozen_conv3x3_act_data_gradient_fused_into_winograd_staging(cfg):
+    """Frozen D layer (generator step): cagc_wino_conv3x3_act_dgrad (LeakyReLU backward applied while the Winograd kernel
+    stages its input) == the two-pass path (cagc_fused_bias_act_bwd, then the Winograd data gradient), BIT for bit — the
+    staged product gout * lrelu'(out) is the same fp32 multiplication."""
+    from cagc.op import modconv as mc
+    B, cin, cout, H, W = cfg
+    torch.manual_seed(10)
+    layer = M.ConvLayer(cin, cout, 3).to(DEV)
+    with torch.no_grad():
+        layer[1].bias.copy_(0.1 * torch.randn(cout))
+    kd.requires_grad(layer, False)
+    x = torch.randn(B, cin, H, W, device=DEV, requires_grad=True)
+    go = torch.randn(B, cout, H, W, device=DEV)
+    outs = {}
+    for fused in (True, False):
+        mc.FUSE_ACT_DGRAD = fused
+        try:
+            (outs[fused],) = torch.autograd.grad(layer(x), x, go)
+        finally:
+            mc.FUSE_ACT_DGRAD = True
+    assert torch.equal(outs[True], outs[False])
+    assert torch.isfinite(outs[True]).all() and float(outs[True].abs().max()) > 0
+
+
 @pytest.mark.parametrize("cfg", [(2, 128, 256, 64, 64), (3, 20, 36, 18, 22), (1, 512, 512, 8, 8), (4, 128, 256, 128, 128)])
 def test_discriminator_skip_blur_down_conv1x1_vs_oracle(cfg):
     """ResBlock skip: Blur(pad 1,1) -> 1x1 stride-2 EqualConv2d (no bias / activation) on the fused path (decimating FIR +
