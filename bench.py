@@ -50,6 +50,9 @@ def conv_flops(name, a):
     if name == "cagc_modconv_wgrad":     # (gw,ws,g,x,s,B,Cin,Cout,H,W,k,up,scale)
         B, cin, cout, H, W, k = a[5:11]
         return 2.0 * B * cin * cout * k * k * H * W
+    if name == "cagc_modconv_wgrad_demod":   # (gw,ws,g,x,s,gwsq,weight,B,Cin,Cout,H,W,k,up,scale)
+        B, cin, cout, H, W, k = a[7:13]
+        return 2.0 * B * cin * cout * k * k * H * W
     if name == "cagc_wino_conv3x3":      # (out,x,up,s,B,Cin,Cout,H,W,...): Winograd F(2x2,3x3) — count the flops the
         B, cin, cout, H, W = a[4:9]      # MFMA pipe EXECUTES (16 GEMMs over H/2*W/2 tiles = 4 MACs per output pixel
         return 2.0 * B * cin * cout * 4 * H * W   # and channel pair), not the 9 of the direct conv it replaces
@@ -83,7 +86,8 @@ KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false>", "cagc_wi
              "cagc_wino_conv3x3_act_dgrad[k_wino<4, true>]": "k_wino<4, true>", "cagc_modconv_fwd": "k_conv_igemm<8, 4, true, false, 1>",
              "cagc_modconv_up_fwd": "k_conv_igemm<8, 4, true, false, 1>",
              "cagc_modconv_dgrad": "k_conv_igemm<8, 12, true, false, 1>",
-             "cagc_modconv_up_dgrad": "k_conv_igemm<8, 12, true, false, 1>", "cagc_modconv_wgrad": "k_wgrad2<5, 2>"}
+             "cagc_modconv_up_dgrad": "k_conv_igemm<8, 12, true, false, 1>", "cagc_modconv_wgrad": "k_wgrad2<5, 2>",
+             "cagc_modconv_wgrad_demod": "k_wgrad2<5, 2>"}
 
 
 def pmc_traffic(symbol):

@@ -25,6 +25,8 @@ _PROTOS = {
     "cagc_pixelnorm_bwd": [_p, _p, _p, _i64, _i, _p],
     "cagc_demod_fwd": [_p, _p, _p, _i, _i, _i, _p],
     "cagc_demod_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "cagc_modbank_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "cagc_modbank_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "cagc_phase_pitch": [_i],
     "cagc_modconv_packed_elems": [_i, _i, _i],
     "cagc_modconv_prep": [_p, _p, _p, _p, _i, _i, _i, _f, _p],

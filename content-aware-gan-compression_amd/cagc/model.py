@@ -333,13 +333,14 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, return_style_scalars=False, noise=None):
+    def forward(self, input, style, return_style_scalars=False, noise=None, _s=None):
+        """`_s`: the layer's modulation vector when the caller already has it (Generator's modulation bank)."""
         conv = self.conv
         fused = (conv._hip_eligible(input) and self.activate.bias is not None
                  and self.activate.negative_slope == 0.2 and abs(self.activate.scale - 2 ** 0.5) < 1e-12)
         if fused:
             batch, cin, h, w = input.shape
-            s = conv.modulation(style)
+            s = _s if _s is not None else conv.modulation(style)
             wp_fwd, wp_bwd, wsq, up_w, up_wb = conv.prepared(h, w)
             oh, ow = (2 * h, 2 * w) if conv.upsample else (h, w)
             if noise is None:
@@ -370,14 +371,14 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, input, style, skip=None, return_style_scalars=False):
+    def forward(self, input, style, skip=None, return_style_scalars=False, _s=None):
         conv = self.conv
         up = getattr(self, "upsample", None)
         fused = (mc.use_hip(input) and input.dtype == torch.float32
                  and (skip is None or (up is not None and up.factor == 2 and tuple(up.kernel.shape) == (4, 4)
                                        and up.pad == (2, 1) and skip.shape[2] * 2 == input.shape[2])))
         if fused:
-            s = conv.modulation(style)
+            s = _s if _s is not None else conv.modulation(style)
             out = mc._ToRGB.apply(input, conv.weight, s, self.bias, skip, up.kernel if skip is not None else None)
             styles = s.view(input.shape[0], 1, input.shape[1], 1, 1)
         else:
@@ -457,6 +458,25 @@ class Generator(nn.Module):
         return self._synthesize(noise_z, inject_index, truncation, truncation_latent, latent_styles, input_is_latent,
                                 noise, randomize_noise, return_rgb_list, return_style_scalars, False)
 
+    def _bank_styles(self, latent):
+        """All modulation vectors s_l = modulation_l(latent[:, idx_l]) by one launch of the modulation bank (GPU fp32,
+        first-order mode); None -> the layers evaluate their own EqualLinear."""
+        if not (mc.use_hip(latent) and latent.dtype == torch.float32 and latent.dim() == 3):
+            return None
+        bank = getattr(self, "_mod_bank", None)
+        if bank is None:
+            layers = [(self.conv1.conv.modulation, 0), (self.to_rgb1.conv.modulation, 1)]
+            i = 1
+            for blk, to_rgb in enumerate(self.to_rgbs):
+                layers += [(self.convs[2 * blk].conv.modulation, i), (self.convs[2 * blk + 1].conv.modulation, i + 1),
+                           (to_rgb.conv.modulation, i + 2)]
+                i += 2
+            bank = mc.ModulationBank(layers) if mc.ModulationBank.eligible(layers, self.style_dim) else False
+            object.__setattr__(self, "_mod_bank", bank)      # not a submodule / not in the state dict
+        if bank is False or latent.shape[1] <= max(bank.idx) or latent.shape[2] != 512:
+            return None
+        return bank(latent)
+
     def _synthesize(self, noise_z, inject_index, truncation, truncation_latent, latent_styles, input_is_latent, noise,
                     randomize_noise, return_rgb_list, return_style_scalars, want_latent):
         if input_is_latent:
@@ -487,25 +507,27 @@ class Generator(nn.Module):
 
         rss = return_style_scalars
         styles_list = []
+        bank = self._bank_styles(latent)            # every layer's modulation vector from ONE launch (or None)
+        bs = (lambda k: bank[k]) if bank is not None else (lambda k: None)
         out = self.input(latent)
-        out = self.conv1(out, latent[:, 0], rss, noise=noise[0])
+        out = self.conv1(out, latent[:, 0], rss, noise=noise[0], _s=bs(0))
         if rss:
             out, sc = out
             styles_list.append(sc)
-        skip = self.to_rgb1(out, latent[:, 1])
+        skip = self.to_rgb1(out, latent[:, 1], _s=bs(1))
         rgb_img_list = [skip]
         i = 1
         for blk, to_rgb in enumerate(self.to_rgbs):
             for j in (0, 1):
-                out = self.convs[2 * blk + j](out, latent[:, i + j], rss, noise=noise[2 * blk + 1 + j])
+                out = self.convs[2 * blk + j](out, latent[:, i + j], rss, noise=noise[2 * blk + 1 + j], _s=bs(2 + 3 * blk + j))
                 if rss:
                     out, sc = out
                     styles_list.append(sc)
             if rss and (i + 3) == latent.shape[1]:   # only the last ToRGB reports its scalars (ref :637-639)
-                skip, sc = to_rgb(out, latent[:, i + 2], skip, True)
+                skip, sc = to_rgb(out, latent[:, i + 2], skip, True, _s=bs(4 + 3 * blk))
                 styles_list.append(sc)
             else:
-                skip = to_rgb(out, latent[:, i + 2], skip)
+                skip = to_rgb(out, latent[:, i + 2], skip, _s=bs(4 + 3 * blk))
             rgb_img_list.append(skip)
             i += 2
         image = skip

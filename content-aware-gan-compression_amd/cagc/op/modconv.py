@@ -542,6 +542,91 @@ class _BlurDownConv1x1(Function):
 
 
 # ---------------------------------------------------------------------------------------------------
+# Modulation bank: all `modulation` EqualLinears of a generator in one launch (csrc/modbank.hip)
+# ---------------------------------------------------------------------------------------------------
+class ModulationBank:
+    """Device tables for cagc_modbank_fwd / _bwd over an ordered list of (EqualLinear, latent index).  The tables hold the
+    parameters' device pointers, so they are rebuilt whenever a parameter's storage moves (`.to()`, reload); optimiser
+    steps update parameters in place and keep them valid."""
+
+    def __init__(self, layers):
+        self.lins = [lin for lin, _ in layers]
+        self.idx = [int(i) for _, i in layers]
+        self.cins = [lin.weight.shape[0] for lin in self.lins]
+        self.L, self.Ctot = len(self.lins), sum(self.cins)
+        self.c0 = [sum(self.cins[:i]) for i in range(self.L)]
+        self.scale = float(self.lins[0].scale)
+        self._key, self._wt, self._bt, self._meta = None, None, None, {}
+
+    @staticmethod
+    def eligible(layers, style_dim):
+        return (style_dim == 512 and len(layers) > 0 and
+                all(l.weight.shape[1] == 512 and l.bias is not None and l.lr_mul == 1 and l.activation is None
+                    and l.weight.dtype == torch.float32 and l.weight.is_contiguous() for l, _ in layers))
+
+    def tables(self, device):
+        key = (device,) + tuple(l.weight.data_ptr() for l in self.lins) + tuple(l.bias.data_ptr() for l in self.lins)
+        if key != self._key:
+            self._wt = torch.tensor([l.weight.data_ptr() for l in self.lins], dtype=torch.int64).to(device)
+            self._bt = torch.tensor([l.bias.data_ptr() for l in self.lins], dtype=torch.int64).to(device)
+            self._key, self._meta = key, {}
+        return self._wt, self._bt
+
+    def meta(self, B, device):
+        m = self._meta.get(B)
+        if m is None:
+            rows = [[cin, idx, B * c0, c0] for cin, idx, c0 in zip(self.cins, self.idx, self.c0)]
+            m = torch.tensor(rows, dtype=torch.int32).to(device)
+            self._meta[B] = m
+        return m
+
+    def __call__(self, latent):
+        params = [l.weight for l in self.lins] + [l.bias for l in self.lins]
+        return _ModBank.apply(latent, self, *params)
+
+
+class _ModBank(Function):
+    """latent [B,n_latent,512] -> tuple of s_l [B,Cin_l] (views of one packed buffer): s_l = EqualLinear_l(latent[:, idx_l])."""
+
+    @staticmethod
+    def forward(ctx, latent, bank, *params):
+        lat = latent.contiguous()
+        B, n_latent, D = lat.shape
+        dev = lat.device
+        wt, bt = bank.tables(dev)
+        meta = bank.meta(B, dev)
+        out = torch.empty(B * bank.Ctot, dtype=lat.dtype, device=dev)
+        with _lib.on_device(lat):
+            _lib.call("cagc_modbank_fwd", _lib.ptr(out), _lib.ptr(lat), wt.data_ptr(), bt.data_ptr(), meta.data_ptr(), bank.L,
+                      bank.Ctot, B, n_latent, D, bank.scale)
+        ctx.bank, ctx.meta, ctx.wt = bank, meta, wt
+        ctx.save_for_backward(lat)
+        return tuple(out[B * c0:B * (c0 + cin)].view(B, cin) for c0, cin in zip(bank.c0, bank.cins))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        (lat,) = ctx.saved_tensors
+        bank = ctx.bank
+        B, n_latent, D = lat.shape
+        dev = lat.device
+        parts = [(g.contiguous().reshape(-1) if g is not None else torch.zeros(B * cin, dtype=lat.dtype, device=dev))
+                 for g, cin in zip(gs, bank.cins)]
+        gs_packed = torch.cat(parts)
+        need_lat = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[2:])
+        gw = torch.empty(bank.Ctot, D, dtype=lat.dtype, device=dev) if need_w else None
+        gb = torch.empty(bank.Ctot, dtype=lat.dtype, device=dev) if need_w else None
+        glat = torch.empty_like(lat) if need_lat else None
+        with _lib.on_device(lat):
+            _lib.call("cagc_modbank_bwd", _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(glat), _lib.ptr(gs_packed), _lib.ptr(lat),
+                      ctx.wt.data_ptr(), ctx.meta.data_ptr(), bank.L, bank.Ctot, B, n_latent, D, bank.scale)
+        gws = [gw[c0:c0 + cin] if need_w else None for c0, cin in zip(bank.c0, bank.cins)]
+        gbs = [gb[c0:c0 + cin] if need_w else None for c0, cin in zip(bank.c0, bank.cins)]
+        return (glat, None, *gws, *gbs)
+
+
+# ---------------------------------------------------------------------------------------------------
 # ToRGB
 # ---------------------------------------------------------------------------------------------------
 class _ToRGB(Function):

@@ -498,7 +498,11 @@ static bool wgrad2_pf_ok(const Wg2Args& a, int mb, int nb) {
   const int PA = a.NPA * a.TH * (a.TW / 4), PB = a.BH * a.QB;
   if (PA > 256 || PB > 256) return false;
   const int cpa = 256 / PA, cpb = 256 / PB;
-  return cdiv(mb * 16, cpa) <= 4 * mb && cdiv(nb * 16, cpb) <= 4 * nb && getenv("CAGC_WGRAD_NOPF") == nullptr;
+  // measured (scripts/time_wgrad.py, gpurun_out/run6.log): prefetching pays only where the plain kernel already runs at one
+  // wave / SIMD (accumulators > 110 registers: 77->39 up-conv 585 -> 433 us); where it runs at two, the second wave hides
+  // the staging latency better than the prefetch does and the extra registers cost that wave (154->154 @64: 444 -> 561 us)
+  const bool one_wave_anyway = ((9 * nb + 3) / 4) * mb * 4 > 110;
+  return one_wave_anyway && cdiv(mb * 16, cpa) <= 4 * mb && cdiv(nb * 16, cpb) <= 4 * nb && getenv("CAGC_WGRAD_NOPF") == nullptr;
 }
 
 struct Wg2Plan { int mb, nb; };

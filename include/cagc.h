@@ -100,6 +100,26 @@ int cagc_demod_bwd(float* gs, float* gwsq, const float* gd, const float* d, cons
                    int B, int Cin, int Cout, cagc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Modulation bank                   replaces the per-layer `modulation` EqualLinear calls (model.py:192, 248:
+ *                                   s_l = F.linear(latent[:, idx_l], W_l * scale, bias_l), one tiny GEMM per styled conv /
+ *                                   ToRGB — 20 per 256 px generator, 60 more launches in backward) by one launch forward
+ *                                   and two backward.  style_dim = 512 only.
+ * Tables (device memory, built once by the caller): wptr_table / bptr_table = L device pointers to the layers'
+ *   modulation.weight [Cin_l,512] / modulation.bias [Cin_l] (bias pointer may be null); meta = L x int32[4] =
+ *   {Cin_l, latent index idx_l, offset of s_l in the packed buffer (floats), first channel c0_l of the layer in the
+ *   concatenation of all layers' channels}; Ctot = sum Cin_l.
+ * cagc_modbank_fwd: latent [B,n_latent,512] -> out packed: s_l = out + off_l, [B,Cin_l] row-major
+ *   (off_l = B * c0_l), s_l = latent[:, idx_l] @ (scale * W_l)^T + bias_l.
+ * cagc_modbank_bwd: gs_packed (same layout as out) -> gw_packed [Ctot,512] (rows c0_l .. c0_l+Cin_l = dL/dW_l),
+ *   gb_packed [Ctot], g_latent [B,n_latent,512] (every element written).  gw/gb [nullable together], g_latent [nullable].
+ * ---------------------------------------------------------------------------------------------- */
+int cagc_modbank_fwd(float* out, const float* latent, const void* wptr_table, const void* bptr_table, const int* meta,
+                     int L, int Ctot, int B, int n_latent, int style_dim, float scale, cagc_stream_t stream);
+int cagc_modbank_bwd(float* gw_packed, float* gb_packed, float* g_latent, const float* gs_packed, const float* latent,
+                     const void* wptr_table, const int* meta, int L, int Ctot, int B, int n_latent, int style_dim,
+                     float scale, cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Modulated convolution             replaces model.py:241-289 — F.conv2d / F.conv_transpose2d with
  *                                   groups=batch on per-sample weights [B*Cout,Cin,k,k].
  *

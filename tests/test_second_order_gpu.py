@@ -201,3 +201,30 @@ def test_full_training_iteration_never_reaches_a_stock_convolution():
         out = it.iteration(0, real, mask, random.Random(0), None)
     torch.cuda.synchronize()
     assert set(out) >= {"d", "r1", "g", "kd_l1_loss", "path"} and all(torch.isfinite(v).all() for v in out.values())
+
+
+def test_modulation_bank_matches_per_layer_linears():
+    """cagc_modbank_fwd / _bwd (every modulation EqualLinear of a generator in one launch) vs the layers evaluated one by
+    one: values, weight / bias gradients and the latent gradient (two layers share latent index 1)."""
+    from cagc.op import modconv as mc
+    torch.manual_seed(12)
+    cins, idx = [154, 3 * 17, 512, 77, 39], [0, 1, 1, 2, 4]
+    lins = [M.EqualLinear(512, c, bias_init=1).to(DEV) for c in cins]
+    with torch.no_grad():
+        for l in lins:
+            l.bias.add_(0.1 * torch.randn_like(l.bias))
+    layers = list(zip(lins, idx))
+    assert mc.ModulationBank.eligible(layers, 512)
+    bank = mc.ModulationBank(layers)
+    for B in (2, 16):
+        latent = torch.randn(B, 5, 512, device=DEV, requires_grad=True)
+        outs = bank(latent)
+        go = [torch.randn(B, c, device=DEV) for c in cins]
+        grads = torch.autograd.grad(outs, [latent] + [l.weight for l in lins] + [l.bias for l in lins], go)
+        lat2 = latent.detach().clone().requires_grad_(True)
+        ref = [l(lat2[:, i]) for l, i in zip(lins, idx)]
+        gref = torch.autograd.grad(ref, [lat2] + [l.weight for l in lins] + [l.bias for l in lins], go)
+        for a, b in zip(outs, ref):
+            assert_close(a, b, 1e-5, f"bank s (B={B})")
+        for nm, a, b in zip(["latent"] + ["w"] * 5 + ["b"] * 5, grads, gref):
+            assert_close(a, b, 1e-5, f"bank grad {nm} (B={B})")
