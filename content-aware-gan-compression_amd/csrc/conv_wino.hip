@@ -27,6 +27,7 @@
 #include "common.h"
 #include "prep_device.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace cagc {
 
@@ -50,11 +51,12 @@ struct WinoArgs {
   const float* bias;
   int B, Cin, Kp, Cout, Mp, H, W;
   int tiles_x, tiles_y, nblocks, mtiles;
+  int pmb;                 // channel blocks per PACKED tile of `up` (wino_mb of the layer); a SUB launch runs fewer per workgroup
   int epi, noise_bstride_on;
   float alpha, act_scale;
 };
 
-template <int MB, bool GATED>
+template <int MB, bool GATED, bool SUB = false>
 __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   constexpr int CK = WCK;
   constexpr int MT = MB * 16;
@@ -176,10 +178,25 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   // Stream order of this wave: chunk j, grid column c4 = 0..3, K-step s = 0..1  ->  slot t = 2*c4 + s;  the ring holds
   // one whole chunk, each slot is refilled for chunk j+1 right after it is consumed (~2000 cycles of MFMA work ahead).
   const int KQ = A.Kp / 4;
-  const float4* ua = reinterpret_cast<const float4*>(A.up) + ((int64_t)mtile * 16 + q * 4) * KQ * 64 + lane;
+  // SUB launches (a grid that would not fill the chip is cut into finer channel tiles): the weights stay packed in tiles of
+  // A.pmb blocks; this workgroup's MB (1 or 2) blocks start at slot0 inside the packed float4, so each lane loads just those
+  // 4 / 8 bytes.  Regular launches: MB == pmb, slot0 = 0, one 16-byte load per lane.
+  const int gb0 = mtile * MB;
+  const int ptile = SUB ? gb0 / A.pmb : mtile;
+  const int slot0 = SUB ? gb0 - ptile * A.pmb : 0;
+  const float4* ua = reinterpret_cast<const float4*>(A.up) + ((int64_t)ptile * 16 + q * 4) * KQ * 64 + lane;
+  auto load_a = [&](int64_t off4) {   // -> float4 whose first MB components are this workgroup's channel blocks
+    if constexpr (!SUB) return ua[off4];
+    else if constexpr (MB == 2) {
+      const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(ua + off4) + slot0);
+      return make_float4(v.x, v.y, 0.f, 0.f);
+    } else {
+      return make_float4(reinterpret_cast<const float*>(ua + off4)[slot0], 0.f, 0.f, 0.f);
+    }
+  };
   float4 ring[8];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) ring[t] = ua[((int64_t)(t >> 1) * KQ + (t & 1)) * 64];
+  for (int t = 0; t < 8; ++t) ring[t] = load_a(((int64_t)(t >> 1) * KQ + (t & 1)) * 64);
 
   f32x4 acc[4][MB][2];
 #pragma unroll
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
       float2 bvn = make_float2(0.f, 0.f);
       if (t < 7) bvn = vb[((((t + 1) >> 1) * CK + 4 * ((t + 1) & 1)) * W_VS) / 2];   // B operand one step ahead
       const float4 a4 = ring[t];
-      ring[t] = ua[((int64_t)c4 * KQ + 2 * jn + s) * 64];
+      ring[t] = load_a(((int64_t)c4 * KQ + 2 * jn + s) * 64);
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
@@ -296,7 +313,19 @@ __global__ __launch_bounds__(256) void k_wino_pack(float* __restrict__ up, const
   wino_pack_elem(up, w, idx, Cout, Cin, Kp, MB, scale, dgrad);
 }
 
-template <int MB, bool GATED = false>
+// Channel blocks per workgroup for THIS launch: the packed tile size, or 2 / 1 when the launch would leave most of the 256
+// CUs idle (small per-GPU batch / 32x32 layers: 8 pixel tiles x 8 channel tiles = 64 workgroups).  Fewer blocks per
+// workgroup = more workgroups; each repeats the input transform, which otherwise idle CUs do for free.
+static int wino_run_mb(int pmb, int M, int nblocks) {
+  if (getenv("CAGC_WINO_NO_SPLIT")) return pmb;
+  auto wgs = [&](int b) { return (int64_t)nblocks * cdiv(M, b * 16); };
+  int mb = pmb;
+  if (pmb == 4 && wgs(4) < 200) mb = 2;
+  if (mb != 1 && wgs(mb) < 200 && (pmb == 4 || pmb == 2 || pmb == 3)) mb = 1;
+  return mb;
+}
+
+template <int MB, bool GATED = false, bool SUB = false>
 static int launch_wino(WinoArgs& a, hipStream_t st, const char* what) {
   constexpr int MT = MB * 16;
   size_t smem = sizeof(float) * ((size_t)2 * 16 * WCK * W_VS + (size_t)2 * WCK * (W_IH * W_IWP + 16));
@@ -306,12 +335,12 @@ static int launch_wino(WinoArgs& a, hipStream_t st, const char* what) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino<MB, GATED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino<MB, GATED, SUB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr[dev] = true;
   }
   a.mtiles = cdiv(a.Cout, MT);
   CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
-  hipLaunchKernelGGL((k_wino<MB, GATED>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(512), smem, st, a);
+  hipLaunchKernelGGL((k_wino<MB, GATED, SUB>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(512), smem, st, a);
   return check_launch(what);
 }
 
@@ -359,7 +388,10 @@ extern "C" int cagc_wino_conv3x3(float* out, const float* x, const float* up, co
   a.tiles_x = W / WTW; a.tiles_y = H / WTH; a.nblocks = B * a.tiles_x * a.tiles_y;
   a.epi = epi; a.noise_bstride_on = (noise_batch == B) ? 1 : 0; a.alpha = alpha; a.act_scale = act_scale;
   hipStream_t st = as_stream(stream);
-  switch (wino_mb(Cout)) {
+  a.pmb = wino_mb(Cout);
+  const int rmb = wino_run_mb(a.pmb, Cout, a.nblocks);
+  if (rmb != a.pmb) return rmb == 2 ? launch_wino<2, false, true>(a, st, what) : launch_wino<1, false, true>(a, st, what);
+  switch (a.pmb) {
     case 1: return launch_wino<1>(a, st, what);
     case 2: return launch_wino<2>(a, st, what);
     case 3: return launch_wino<3>(a, st, what);
@@ -387,7 +419,10 @@ extern "C" int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const f
   a.tiles_x = W / WTW; a.tiles_y = H / WTH; a.nblocks = B * a.tiles_x * a.tiles_y;
   a.epi = CAGC_EPI_LINEAR; a.alpha = alpha; a.act_scale = 1.f;
   hipStream_t st = as_stream(stream);
-  switch (wino_mb(Cin)) {
+  a.pmb = wino_mb(Cin);
+  const int rmb = wino_run_mb(a.pmb, Cin, a.nblocks);
+  if (rmb != a.pmb) return rmb == 2 ? launch_wino<2, true, true>(a, st, what) : launch_wino<1, true, true>(a, st, what);
+  switch (a.pmb) {
     case 1: return launch_wino<1, true>(a, st, what);
     case 2: return launch_wino<2, true>(a, st, what);
     case 3: return launch_wino<3, true>(a, st, what);
