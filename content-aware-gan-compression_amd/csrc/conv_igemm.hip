@@ -591,10 +591,36 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
       if (ks > nchunks / 2) ks = nchunks / 2;
       if (ks < 1) ks = 1;
     }
-    a.ksplit = ks;
+    // Items with different tap counts (the 4 / 2 / 2 / 1-tap output phases of a transposed conv) make workgroups of very
+    // different duration; when the launch is about one round of the chip, the makespan is the 4-tap workgroups' and half
+    // the CUs idle (256 -> 512 @64^2 at per-GPU batch 2: 351 us for 203 us of MFMA work).  Split K per item in proportion
+    // to its taps instead, so every workgroup carries the same number of (tap, chunk) products.
+    int min_taps = 1 << 20, max_taps = 0;
+    for (int p = 0; p < nitems; ++p) {
+      min_taps = raw[p].ntaps < min_taps ? raw[p].ntaps : min_taps;
+      max_taps = raw[p].ntaps > max_taps ? raw[p].ntaps : max_taps;
+    }
+    const bool by_taps = allow_split && nitems > 1 && raw[0].nph == 1 && max_taps > min_taps && tiles_all * mt <= 512 &&
+                         nchunks >= 8 && getenv("CAGC_NO_TAP_SPLIT") == nullptr;
+    int ks_max = ks;
+    if (by_taps) {
+      int64_t units = 0;   // workgroups if every item is split `ntaps / min_taps` ways
+      for (int p = 0; p < nitems; ++p)
+        units += (int64_t)cdiv(a.B, a.items[p].IPB) * a.items[p].tiles_x * a.items[p].tiles_y * mt * (raw[p].ntaps / min_taps);
+      const int base = units < 256 ? cdiv(256, units) : 1;
+      ks_max = 1;
+      for (int p = 0; p < nitems; ++p) {
+        int k = base * (raw[p].ntaps / min_taps);
+        if (k > nchunks / 2) k = nchunks / 2;
+        if (k < 1) k = 1;
+        a.items[p].ks = k;
+        ks_max = k > ks_max ? k : ks_max;
+      }
+    }
+    a.ksplit = ks_max;
     for (int p = 0; p < nitems; ++p) {
       ConvItem& I = a.items[p];
-      I.ks = ks;
+      if (!by_taps) I.ks = ks;
       blocks += cdiv(a.B, I.IPB) * I.tiles_x * I.tiles_y * I.ks;
       I.block_end = blocks;
     }

@@ -94,7 +94,15 @@ __global__ __launch_bounds__(256) void k_modbank_bwd_lat(float* __restrict__ gla
       __syncthreads();
       for (int t = threadIdx.x; t < n; t += 256) g_s[t] = gs[m.off + (int64_t)b * m.cin + cbase + t];
       __syncthreads();
-      for (int c = 0; c < n; ++c) {
+      int c = 0;
+      for (; c + 8 <= n; c += 8) {     // 8 independent 8-byte loads in flight per lane (the loop is pure load latency)
+        float2 wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const float2*>(w + (int64_t)(cbase + c + u) * MB_D + k);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc0 += g_s[c + u] * wv[u].x; acc1 += g_s[c + u] * wv[u].y; }
+      }
+      for (; c < n; ++c) {
         const float2 wv = *reinterpret_cast<const float2*>(w + (int64_t)(cbase + c) * MB_D + k);
         acc0 += g_s[c] * wv.x;
         acc1 += g_s[c] * wv.y;

