@@ -595,13 +595,16 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
     // different duration; when the launch is about one round of the chip, the makespan is the 4-tap workgroups' and half
     // the CUs idle (256 -> 512 @64^2 at per-GPU batch 2: 351 us for 203 us of MFMA work).  Split K per item in proportion
     // to its taps instead, so every workgroup carries the same number of (tap, chunk) products.
+    // MEASURED NEGATIVE (gpurun_out/run10.log, per-GPU batch 2): 304 -> 491 us on the 128->256 @257^2 stride-2 data gradient,
+    // 305 -> 433 us on the 256->128 @128^2 transposed conv: the 4-way fp32-atomic accumulation of the 4-tap phase costs more
+    // than the idle CUs it fills.  Kept behind CAGC_TAP_SPLIT=1 for the record; the default is the uniform split.
     int min_taps = 1 << 20, max_taps = 0;
     for (int p = 0; p < nitems; ++p) {
       min_taps = raw[p].ntaps < min_taps ? raw[p].ntaps : min_taps;
       max_taps = raw[p].ntaps > max_taps ? raw[p].ntaps : max_taps;
     }
     const bool by_taps = allow_split && nitems > 1 && raw[0].nph == 1 && max_taps > min_taps && tiles_all * mt <= 512 &&
-                         nchunks >= 8 && getenv("CAGC_NO_TAP_SPLIT") == nullptr;
+                         nchunks >= 8 && getenv("CAGC_TAP_SPLIT") != nullptr;   // OFF by default — measured slower, see below
     int ks_max = ks;
     if (by_taps) {
       int64_t units = 0;   // workgroups if every item is split `ntaps / min_taps` ways

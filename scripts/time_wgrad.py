@@ -11,6 +11,8 @@ layers = [(154, 154, 4, 0), (154, 154, 4, 1), (154, 154, 8, 0), (154, 154, 8, 1)
           (39, 39, 256, 0)]
 tot = 0.0
 tot0 = 0.0
+if os.environ.get("LAYERS"):      # e.g. LAYERS=8,10,12 : only these rows (PMC runs average per kernel symbol)
+    layers = [layers[int(i)] for i in os.environ["LAYERS"].split(",")]
 for cin, cout, H, up in layers:
     W = H
     x = torch.randn(B, cin, H, W, device="cuda")
