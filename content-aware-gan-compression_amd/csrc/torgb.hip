@@ -5,6 +5,7 @@
 // evaluated in the epilogue from the 4x-smaller previous RGB (2x2 non-zero polyphase taps per output).
 // Backward: gx (one streamed write) and the per-sample weight gradient gws[b,o,c] = sum_p g x.
 #include "common.h"
+#include <stdlib.h>
 
 namespace cagc {
 
@@ -57,6 +58,104 @@ __global__ __launch_bounds__(256) void k_torgb_fwd(float* __restrict__ out, cons
     if (skip) {
       const int Y = (int)(p / W), X = (int)(p - (int64_t)Y * W);
       // U[u] (zero-inserted, pad0 = 2): tap i reads u = Y + i - 2, non-zero iff even and 0 <= u/2 < SH
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int uy = Y + i - 2;
+        if (uy < 0 || (uy & 1)) continue;
+        const int sy = uy >> 1;
+        if (sy >= SH) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ux = X + j - 2;
+          if (ux < 0 || (ux & 1)) continue;
+          const int sx = ux >> 1;
+          if (sx >= SW) continue;
+          const float kv = kf[i * 4 + j];
+          const int64_t so = ((int64_t)b * 3 * SH + sy) * SW + sx;
+          r[0] += kv * skip[so];
+          r[1] += kv * skip[so + (int64_t)SH * SW];
+          r[2] += kv * skip[so + 2 * (int64_t)SH * SW];
+        }
+      }
+    }
+    out[((int64_t)b * 3 + 0) * HW + p] = r[0];
+    out[((int64_t)b * 3 + 1) * HW + p] = r[1];
+    out[((int64_t)b * 3 + 2) * HW + p] = r[2];
+  }
+}
+
+// Under-filled launches (low resolutions / small per-GPU batch): the kernel above gives every thread ALL C channels of its
+// 4 pixels — a serial chain of C dependent-latency loads, 50-60 us for C = 512 whatever the image size.  Here a workgroup
+// covers 256 pixels (or the whole image if smaller) and splits the channels over its 4 wavefronts and, when the image has
+// fewer than 64 pixel quads, over the spare lanes as well (lane = (quad, channel group)); 8 loads in flight per lane; the
+// partial sums meet in LDS and the first NQ lanes run the same bias + skip epilogue.
+__global__ __launch_bounds__(256) void k_torgb_fwd_split(float* __restrict__ out, const float* __restrict__ x,
+                                                         const float* __restrict__ w, const float* __restrict__ s,
+                                                         const float* __restrict__ bias, const float* __restrict__ skip,
+                                                         const float* __restrict__ fir, int C, int H, int W, int nstrip,
+                                                         int NQ, float scale) {
+  extern __shared__ float wm[];  // [3][C] then [256][12] partial sums
+  __shared__ float kf[16];
+  float* red = wm + 3 * C;
+  const int b = blockIdx.x / nstrip, strip = blockIdx.x - b * nstrip;
+  const int64_t HW = (int64_t)H * W;
+  for (int e = threadIdx.x; e < 3 * C; e += 256) {
+    const int c = e % C;
+    wm[e] = scale * w[e] * s[(int64_t)b * C + c];
+  }
+  if (skip && threadIdx.x < 16) kf[threadIdx.x] = fir[15 - threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int CG = 64 / NQ;                       // channel groups inside a wavefront
+  const int quad = lane % NQ, cg = lane / NQ;
+  const int nsub = 4 * CG, sub = wave * CG + cg;   // this lane's channel subset: sub, sub + nsub, ...
+  const int64_t p0 = (int64_t)strip * 256 + quad * 4;
+  float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+  if (p0 < HW) {
+    const float* xb = x + (int64_t)b * C * HW + p0;
+    int c = sub;
+    for (; c + 7 * nsub < C; c += 8 * nsub) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(xb + (int64_t)(c + u * nsub) * HW);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int cc = c + u * nsub;
+        const float w0 = wm[cc], w1 = wm[C + cc], w2 = wm[2 * C + cc];
+        a0[0] += w0 * v[u].x; a0[1] += w0 * v[u].y; a0[2] += w0 * v[u].z; a0[3] += w0 * v[u].w;
+        a1[0] += w1 * v[u].x; a1[1] += w1 * v[u].y; a1[2] += w1 * v[u].z; a1[3] += w1 * v[u].w;
+        a2[0] += w2 * v[u].x; a2[1] += w2 * v[u].y; a2[2] += w2 * v[u].z; a2[3] += w2 * v[u].w;
+      }
+    }
+    for (; c < C; c += nsub) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)c * HW);
+      const float w0 = wm[c], w1 = wm[C + c], w2 = wm[2 * C + c];
+      a0[0] += w0 * v.x; a0[1] += w0 * v.y; a0[2] += w0 * v.z; a0[3] += w0 * v.w;
+      a1[0] += w1 * v.x; a1[1] += w1 * v.y; a1[2] += w1 * v.z; a1[3] += w1 * v.w;
+      a2[0] += w2 * v.x; a2[1] += w2 * v.y; a2[2] += w2 * v.z; a2[3] += w2 * v.w;
+    }
+  }
+  float* my = red + threadIdx.x * 12;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { my[k] = a0[k]; my[4 + k] = a1[k]; my[8 + k] = a2[k]; }
+  __syncthreads();
+  if (threadIdx.x >= NQ || p0 >= HW) return;
+  float r4[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) r4[k] = 0.f;
+  for (int wv = 0; wv < 4; ++wv)               // fixed summation order: deterministic
+    for (int g2 = 0; g2 < CG; ++g2) {
+      const float* o = red + (wv * 64 + g2 * NQ + quad) * 12;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) r4[k] += o[k];
+    }
+  const int SH = H / 2, SW = W / 2;
+  for (int k = 0; k < 4; ++k) {
+    const int64_t p = p0 + k;
+    if (p >= HW) break;
+    float r[3] = {r4[k] + bias[0], r4[4 + k] + bias[1], r4[8 + k] + bias[2]};
+    if (skip) {
+      const int Y = (int)(p / W), X = (int)(p - (int64_t)Y * W);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int uy = Y + i - 2;
@@ -153,6 +252,19 @@ extern "C" int cagc_torgb_fwd(float* out, const float* x, const float* w, const 
   CAGC_REQUIRE(3 * C * sizeof(float) <= 48 * 1024, "%s: C too large", what);
   const int64_t HW = (int64_t)H * W;
   const int nstrip = cdiv(HW, RGB_PIX);
+  if (HW % 4 == 0 && (int64_t)B * nstrip < 512 && ((uintptr_t)x % 16) == 0 && getenv("CAGC_TORGB_NOSPLIT") == nullptr) {
+    // under-filled: 256-pixel workgroups, channels split over wavefronts (and spare lanes for images under 256 pixels)
+    const int quads = (int)(HW / 4 < 64 ? HW / 4 : 64);
+    int NQ = 1;
+    while (NQ * 2 <= quads) NQ *= 2;            // power of two <= 64 (quads is one for every size the generator produces)
+    if (NQ == quads) {
+      const int ns = cdiv(HW, 256);
+      const size_t smem = (3 * (size_t)C + 256 * 12) * sizeof(float);
+      hipLaunchKernelGGL(k_torgb_fwd_split, dim3((unsigned)(B * ns)), dim3(256), smem, as_stream(stream), out, x, w, s, bias,
+                         skip, fir, C, H, W, ns, NQ, scale);
+      return check_launch(what);
+    }
+  }
   hipLaunchKernelGGL(k_torgb_fwd, dim3((unsigned)(B * nstrip)), dim3(256), 3 * C * sizeof(float), as_stream(stream), out, x,
                      w, s, bias, skip, fir, C, H, W, nstrip, scale);
   return check_launch(what);
