@@ -206,7 +206,10 @@ struct Wg2Args {
   signed char pair_tap[4][12], pair_nb[4][12], pair_newa[4][12];
 };
 
-template <int MB, int NB>
+// AFF: affine staging map (a thread owns one float4 position of the per-channel tile and walks over channels: no index
+// arithmetic per load, row / column masks once per tile).  PMC on the 39->39 @256^2 layer showed 4.8 VALU instructions
+// per MFMA with the generic row-indexed map (profiles/r02_wgrad_pmc.md) — the staging loops' float->int index math.
+template <int MB, int NB, bool AFF>
 __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)) void k_wgrad2(const Wg2Args A) {
   constexpr int MT = MB * 16, NT = NB * 16;
   constexpr int PPW = (9 * NB + 3) / 4;
@@ -244,6 +247,21 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)
   const int rpa = 256 / QA;                    // A rows per pass of the workgroup
   const int aq = tid % QA, ar = tid / QA;
   const int bq = tid & 15, br = tid >> 4;      // 16 rows per pass
+  // affine map (AFF): A has PA = NPA*TH*QA float4 positions per channel, cpa = 256 / PA channels per pass; B likewise
+  const int f_PA = A.NPA * TH * QA, f_cpa = AFF ? 256 / f_PA : 1;
+  const int f_apos = tid % f_PA, f_ac0 = tid / f_PA;
+  const bool f_aon = f_ac0 < f_cpa;
+  const int f_aq = f_apos % QA, f_arow = f_apos / QA;
+  const int f_apl = f_arow / TH, f_aiy = f_arow - f_apl * TH;
+  const int f_agpos = (f_apl * A.AHg + f_aiy) * A.APitch + 4 * f_aq, f_alpos = f_arow * TW + 4 * f_aq;
+  const int f_acs = A.NPA * A.AHg * A.APitch;
+  const int f_PB = A.BH * A.QB, f_cpb = AFF ? 256 / f_PB : 1;
+  const int f_bpos = tid % f_PB, f_bc0 = tid / f_PB;
+  const bool f_bon = f_bc0 < f_cpb;
+  const int f_bq = f_bpos % A.QB, f_biy = f_bpos / A.QB;
+  const int f_bgpos = f_biy * A.W + 4 * f_bq, f_blpos = f_biy * A.BWp + 4 * f_bq;
+  const int f_bcs = A.H * A.W;
+  const int64_t f_aimg = (int64_t)A.Cout * f_acs, f_bimg = (int64_t)A.Cin * f_bcs;
 
   for (int tile = sp; tile < A.ntiles; tile += A.nsplit) {
     int t2 = tile;
@@ -252,6 +270,47 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)
     const int b = t2 / A.tiles_y;
     const int y0 = tyi * TH, x0 = txi * TW;
     __syncthreads();
+    if constexpr (AFF) {
+      {
+        const int gy = y0 + f_aiy, gx = x0 + 4 * f_aq;
+        const bool ok = f_aon && gy < A.Hk && gx + 4 <= A.APitch;
+        const bool m0 = gx + 0 >= A.Wk, m1 = gx + 1 >= A.Wk, m2 = gx + 2 >= A.Wk, m3 = gx + 3 >= A.Wk;
+        const float* src = A.ga + (int64_t)b * f_aimg + (int64_t)y0 * A.APitch + x0 + f_agpos + (int64_t)(o0 + f_ac0) * f_acs;
+        if (f_aon) {
+#pragma unroll 4
+          for (int oc = f_ac0; oc < MT; oc += f_cpa) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && o0 + oc < A.Cout) v = *reinterpret_cast<const float4*>(src);
+            src += (int64_t)f_cpa * f_acs;
+            if (m3) { v.w = 0.f; if (m2) v.z = 0.f; if (m1) v.y = 0.f; if (m0) v.x = 0.f; }
+            float* dst = a_lds + oc * A.ACS + f_alpos;
+            *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+          }
+        }
+      }
+      {
+        const int gy = y0 + A.b_y0 + f_biy, gx = x0 - 4 + 4 * f_bq;
+        const bool ok = f_bon && gy >= 0 && gy < A.H && gx >= 0 && gx + 4 <= A.W;
+        const float* src = A.x + (int64_t)b * f_bimg + (int64_t)(y0 + A.b_y0) * A.W + x0 - 4 + f_bgpos + (int64_t)(i0 + f_bc0) * f_bcs;
+        const float* sp_ = A.s ? A.s + b * A.Cin + i0 + f_bc0 : nullptr;
+        if (f_bon) {
+#pragma unroll 4
+          for (int ic = f_bc0; ic < NT; ic += f_cpb) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && i0 + ic < A.Cin) {
+              v = *reinterpret_cast<const float4*>(src);
+              const float sc = sp_ ? sp_[ic - f_bc0] : 1.f;
+              v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+            }
+            src += (int64_t)f_cpb * f_bcs;
+            float* dst = b_lds + ic * A.BCS + f_blpos;
+            *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+          }
+        }
+      }
+    } else {
     // ---- stage A: [MT][NPA][TH][TW], no halo, 16-byte loads ------------------------------------------
 #pragma unroll 4
     for (int r = ar; r < a_rows; r += rpa) {
@@ -291,6 +350,7 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)
         *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
       }
     }
+    }   // !AFF
     __syncthreads();
     // ---- MFMA over the tile's pixels -------------------------------------------------------------------
     for (int row = 0; row < TH; ++row) {
@@ -606,7 +666,7 @@ static int launch_wgrad2(Wg2Args& a, hipStream_t st, const char* what) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad2<MB, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad2<MB, NB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr[dev] = true;
   }
   dim3 grid(a.Mp / (16 * MB), a.Np / (16 * NB), a.nsplit);
@@ -618,7 +678,17 @@ static int launch_wgrad2(Wg2Args& a, hipStream_t st, const char* what) {
     }
     hipLaunchKernelGGL((k_wgrad2_pf<MB, NB>), grid, dim3(256), smem, st, a);
   } else {
-    hipLaunchKernelGGL((k_wgrad2<MB, NB>), grid, dim3(256), smem, st, a);
+    const int PA = a.NPA * a.TH * (a.TW / 4), PB = a.BH * a.QB;
+    if (PA <= 256 && PB <= 256 && getenv("CAGC_WGRAD_NOAFF") == nullptr) {
+      static bool attr_af[64] = {};
+      if (dev >= 0 && dev < 64 && !attr_af[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad2<MB, NB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_af[dev] = true;
+      }
+      hipLaunchKernelGGL((k_wgrad2<MB, NB, true>), grid, dim3(256), smem, st, a);
+    } else {
+      hipLaunchKernelGGL((k_wgrad2<MB, NB, false>), grid, dim3(256), smem, st, a);
+    }
   }
   return check_launch(what);
 }
