@@ -561,8 +561,12 @@ static bool wgrad2_pf_ok(const Wg2Args& a, int mb, int nb) {
   // measured (scripts/time_wgrad.py, gpurun_out/run6.log): prefetching pays only where the plain kernel already runs at one
   // wave / SIMD (accumulators > 110 registers: 77->39 up-conv 585 -> 433 us); where it runs at two, the second wave hides
   // the staging latency better than the prefetch does and the extra registers cost that wave (154->154 @64: 444 -> 561 us)
-  const bool one_wave_anyway = ((9 * nb + 3) / 4) * mb * 4 > 110;
-  return one_wave_anyway && cdiv(mb * 16, cpa) <= 4 * mb && cdiv(nb * 16, cpb) <= 4 * nb && getenv("CAGC_WGRAD_NOPF") == nullptr;
+  // i.e. prefetch exactly when it does not cost occupancy: either the prefetching kernel still fits two waves / SIMD
+  // (small accumulator sets: 77->39 up-conv on plan {3,1}: 587 -> 433 us), or the plain kernel is at one wave anyway
+  const int acc = ((9 * nb + 3) / 4) * mb * 4;
+  const bool plain_two = acc <= 110, pf_two = acc + (4 * mb + 4 * nb) * 4 + 110 <= 256;
+  return (pf_two || !plain_two) && cdiv(mb * 16, cpa) <= 4 * mb && cdiv(nb * 16, cpb) <= 4 * nb &&
+         getenv("CAGC_WGRAD_NOPF") == nullptr;
 }
 
 struct Wg2Plan { int mb, nb; };
