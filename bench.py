@@ -82,8 +82,8 @@ def stream_bytes(name, a):
 
 
 # dominant-entry-point -> device symbol (for the PMC traffic lookup) and MFMA instruction
-KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false>", "cagc_wino_conv3x3[k_wino<3, false>]": "k_wino<3, false>",
-             "cagc_wino_conv3x3_act_dgrad[k_wino<4, true>]": "k_wino<4, true>", "cagc_modconv_fwd": "k_conv_igemm<8, 4, true, false, 1>",
+KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false, false>", "cagc_wino_conv3x3[k_wino<3, false>]": "k_wino<3, false, false>",
+             "cagc_wino_conv3x3_act_dgrad[k_wino<4, true>]": "k_wino<4, true, false>", "cagc_modconv_fwd": "k_conv_igemm<8, 4, true, false, 1>",
              "cagc_modconv_up_fwd": "k_conv_igemm<8, 4, true, false, 1>",
              "cagc_modconv_dgrad": "k_conv_igemm<8, 12, true, false, 1>",
              "cagc_modconv_up_dgrad": "k_conv_igemm<8, 12, true, false, 1>", "cagc_modconv_wgrad": "k_wgrad2<5, 2>",

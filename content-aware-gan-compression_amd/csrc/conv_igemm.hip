@@ -709,6 +709,26 @@ static bool fused_phase_ok(int B, int H, int W, int Mp) {
   return tiles * cdiv(Mp, 64) >= 256;
 }
 
+// Balanced per-phase launches for under-filled transposed-conv style launches (4 output phases with 4 / 2 / 2 / 1 taps):
+// one launch per phase with 2 / 4 / 4 / 8 channel blocks per workgroup, so every workgroup carries 8 (tap, block) units
+// and the chip sees ~9/8 * tiles * blocks equal workgroups — no K split, no atomics, no zero-fill of the main region.
+// (The alternative — splitting K in proportion to the taps — was measured slower: the atomics cost more than the idle CUs.)
+static bool balanced_phases_ok(int B, int Hv, int Wv, int Mp) {
+  static const bool off = getenv("CAGC_NO_PHASE_MB") != nullptr;
+  if (off) return false;
+  const int nblk = Mp / 16;
+  if (nblk % 8 != 0) return false;
+  const int TW = pow2ceil(Wv) < 32 ? (pow2ceil(Wv) < 4 ? 4 : pow2ceil(Wv)) : 32;
+  int TH = pow2ceil(Hv);
+  if (TH > CONV_NT / TW) TH = CONV_NT / TW;
+  int IPB = CONV_NT / (TW * TH);
+  if (IPB > pow2ceil(B)) IPB = pow2ceil(B);
+  const int64_t T = (int64_t)cdiv(B, IPB) * cdiv(Wv, TW) * cdiv(Hv, TH);
+  const int64_t old_wgs = 4 * T * (nblk / 8), new_wgs = T * nblk * 9 / 8;
+  return old_wgs < 512 && new_wgs >= 200;
+}
+static int phase_mb(int ntaps) { return ntaps >= 4 ? 2 : (ntaps == 2 ? 4 : 8); }
+
 static void base_args(ConvArgs& a, float* out, const float* in, const float* wp, int B, int K, int M) {
   memset(&a, 0, sizeof(a));
   a.in = in; a.out = out; a.wp = wp;
@@ -806,13 +826,21 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   // Two launches: the main regions keep the small staging footprint (NV = 4 -> 2 waves / SIMD); the thin strips
   // need longer halo tiles.  Split-K launches accumulate with atomics, so t is zeroed once up front.
   hipStream_t st = as_stream(stream);
-  const bool small = (int64_t)B * H * W <= 32768;   // only small layers are ever split over K
+  bool small = (int64_t)B * H * W <= 32768;   // only small layers are ever split over K
+  ConvArgs a2 = a;
+  int rc;
+  if (small && balanced_phases_ok(B, H, W, a.Mp)) {
+    for (int ph = 0; ph < 4; ++ph) {
+      ConvArgs ap = a;
+      rc = run_conv(ap, &items[ph], 1, st, what, false, false, phase_mb(items[ph].ntaps));
+      if (rc) return rc;
+    }
+    small = false;      // strips: zero just their regions, as in the large-layer path
+  } else {
   if (small) {
     const size_t bytes = sizeof(float) * (size_t)B * Cout * 4 * (H + 1) * a.Wopitch;
     { int zrc = zero_fill(t, bytes, st); if (zrc) return zrc; }
   }
-  ConvArgs a2 = a;
-  int rc;
   if (fused_phase_ok(B, H, W, a.Mp)) {
     RawTap t9[9];
     RawItem fi = fused_phase_item(t9, H, W, /*planar_out=*/true);
@@ -821,6 +849,7 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
     rc = run_conv(a, items, 4, st, what, false, small);
   }
   if (rc) return rc;
+  }
   if (!small) {   // strips: few workgroups with long K loops -> split K; zero just the strip regions first
     const int64_t planes = (int64_t)B * Cout * 4;
     hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (H + 1 + W + 1), 256)), dim3(256), 0, st, t, planes, H + 1,
@@ -928,7 +957,15 @@ extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_b
   int rc;
   // low-resolution layers: too few pixel tiles to fill the chip and a 64-chunk K loop per workgroup -> split K
   // (atomics), which needs the whole gradient zeroed first
-  const bool small = (int64_t)B * Ho * Wo <= 32768;
+  bool small = (int64_t)B * Ho * Wo <= 32768;
+  if (small && balanced_phases_ok(B, Ho, Wo, a.Mp)) {
+    for (int ph = 0; ph < 4; ++ph) {
+      ConvArgs ap = a;
+      rc = run_conv(ap, &main_items[ph], 1, st, what, false, false, phase_mb(main_items[ph].ntaps));
+      if (rc) return rc;
+    }
+    small = false;
+  } else {
   if (small) {
     const size_t bytes = sizeof(float) * (size_t)B * Cin * Hin * out_pitch;
     { int zrc = zero_fill(gx, bytes, st); if (zrc) return zrc; }
@@ -941,6 +978,7 @@ extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_b
     rc = run_conv(a, main_items, 4, st, what, false, small);
   }
   if (rc) return rc;
+  }
   if (!small) {
     const int64_t planes = (int64_t)B * Cin;
     hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (Hin + Win), 256)), dim3(256), 0, st, gx, planes, Hin, Win,

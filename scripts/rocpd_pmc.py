@@ -26,13 +26,13 @@ for n, c, k, v, t in rows[:a.top]:
     print(f"| {n} | {c} | {k} | {v:.4g} | {v / k:.4g} | {t / 1e6:.3f} |")
 
 if a.mfma:
-    # one row per kernel: MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * #SIMDs); the counter sums busy
-    # cycles over every SIMD of the chip (256 CUs x 4), GRBM_GUI_ACTIVE is the dispatch's duration in shader cycles
+    # one row per kernel: MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the SQ counter
+    # sums busy cycles over every SIMD of the chip (256 CUs x 4), GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles
     piv = {}
     for n, c, k, v, t in rows:
         piv.setdefault(n, {})[c] = (k, v, t)
     print()
-    print("| kernel | dispatches | total ms | MFMA busy cycles / dispatch | GUI active cycles / dispatch | MFMA busy (of 1024 SIMDs) | MFMA insts / dispatch |")
+    print("| kernel | dispatches | total ms | MFMA busy cycles / dispatch | GUI active cycles / dispatch | MFMA busy fraction | MFMA insts / dispatch |")
     print("|---|---|---|---|---|---|---|")
     order = sorted(piv.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", (0, 0, 0))[2])
     for n, d in order[:40]:
@@ -44,4 +44,4 @@ if a.mfma:
         if busy == 0:
             continue
         nm = n if len(n) < 90 else n[:87] + "..."
-        print(f"| {nm} | {k} | {t / 1e6:.3f} | {busy / k:.4g} | {gui / k:.4g} | {busy / (gui * 1024):.3f} | {insts / k:.4g} |")
+        print(f"| {nm} | {k} | {t / 1e6:.3f} | {busy / k:.4g} | {gui / k:.4g} | {busy / (gui * 128):.3f} | {insts / k:.4g} |")
