@@ -714,8 +714,11 @@ static bool fused_phase_ok(int B, int H, int W, int Mp) {
 // and the chip sees ~9/8 * tiles * blocks equal workgroups — no K split, no atomics, no zero-fill of the main region.
 // (The alternative — splitting K in proportion to the taps — was measured slower: the atomics cost more than the idle CUs.)
 static bool balanced_phases_ok(int B, int Hv, int Wv, int Mp) {
-  static const bool off = getenv("CAGC_NO_PHASE_MB") != nullptr;
-  if (off) return false;
+  // MEASURED NEGATIVE (gpurun_out/run14.log, per-GPU batch 2): 512->256 @64^2 330 -> 597 us, 512->512 @32^2 248 -> 586 us.
+  // A workgroup's cost at these sizes is dominated by staging its input tile, which does not shrink with the number of
+  // channel blocks — four times the workgroups stage the same tiles four times.  Off unless CAGC_PHASE_MB=1.
+  static const bool on = getenv("CAGC_PHASE_MB") != nullptr;
+  if (!on) return false;
   const int nblk = Mp / 16;
   if (nblk % 8 != 0) return false;
   const int TW = pow2ceil(Wv) < 32 ? (pow2ceil(Wv) < 4 ? 4 : pow2ceil(Wv)) : 32;
