@@ -102,17 +102,22 @@ def batch_saliency_scores(generator, img, hit, sp):
 
 
 def content_aware_scores(generator, n_sample, batch_size, noise_prob, mask_fn, device, latent_dim=512, rank=0, world=1,
-                         rng=None):
+                         rng=None, seed=None, noise_fn=None):
     """Sum over batches of the per-batch scores (prune.py:45-46).  With world > 1 the batches are dealt round-robin
-    to the ranks and the score vectors are summed with ONE all-reduce at the end."""
+    to the ranks and the score vectors are summed with ONE all-reduce at the end.
+    `seed`: every batch draws its latents and salt-and-pepper pattern from its own generator (seed + batch index), so the
+    result does not depend on how the batches are dealt to ranks; `noise_fn(batch_index, batch)` optionally supplies the
+    per-layer noise maps (default: fresh noise, as prune.py)."""
     n_batch = max(1, n_sample // batch_size)
     sizes = [batch_size] * (n_batch - 1) + [batch_size + n_sample % batch_size]
     total = None
     for idx, b in enumerate(sizes):
         if idx % world != rank:
             continue
+        if seed is not None:
+            rng = torch.Generator(device=device).manual_seed(int(seed) + idx)
         z = torch.randn(b, latent_dim, device=device, generator=rng)
-        img = generator([z])
+        img = generator([z], noise=noise_fn(idx, b)) if noise_fn is not None else generator([z])
         hit, sp = salt_pepper(mask_fn(img.detach()), noise_prob, rng)
         sc = batch_saliency_scores(generator, img, hit, sp)
         total = sc if total is None else [a + c for a, c in zip(total, sc)]

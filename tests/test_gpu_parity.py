@@ -673,3 +673,71 @@ def test_c_abi_error_contract():
     e = torch.empty(0, 8, 10, 12, device=DEV)
     assert fused_leaky_relu(e, torch.zeros(8, device=DEV)).shape == e.shape
     assert upfirdn2d(e, k, pad=(1, 1)).shape == (0, 8, 9, 11)
+
+
+# ---------------------------------------------------------------------------------------------------
+# GraphedKDStep with world_size = 2: two processes on this one GPU (CAGC_SINGLE_DEVICE=1, gloo), each capturing its own
+# HIP graphs and joining the flat-gradient all-reduce between them == one process on the concatenated batch.
+# ---------------------------------------------------------------------------------------------------
+def _graph2_inputs(g, meta):
+    import torch as _t
+    gen = _t.Generator().manual_seed(5)
+    nl = 7
+    return dict(z=[_t.randn(8, 24, generator=gen), _t.randn(8, 24, generator=gen)], mask=g["mask"].repeat(2, 1, 1, 1),
+                sn=[_t.randn(8, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), generator=gen) for i in range(nl)],
+                tn=[_t.randn(8, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), generator=gen) for i in range(nl)])
+
+
+def _graph2_models(g, meta):
+    student = M.Generator(32, 24, 2, generator_net_shape=meta["student_shape"])
+    student.load_state_dict(sub(g, "student_sd/"), strict=True)
+    teacher = M.Generator(32, 24, 2, generator_net_shape=meta["teacher_shape"])
+    teacher.load_state_dict(sub(g, "teacher_sd/"), strict=True)
+    disc = M.Discriminator(32)
+    disc.load_state_dict(ref_model.regenerate_state_dict(load_json("discriminator32_keys"), g["d_seed"]), strict=True)
+    return student.to(DEV), teacher.to(DEV), disc.to(DEV)
+
+
+def _graph2_worker(rank, world, port, tmp):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      CAGC_SINGLE_DEVICE="1", CAGC_DIST_BACKEND="gloo")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "content-aware-gan-compression_amd"), os.path.dirname(os.path.abspath(__file__))):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from cagc import distributed as cd
+    cd.init_from_env()
+    g = load_npz("kd_step_tiny")
+    meta = load_json("kd_step_tiny_meta")
+    student, teacher, disc = _graph2_models(g, meta)
+    d = _graph2_inputs(g, meta)
+    sl = slice(rank, None, world)          # rank r takes samples r::2: keeps D's minibatch-stddev groups identical
+    step = kd.GraphedKDStep(student, teacher, disc, 4, cu(d["mask"][sl]), random_noise=False, world_size=world, latent=24)
+    for _ in range(2):
+        step.g_step([cu(z[sl]) for z in d["z"]], 3, cu(d["mask"][sl]), [cu(n[sl]) for n in d["sn"]], [cu(n[sl]) for n in d["tn"]])
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({k: v.detach().cpu() for k, v in student.named_parameters()}, tmp)
+    cd.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_kd_step_two_processes_equal_one_process(tmp_path):
+    import os
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path / "graph2.pt")
+    mp.spawn(_graph2_worker, args=(2, 29500 + (os.getpid() % 90), tmp), nprocs=2, join=True)
+    got = torch.load(tmp)
+    g = load_npz("kd_step_tiny")
+    meta = load_json("kd_step_tiny_meta")
+    student, teacher, disc = _graph2_models(g, meta)
+    d = _graph2_inputs(g, meta)
+    step = kd.KDStep(student, teacher, disc, latent=24)
+    for _ in range(2):
+        step.g_step([cu(z) for z in d["z"]], 3, cu(d["mask"]), [cu(n) for n in d["sn"]], [cu(n) for n in d["tn"]])
+    for k, p in student.named_parameters():
+        # two Adam steps (beta1 = 0: update = lr * g / sqrt(v)) on gradients that differ at atomics / summation-order level
+        assert_close(got[k], p.detach(), 2e-3, "2-process graph replay param " + k)

@@ -48,7 +48,7 @@ def test_oracle_saliency_matches_reference():
         assert_close(gr.abs().mean(dim=[0, 1, 3, 4]), g[f"score{i}"], 5e-5, f"oracle layer {i}")
 
 
-def test_salt_pepper_statistics_and_sharded_sum():
+def test_salt_pepper_statistics():
     torch.manual_seed(0)
     mask = torch.zeros(8, 1, 64, 64)
     mask[:, :, 16:48, 16:48] = 1
@@ -57,3 +57,55 @@ def test_salt_pepper_statistics_and_sharded_sum():
     frac = float(hit.sum() / mask.sum())
     assert 0.22 < frac < 0.28
     assert set(sp[hit > 0].unique().tolist()) == {-1.0, 1.0} and float(sp[hit == 0].abs().sum()) == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# sharded sweep: batches dealt round-robin to 2 gloo ranks + one all-reduce == the single-process sweep
+# ---------------------------------------------------------------------------------------------------
+def _sweep_objects():
+    g = load_npz("saliency_tiny")
+    meta = load_json("generator_tiny_keys")
+    net = M.Generator(meta["config"]["size"], meta["config"]["style_dim"], meta["config"]["n_mlp"],
+                      generator_net_shape=meta["config"]["shape"])
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    size = meta["config"]["size"]
+
+    def mask_fn(img):
+        m = torch.zeros(img.shape[0], 1, size, size)
+        m[:, :, 6:26, 8:24] = 1
+        return m
+
+    def noise_fn(idx, b):
+        gen = torch.Generator().manual_seed(1000 + idx)
+        return [torch.randn(b, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), generator=gen) for i in range(net.num_layers)]
+
+    return net, mask_fn, noise_fn, meta["config"]["style_dim"]
+
+
+def _sweep_worker(rank, world, port, tmp):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from cagc import distributed as cd
+    torch.set_num_threads(2)
+    cd.init_from_env(backend="gloo")
+    net, mask_fn, noise_fn, sdim = _sweep_objects()
+    sc = prune.content_aware_scores(net, 5 * 3, 3, 0.3, mask_fn, torch.device("cpu"), latent_dim=sdim, rank=rank, world=world,
+                                    seed=77, noise_fn=noise_fn)
+    if rank == 0:
+        torch.save([t.clone() for t in sc], tmp)
+    cd.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_saliency_sweep_two_ranks_equal_one_rank(tmp_path):
+    import os
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path / "sweep.pt")
+    mp.spawn(_sweep_worker, args=(2, 29700 + (os.getpid() % 200), tmp), nprocs=2, join=True)
+    got = torch.load(tmp)
+    net, mask_fn, noise_fn, sdim = _sweep_objects()
+    want = prune.content_aware_scores(net, 5 * 3, 3, 0.3, mask_fn, torch.device("cpu"), latent_dim=sdim, seed=77, noise_fn=noise_fn)
+    assert len(got) == len(want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert_close(a, b, 1e-6, f"sharded score layer {i}")
