@@ -56,8 +56,8 @@ def conv_flops(name, a):
     if name == "cagc_wino_conv3x3":      # (out,x,up,s,B,Cin,Cout,H,W,...): Winograd F(2x2,3x3) — count the flops the
         B, cin, cout, H, W = a[4:9]      # MFMA pipe EXECUTES (16 GEMMs over H/2*W/2 tiles = 4 MACs per output pixel
         return 2.0 * B * cin * cout * 4 * H * W   # and channel pair), not the 9 of the direct conv it replaces
-    if name == "cagc_wino_conv3x3_act_dgrad":   # (gx,gout,act_out,up,B,Cin,Cout,H,W,...)
-        B, cin, cout, H, W = a[4:9]
+    if name == "cagc_wino_conv3x3_act_dgrad":   # (gx,gout,act_out,up,residual,B,Cin,Cout,H,W,...)
+        B, cin, cout, H, W = a[5:10]
         return 2.0 * B * cin * cout * 4 * H * W
     if name in ("cagc_conv3x3s2_fwd", "cagc_conv3x3s2_dgrad"):   # (out,x,wp,B,Cin,Cout,Hin,Win,pitch)
         B, cin, cout, hin, win = a[3:8]
@@ -131,7 +131,7 @@ class KernelTimer:
             key = name
             if name in ("cagc_wino_conv3x3", "cagc_wino_conv3x3_act_dgrad"):   # one record family per device kernel, so the
                 gated = name.endswith("act_dgrad")                              # average launch duration is comparable with the
-                nblk = -(-(args[5] if gated else args[6]) // 16)                # rocprofv3 per-symbol summary (conv_wino.hip wino_mb)
+                nblk = -(-(args[6]) // 16)                                      # rocprofv3 per-symbol summary (conv_wino.hip wino_mb)
                 mb = nblk if nblk <= 3 else (3 if (nblk % 4 != 0 and nblk % 3 == 0) else 4)
                 key = f"{name}[k_wino<{mb}, {'true' if gated else 'false'}>]"
             self.records.append((key, s, e, conv_flops(name, args), stream_bytes(name, args)))

@@ -47,7 +47,7 @@ _PROTOS = {
     "cagc_wino_packed_elems": [_i, _i],
     "cagc_wino_prep": [_p, _p, _i, _i, _f, _i, _p],
     "cagc_wino_conv3x3": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _f, _f, _p],
-    "cagc_wino_conv3x3_act_dgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p],
+    "cagc_wino_conv3x3_act_dgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p],
     "cagc_fir4x4_pitched": [_p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "cagc_conv3x3s2_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "cagc_conv3x3s2_dgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

@@ -642,7 +642,29 @@ class ResBlock(nn.Module):
         self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=True)
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, activate=False, bias=False)
 
+    def _frozen_fast_path(self, input):
+        """Generator step (D frozen, only the input gradient wanted), Winograd-sized feature map, the stock layer pattern."""
+        c1, c2, sk = self.conv1, self.conv2, self.skip
+        if not (mc.FUSE_RESBLOCK and mc.WINO_DGRAD and mc.FUSE_ACT_DGRAD and mc.use_hip(input) and input.dtype == torch.float32
+                and torch.is_grad_enabled() and input.requires_grad and input.dim() == 4):
+            return False
+        if any(p.requires_grad for p in self.parameters()):
+            return False
+        H, W = input.shape[2], input.shape[3]
+        return (c1._fused_s1 and c2._fused_down and sk._fused_skip and mc.wino_ok(H, W) and H % 2 == 0 and W % 2 == 0
+                and c1[1].bias is not None and c1[1].negative_slope == 0.2 and c2[1].bias is None and len(c2) == 3
+                and isinstance(c2[2], FusedLeakyReLU) and c2[2].bias is not None and c2[2].negative_slope == 0.2
+                and tuple(c2[0].pad) == (2, 2) and tuple(sk[0].pad) == (1, 1) and sk[1].bias is None)
+
     def forward(self, input):
+        if self._frozen_fast_path(input):
+            c1, c2, sk = self.conv1, self.conv2, self.skip
+            up1_fwd, up1_bwd = c1._wino_weights(c1[0])
+            wp2_fwd, wp2_bwd = c2._packed_weights(c2[1])
+            wpsk_fwd, wpsk_bwd = sk._packed_weights(sk[1])
+            return mc._ResBlockFrozen.apply(input, c1[0].weight, c1[1].bias, up1_fwd, up1_bwd, c2[1].weight, c2[2].bias, wp2_fwd,
+                                            wp2_bwd, c2[0].kernel, tuple(c2[0].pad), sk[1].weight, wpsk_fwd, wpsk_bwd,
+                                            sk[0].kernel, tuple(sk[0].pad))
         a, b = self.conv2(self.conv1(input)), self.skip(input)
         if mc.use_hip(a):
             return mc.add_scale(a, b, 1.0 / math.sqrt(2))

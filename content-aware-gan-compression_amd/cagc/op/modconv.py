@@ -26,6 +26,8 @@ EPI_LINEAR, EPI_STYLED = 0, 1
 WINO_DGRAD = os.environ.get("CAGC_WINO_DGRAD", "1") == "1"
 # frozen-D data gradient of conv3x3 + FusedLeakyReLU as ONE launch (activation backward fused into the conv's staging)
 FUSE_ACT_DGRAD = os.environ.get("CAGC_FUSE_ACT_DGRAD", "1") == "1"
+# frozen discriminator ResBlocks as one autograd node (gradient merge / scale folded into the kernels)
+FUSE_RESBLOCK = os.environ.get("CAGC_FUSE_RESBLOCK", "1") == "1"
 SQRT2 = 2 ** 0.5
 
 # ---------------------------------------------------------------------------------------------------
@@ -352,8 +354,8 @@ class _Conv3x3Act(Function):
             # kernel's input staging, one launch instead of a streaming pass + a conv
             gx = torch.empty(B, C, H, W, dtype=gout.dtype, device=gout.device)
             with _lib.on_device(gout):
-                _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(gout), _lib.ptr(out), _lib.ptr(up_bwd), B, C, cout,
-                          H, W, 0.2, SQRT2)
+                _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(gout), _lib.ptr(out), _lib.ptr(up_bwd), None, B, C,
+                          cout, H, W, 0.2, SQRT2)
             return gx, None, None, None, None, None
         gz = torch.empty_like(gout)
         gbias = torch.zeros(cout, dtype=gout.dtype, device=gout.device) if ctx.needs_input_grad[2] else None
@@ -539,6 +541,100 @@ class _BlurDownConv1x1(Function):
             y = _launch(x, fir, (1, 1), (2, 2), p4, (ho, wo))
             gweight = cc.wgrad_s1(gout, y, 1, scale)
         return gx, gweight, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# Frozen discriminator ResBlock (generator step): one autograd node
+# ---------------------------------------------------------------------------------------------------
+_flip_scaled_cache = {}
+
+
+def _flipped_scaled(fir, scale):
+    """flip(fir) * scale, cached per tensor object (see _flipped)."""
+    key = (id(fir), float(scale))
+    e = _flip_scaled_cache.get(key)
+    if e is None or e[0] is not fir or e[1] != fir._version:
+        if len(_flip_scaled_cache) > 64:
+            _flip_scaled_cache.clear()
+        e = (fir, fir._version, (_flipped(fir) * scale).contiguous())
+        _flip_scaled_cache[key] = e
+    return e[2]
+
+
+class _ResBlockFrozen(Function):
+    """ResBlock of the discriminator (reference model.py:719-737: conv1 3x3 -> conv2 Blur + 3x3 stride 2, skip Blur + 1x1
+    stride 2, (a + b) / sqrt 2) with FROZEN weights, as ONE autograd node: forward = the same kernels the three ConvLayers
+    launch; backward returns only the input gradient and folds what autograd would add as separate passes into them —
+    the 1/sqrt 2 of the merge rides in the activation backward's scale (conv path) and in the adjoint FIR's taps (skip
+    path), and the skip path's gradient is added inside the store of the conv path's last kernel
+    (cagc_wino_conv3x3_act_dgrad residual).  Saves a full-tensor multiply and a full-tensor accumulate per block."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, up1_fwd, up1_bwd, w2, b2, wp2_fwd, wp2_bwd, fir2, pad2, wsk, wpsk_fwd, wpsk_bwd, firsk, padsk):
+        from .upfirdn2d import _launch
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        cout = w2.shape[0]
+        dev = x.device
+        scale = 1.0 / SQRT2
+        with _lib.on_device(x):
+            y1 = torch.empty(B, C, H, W, dtype=x.dtype, device=dev)
+            _lib.call("cagc_wino_conv3x3", _lib.ptr(y1), _lib.ptr(x), _lib.ptr(up1_fwd), None, B, C, C, H, W, EPI_STYLED,
+                      None, None, 0, None, _lib.ptr(b1.detach().contiguous()), 0.2, SQRT2)
+            hb, wb = H + pad2[0] + pad2[1] - 3, W + pad2[0] + pad2[1] - 3
+            pitch = (wb + 3) // 4 * 4
+            ho, wo = (hb - 3) // 2 + 1, (wb - 3) // 2 + 1
+            tmp = torch.empty(B, C, hb, pitch, dtype=x.dtype, device=dev)
+            _lib.call("cagc_fir4x4_pitched", _lib.ptr(tmp), _lib.ptr(y1), _lib.ptr(fir2), B * C, H, W, W, hb, wb, pitch, pad2[0], pad2[0])
+            y2 = torch.empty(B, cout, ho, wo, dtype=x.dtype, device=dev)
+            _lib.call("cagc_conv3x3s2_fwd", _lib.ptr(y2), _lib.ptr(tmp), _lib.ptr(wp2_fwd), B, C, cout, hb, wb, pitch)
+            del tmp
+            y2a = torch.empty_like(y2)
+            _lib.call("cagc_fused_bias_act_fwd", _lib.ptr(y2a), _lib.ptr(y2), _lib.ptr(b2.detach().contiguous()), B, cout, ho * wo,
+                      0.2, SQRT2)
+            del y2
+            ys = _launch(x, firsk, (1, 1), (2, 2), (padsk[0], padsk[1], padsk[0], padsk[1]), (ho, wo))
+            sk = torch.empty(B, cout, ho, wo, dtype=x.dtype, device=dev)
+            _lib.call("cagc_modconv_fwd", _lib.ptr(sk), _lib.ptr(ys), _lib.ptr(wpsk_fwd), None, B, C, cout, ho, wo, 1, EPI_LINEAR,
+                      None, None, 0, None, None, 0.2, 1.0)
+            del ys
+            out = torch.empty_like(sk)
+            _lib.call("cagc_add_scale", _lib.ptr(out), _lib.ptr(y2a), _lib.ptr(sk), out.numel(), scale)
+        ctx.save_for_backward(y1, y2a, up1_bwd, wp2_bwd, wpsk_bwd, fir2, firsk)
+        ctx.cfg = (B, C, H, W, cout, ho, wo, hb, wb, pitch, tuple(pad2), tuple(padsk))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from .upfirdn2d import _launch
+        y1, y2a, up1_bwd, wp2_bwd, wpsk_bwd, fir2, firsk = ctx.saved_tensors
+        B, C, H, W, cout, ho, wo, hb, wb, pitch, pad2, padsk = ctx.cfg
+        g = g.contiguous()
+        dev = g.device
+        scale = 1.0 / SQRT2
+        with _lib.on_device(g):
+            # skip branch: 1x1 data gradient, then the adjoint of the decimating FIR with the merge's 1/sqrt2 in its taps
+            gy = torch.empty(B, C, ho, wo, dtype=g.dtype, device=dev)
+            _lib.call("cagc_modconv_dgrad", _lib.ptr(gy), None, _lib.ptr(g), _lib.ptr(wpsk_bwd), None, None, B, C, cout, ho, wo, 1)
+            gp = (4 - padsk[0] - 1, W - 2 * wo + padsk[0], 4 - padsk[0] - 1, H - 2 * ho + padsk[0])
+            gx_skip = _launch(gy, _flipped_scaled(firsk, scale), (2, 2), (1, 1), gp, (H, W))
+            del gy
+            # conv branch: activation backward carrying the 1/sqrt2, stride-2 data gradient, adjoint blur
+            gz2 = torch.empty_like(g)
+            _lib.call("cagc_fused_bias_act_bwd", _lib.ptr(gz2), None, _lib.ptr(g), _lib.ptr(y2a), B, cout, ho * wo, 0.2, SQRT2 * scale)
+            gtmp = torch.empty(B, C, hb, pitch, dtype=g.dtype, device=dev)
+            _lib.call("cagc_conv3x3s2_dgrad", _lib.ptr(gtmp), _lib.ptr(gz2), _lib.ptr(wp2_bwd), B, C, cout, hb, wb, pitch)
+            del gz2
+            g1 = torch.empty(B, C, H, W, dtype=g.dtype, device=dev)
+            gpad = 4 - pad2[0] - 1
+            _lib.call("cagc_fir4x4_pitched", _lib.ptr(g1), _lib.ptr(gtmp), _lib.ptr(_flipped(fir2)), B * C, hb, wb, pitch, H, W, W, gpad, gpad)
+            del gtmp
+            # conv1: LeakyReLU backward in the staging, the skip branch's gradient added in the store
+            gx = torch.empty(B, C, H, W, dtype=g.dtype, device=dev)
+            _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(g1), _lib.ptr(y1), _lib.ptr(up1_bwd), _lib.ptr(gx_skip),
+                      B, C, C, H, W, 0.2, SQRT2)
+        return (gx,) + (None,) * 15
 
 
 # ---------------------------------------------------------------------------------------------------

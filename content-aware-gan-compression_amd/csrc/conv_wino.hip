@@ -44,6 +44,7 @@ struct WinoArgs {
   const float* up;         // [mtiles][16][Kp/4][64][4]  (k_wino_pack)
   const float* in_scale;   // [B,Cin] or null
   const float* gate;       // [B,Cin,H,W] or null: the staged input is multiplied by lrelu'(gate) = (gate > 0 ? 1 : gate_alpha) * gate_scale
+  const float* residual;   // [B,Cout,H,W] or null: added to the (linear-epilogue) output — gradient accumulation in the store
   float gate_alpha, gate_scale;
   const float* out_scale;  // [B,Cout] or null
   const float* noise;
@@ -290,6 +291,11 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
           float y[2][2] = {{(z[0].x + z[1].x + z[2].x) * osc, (z[0].y + z[1].y + z[2].y) * osc},
                            {(z[1].x - z[2].x - z[3].x) * osc, (z[1].y - z[2].y - z[3].y) * osc}};
           float* op = A.out + ((int64_t)(b * A.Cout + m)) * HW + (int64_t)oy * A.W + ox;
+          if (GATED && A.residual) {   // second gradient contribution of the same tensor (ResBlock skip branch)
+            const float* rp = A.residual + ((int64_t)(b * A.Cout + m)) * HW + (int64_t)oy * A.W + ox;
+            const float2 r0 = *reinterpret_cast<const float2*>(rp), r1 = *reinterpret_cast<const float2*>(rp + A.W);
+            y[0][0] += r0.x; y[0][1] += r0.y; y[1][0] += r1.x; y[1][1] += r1.y;
+          }
 #pragma unroll
           for (int a = 0; a < 2; ++a) {
             float y0v = y[a][0], y1v = y[a][1];
@@ -404,8 +410,9 @@ extern "C" int cagc_wino_conv3x3(float* out, const float* x, const float* up, co
 // cagc_fused_bias_act_bwd pass (12 B per element of HBM traffic) disappears when no bias / weight gradient is wanted
 // (D frozen on the generator step).  up = cagc_wino_prep(..., dgrad = 1) packing; channels: gout/act_out [B,Cout,H,W] ->
 // gx [B,Cin,H,W].
-extern "C" int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const float* act_out, const float* up, int B, int Cin,
-                                           int Cout, int H, int W, float alpha, float act_scale, cagc_stream_t stream) {
+extern "C" int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const float* act_out, const float* up,
+                                           const float* residual, int B, int Cin, int Cout, int H, int W, float alpha,
+                                           float act_scale, cagc_stream_t stream) {
   const char* what = "cagc_wino_conv3x3_act_dgrad";
   CAGC_REQUIRE(gx && gout && act_out && up, "%s: null tensor", what);
   CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
@@ -414,7 +421,8 @@ extern "C" int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const f
   CAGC_REQUIRE((int64_t)B * Cout * H * W < (1ll << 31), "%s: input too large for 32-bit offsets", what);
   WinoArgs a;
   memset(&a, 0, sizeof(a));
-  a.in = gout; a.gate = act_out; a.gate_alpha = alpha; a.gate_scale = act_scale; a.out = gx; a.up = up;
+  CAGC_REQUIRE(!residual || ((uintptr_t)residual % 8) == 0, "%s: unaligned residual", what);
+  a.in = gout; a.gate = act_out; a.gate_alpha = alpha; a.gate_scale = act_scale; a.out = gx; a.up = up; a.residual = residual;
   a.B = B; a.Cin = Cout; a.Kp = round_up(Cout, WCK); a.Cout = Cin; a.Mp = round_up(Cin, 16); a.H = H; a.W = W;
   a.tiles_x = W / WTW; a.tiles_y = H / WTH; a.nblocks = B * a.tiles_x * a.tiles_y;
   a.epi = CAGC_EPI_LINEAR; a.alpha = alpha; a.act_scale = 1.f;

@@ -243,8 +243,10 @@ int cagc_wino_conv3x3(float* out, const float* x, const float* up, const float* 
  * activation's backward fused into the conv's input staging:  gx [B,Cin,H,W] = dgrad( gout * lrelu'(act_out) ), where
  * lrelu'(v) = (v > 0 ? 1 : alpha) * act_scale and up = cagc_wino_prep(..., dgrad = 1).  Replaces fused_bias_act(grad=1)
  * (op/fused_act.py:29-39) + cuDNN dgrad when neither grad_bias nor grad_weight is wanted (D frozen on the G step). */
-int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const float* act_out, const float* up, int B, int Cin,
-                                int Cout, int H, int W, float alpha, float act_scale, cagc_stream_t stream);
+/* residual [B,Cin,H,W] [nullable]: added to gx in the kernel's store (a second gradient contribution of the same tensor —
+ * the ResBlock's skip branch — without the separate accumulation pass autograd would launch; may alias nothing). */
+int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const float* act_out, const float* up, const float* residual,
+                                int B, int Cin, int Cout, int H, int W, float alpha, float act_scale, cagc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Discriminator down-sampling conv  replaces the reference's Blur(pad=(2,2)) -> EqualConv2d(3x3, stride 2,

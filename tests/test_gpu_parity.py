@@ -741,3 +741,33 @@ def test_graphed_kd_step_two_processes_equal_one_process(tmp_path):
     for k, p in student.named_parameters():
         # two Adam steps (beta1 = 0: update = lr * g / sqrt(v)) on gradients that differ at atomics / summation-order level
         assert_close(got[k], p.detach(), 2e-3, "2-process graph replay param " + k)
+
+
+@pytest.mark.parametrize("cfg", [(2, 128, 256, 64, 64), (3, 64, 64, 32, 32), (16, 128, 256, 256, 256)])
+def test_frozen_resblock_single_node_matches_layerwise_path(cfg):
+    """Frozen D ResBlock as ONE autograd node (merge scale folded into the activation backward / adjoint FIR, skip-branch
+    gradient added inside the Winograd data-gradient kernel's store) vs the layer-by-layer path: identical forward, input
+    gradient equal up to the re-association of the 1/sqrt(2) factor."""
+    from cagc.op import modconv as mc
+    B, cin, cout, H, W = cfg
+    torch.manual_seed(13)
+    blk = M.ResBlock(cin, cout).to(DEV)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(0.1 * torch.randn_like(p))
+    kd.requires_grad(blk, False)
+    x = torch.randn(B, cin, H, W, device=DEV, requires_grad=True)
+    go = torch.randn(B, cout, H // 2, W // 2, device=DEV)
+    res = {}
+    for fused in (True, False):
+        mc.FUSE_RESBLOCK = fused
+        try:
+            assert blk._frozen_fast_path(x) == fused
+            y = blk(x)
+            (gx,) = torch.autograd.grad(y, x, go)
+            res[fused] = (y.detach(), gx)
+        finally:
+            mc.FUSE_RESBLOCK = True
+    assert torch.equal(res[True][0], res[False][0])
+    assert_close(res[True][1], res[False][1], 2e-6, f"{cfg} frozen ResBlock input gradient")
