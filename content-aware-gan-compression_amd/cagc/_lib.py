@@ -21,6 +21,7 @@ _PROTOS = {
     "cagc_fused_bias_act_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _p],
     "cagc_fused_bias_act_bwd2": [_p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _p],
     "cagc_upfirdn2d": [_p, _p, _p, _i64] + [_i] * 14 + [_p],
+    "cagc_fir4x4_up2_acc": [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _p],
     "cagc_pixelnorm_fwd": [_p, _p, _i64, _i, _p],
     "cagc_pixelnorm_bwd": [_p, _p, _p, _i64, _i, _p],
     "cagc_demod_fwd": [_p, _p, _p, _i, _i, _i, _p],

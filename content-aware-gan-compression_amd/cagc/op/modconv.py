@@ -614,12 +614,6 @@ class _ResBlockFrozen(Function):
         dev = g.device
         scale = 1.0 / SQRT2
         with _lib.on_device(g):
-            # skip branch: 1x1 data gradient, then the adjoint of the decimating FIR with the merge's 1/sqrt2 in its taps
-            gy = torch.empty(B, C, ho, wo, dtype=g.dtype, device=dev)
-            _lib.call("cagc_modconv_dgrad", _lib.ptr(gy), None, _lib.ptr(g), _lib.ptr(wpsk_bwd), None, None, B, C, cout, ho, wo, 1)
-            gp = (4 - padsk[0] - 1, W - 2 * wo + padsk[0], 4 - padsk[0] - 1, H - 2 * ho + padsk[0])
-            gx_skip = _launch(gy, _flipped_scaled(firsk, scale), (2, 2), (1, 1), gp, (H, W))
-            del gy
             # conv branch: activation backward carrying the 1/sqrt2, stride-2 data gradient, adjoint blur
             gz2 = torch.empty_like(g)
             _lib.call("cagc_fused_bias_act_bwd", _lib.ptr(gz2), None, _lib.ptr(g), _lib.ptr(y2a), B, cout, ho * wo, 0.2, SQRT2 * scale)
@@ -630,10 +624,22 @@ class _ResBlockFrozen(Function):
             gpad = 4 - pad2[0] - 1
             _lib.call("cagc_fir4x4_pitched", _lib.ptr(g1), _lib.ptr(gtmp), _lib.ptr(_flipped(fir2)), B * C, hb, wb, pitch, H, W, W, gpad, gpad)
             del gtmp
-            # conv1: LeakyReLU backward in the staging, the skip branch's gradient added in the store
+            # conv1: LeakyReLU backward in the Winograd kernel's staging
             gx = torch.empty(B, C, H, W, dtype=g.dtype, device=dev)
-            _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(g1), _lib.ptr(y1), _lib.ptr(up1_bwd), _lib.ptr(gx_skip),
+            _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(g1), _lib.ptr(y1), _lib.ptr(up1_bwd), None,
                       B, C, C, H, W, 0.2, SQRT2)
+            del g1
+            # skip branch: 1x1 data gradient, then the adjoint of the decimating FIR (the merge's 1/sqrt2 in its taps) added
+            # onto gx in the same streaming pass.  (Adding it inside the Winograd kernel's store instead was measured: +0.4 ms
+            # on that MFMA-bound kernel's un-overlapped epilogue for the 0.36 ms pass it saved — bench_r2_i.)
+            gy = torch.empty(B, C, ho, wo, dtype=g.dtype, device=dev)
+            _lib.call("cagc_modconv_dgrad", _lib.ptr(gy), None, _lib.ptr(g), _lib.ptr(wpsk_bwd), None, None, B, C, cout, ho, wo, 1)
+            gp = (4 - padsk[0] - 1, W - 2 * wo + padsk[0], 4 - padsk[0] - 1, H - 2 * ho + padsk[0])
+            if gp == (2, 1, 2, 1) and W % 4 == 0:
+                _lib.call("cagc_fir4x4_up2_acc", _lib.ptr(gx), _lib.ptr(gy), _lib.ptr(_flipped_scaled(firsk, scale)), _lib.ptr(gx),
+                          B * C, ho, wo, H, W)
+            else:
+                gx += _launch(gy, _flipped_scaled(firsk, scale), (2, 2), (1, 1), gp, (H, W))
         return (gx,) + (None,) * 15
 
 

@@ -160,9 +160,9 @@ __global__ __launch_bounds__(256) void k_fir_s1(float* __restrict__ out, const f
 // skip blur): polyphase — every output has exactly 2x2 non-zero taps.  32x32 output tile from an 18x18 input patch;
 // thread = (output row, 4 adjacent columns): 2 rows x 4 columns of the patch in registers (8 LDS reads for 4 outputs,
 // the generic kernel does 16 predicated reads per output), one 16-byte store.  Requires out_w % 4 == 0.
-__global__ __launch_bounds__(256) void k_fir4_up2(float* __restrict__ out, const float* __restrict__ x,
-                                                  const float* __restrict__ kern, int in_h, int in_w, int out_h, int out_w,
-                                                  int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) void k_fir4_up2(float* out, const float* __restrict__ x,
+                                                  const float* __restrict__ kern, const float* acc, int in_h, int in_w,
+                                                  int out_h, int out_w, int tiles_x, int tiles_y) {
   constexpr int IT = FT / 2 + 2, LW = IT + 1;   // 18 input rows / cols: iy = Y0/2 - 1 .. Y0/2 + 16
   __shared__ float tile[IT * LW];
   __shared__ float kf[16];
@@ -203,7 +203,12 @@ __global__ __launch_bounds__(256) void k_fir4_up2(float* __restrict__ out, const
     o[2] += w[a][1] * k0 + w[a][2] * k2;   // X+2 (even): cols X/2, X/2+1
     o[3] += w[a][2] * k1 + w[a][3] * k3;   // X+3 (odd):  cols X/2+1, X/2+2
   }
-  *reinterpret_cast<float4*>(out + (p * out_h + Y) * (int64_t)out_w + X) = make_float4(o[0], o[1], o[2], o[3]);
+  const int64_t oi = (p * out_h + Y) * (int64_t)out_w + X;
+  if (acc) {   // out = fir(x) + acc  (acc may alias out: every thread reads exactly the 4 elements it then writes)
+    const float4 a = *reinterpret_cast<const float4*>(acc + oi);
+    o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
+  }
+  *reinterpret_cast<float4*>(out + oi) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // 4x4 FIR + 2x decimation with pad0 = 1 (the discriminator's skip path evaluated only where its stride-2 1x1 conv
@@ -546,7 +551,8 @@ extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, i
       hipLaunchKernelGGL((k_fir4_updown<1, 2>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w,
                          pad_x0, pad_y0, tx, ty);
     else if (pad_x0 == 2 && pad_y0 == 2 && out_w % 4 == 0 && ((uintptr_t)out % 16) == 0)
-      hipLaunchKernelGGL(k_fir4_up2, dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w, tx, ty);
+      hipLaunchKernelGGL(k_fir4_up2, dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, (const float*)nullptr, in_h, in_w, out_h,
+                         out_w, tx, ty);
     else
       hipLaunchKernelGGL((k_fir4_updown<2, 1>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w,
                          pad_x0, pad_y0, tx, ty);
@@ -612,4 +618,23 @@ extern "C" int cagc_fir4x4_pitched(float* out, const float* x, const float* kern
     hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, x, kernel, in_h, in_w,
                        in_pitch, out_h, out_w, out_pitch, pad_x0, pad_y0, tx, ty);
   return check_launch("cagc_fir4x4_pitched");
+}
+
+// out = upfirdn2d(x, kernel 4x4, up = 2, pad0 = 2) + acc — the adjoint of the discriminator skip path's decimating blur
+// accumulated onto the gradient the ResBlock's conv path already produced (acc may alias out), instead of a separate
+// full-tensor add.  Only the polyphase fast path (out_w % 4 == 0, 16-byte aligned); otherwise CAGC_ERR_UNSUPPORTED.
+extern "C" int cagc_fir4x4_up2_acc(float* out, const float* x, const float* kernel, const float* acc, int64_t planes, int in_h,
+                                   int in_w, int out_h, int out_w, cagc_stream_t stream) {
+  if (planes == 0) return CAGC_OK;
+  CAGC_REQUIRE(out && x && kernel && acc && planes > 0 && in_h > 0 && in_w > 0, "cagc_fir4x4_up2_acc: bad argument");
+  if (!(out_h == 2 * in_h && out_w == 2 * in_w && out_w % 4 == 0 && (((uintptr_t)out | (uintptr_t)acc) % 16) == 0)) {
+    set_error("cagc_fir4x4_up2_acc: shape / alignment not covered by the polyphase kernel");
+    return CAGC_ERR_UNSUPPORTED;
+  }
+  const int tx = cdiv(out_w, FT), ty = cdiv(out_h, FT);
+  const int64_t nb = planes * tx * ty;
+  CAGC_REQUIRE(nb < (1ll << 31), "cagc_fir4x4_up2_acc: too large");
+  hipLaunchKernelGGL(k_fir4_up2, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, x, kernel, acc, in_h, in_w, out_h, out_w,
+                     tx, ty);
+  return check_launch("cagc_fir4x4_up2_acc");
 }

@@ -78,6 +78,13 @@ int cagc_upfirdn2d(float* out, const float* x, const float* kernel, int64_t plan
                    int out_h, int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
                    int pad_x0, int pad_x1, int pad_y0, int pad_y1, cagc_stream_t stream);
 
+/* out [planes,2h,2w] = upfirdn2d(x [planes,h,w], kernel 4x4, up = 2, pad = (2,1)) + acc (acc may alias out): the adjoint
+ * of the discriminator skip path's decimating blur (op/upfirdn2d.py:29-43) accumulated onto the gradient the ResBlock's
+ * conv path already produced, instead of autograd's separate full-tensor add.  2w % 4 == 0, 16-byte aligned tensors;
+ * otherwise CAGC_ERR_UNSUPPORTED (the caller falls back to cagc_upfirdn2d + an add). */
+int cagc_fir4x4_up2_acc(float* out, const float* x, const float* kernel, const float* acc, int64_t planes, int in_h,
+                        int in_w, int out_h, int out_w, cagc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * PixelNorm                         replaces model.py:23-24 (4 composed torch kernels).
  * x [rows, dim]: y = x * rsqrt(mean(x^2) + 1e-8).  One wavefront per row, shuffle reduction.
