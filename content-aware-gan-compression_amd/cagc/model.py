@@ -171,7 +171,7 @@ def invalidate_caches(module):
     write, a HIP-graph replay that rewrites a frozen weight) must be followed by this call.  `cagc.kd.accumulate` and
     `load_checkpoint` call it; `load_state_dict` / optimiser steps bump the counter themselves."""
     for m in module.modules():
-        for attr in ("_scaled", "_packed", "_wino", "_packed_wino"):
+        for attr in ("_scaled", "_packed", "_wino", "_packed_wino", "_packed_gemm"):
             if getattr(m, attr, None) is not None:
                 setattr(m, attr, None)
 
@@ -580,7 +580,26 @@ class ConvLayer(nn.Sequential):
     def _apply(self, fn, *a, **k):
         self._packed = None
         self._packed_wino = None
+        self._packed_gemm = None
         return super()._apply(fn, *a, **k)
+
+    def _gemm_weights(self, conv):
+        """(scale*W [Cout,Cin], its transpose) of a 1x1 conv, for the plain-GEMM formulation of the ResBlock skip (a 1x1
+        convolution over NCHW is out[b] = W @ x[b]: a library batched SGEMM, rocBLAS reaches 90-130 TFLOP/s on these
+        shapes where the implicit-GEMM kernel's 8-channel chunks give 63-90 — scripts/time_1x1.py).  Cached for frozen
+        weights like the packed operands."""
+        w = conv.weight
+        def make():
+            w2 = (w.detach().reshape(w.shape[0], w.shape[1]) * conv.scale).contiguous()
+            return w2, w2.t().contiguous()
+        if w.requires_grad:
+            return make()
+        key = (w._version, w.data_ptr(), w.device)
+        c = getattr(self, "_packed_gemm", None)
+        if c is None or c[0] != key:
+            c = (key, make())
+            self._packed_gemm = c
+        return c[1]
 
     def _wino_weights(self, conv):
         w = conv.weight
@@ -661,7 +680,7 @@ class ResBlock(nn.Module):
             c1, c2, sk = self.conv1, self.conv2, self.skip
             up1_fwd, up1_bwd = c1._wino_weights(c1[0])
             wp2_fwd, wp2_bwd = c2._packed_weights(c2[1])
-            wpsk_fwd, wpsk_bwd = sk._packed_weights(sk[1])
+            wpsk_fwd, wpsk_bwd = sk._gemm_weights(sk[1])
             return mc._ResBlockFrozen.apply(input, c1[0].weight, c1[1].bias, up1_fwd, up1_bwd, c2[1].weight, c2[2].bias, wp2_fwd,
                                             wp2_bwd, c2[0].kernel, tuple(c2[0].pad), sk[1].weight, wpsk_fwd, wpsk_bwd,
                                             sk[0].kernel, tuple(sk[0].pad))

@@ -566,8 +566,9 @@ class _ResBlockFrozen(Function):
     stride 2, (a + b) / sqrt 2) with FROZEN weights, as ONE autograd node: forward = the same kernels the three ConvLayers
     launch; backward returns only the input gradient and folds what autograd would add as separate passes into them —
     the 1/sqrt 2 of the merge rides in the activation backward's scale (conv path) and in the adjoint FIR's taps (skip
-    path), and the skip path's gradient is added inside the store of the conv path's last kernel
-    (cagc_wino_conv3x3_act_dgrad residual).  Saves a full-tensor multiply and a full-tensor accumulate per block."""
+    path), the skip path's gradient is accumulated in the adjoint FIR's streaming pass (cagc_fir4x4_up2_acc), and the skip's
+    1x1 conv is a library batched SGEMM whose epilogue (alpha, beta) performs the residual merge.  Saves a full-tensor
+    multiply, a full-tensor accumulate and the merge pass per block."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, up1_fwd, up1_bwd, w2, b2, wp2_fwd, wp2_bwd, fir2, pad2, wsk, wpsk_fwd, wpsk_bwd, firsk, padsk):
@@ -594,12 +595,11 @@ class _ResBlockFrozen(Function):
                       0.2, SQRT2)
             del y2
             ys = _launch(x, firsk, (1, 1), (2, 2), (padsk[0], padsk[1], padsk[0], padsk[1]), (ho, wo))
-            sk = torch.empty(B, cout, ho, wo, dtype=x.dtype, device=dev)
-            _lib.call("cagc_modconv_fwd", _lib.ptr(sk), _lib.ptr(ys), _lib.ptr(wpsk_fwd), None, B, C, cout, ho, wo, 1, EPI_LINEAR,
-                      None, None, 0, None, None, 0.2, 1.0)
+            # skip 1x1 conv + residual merge as ONE library batched SGEMM with its epilogue:
+            #   out[b] = (1/sqrt2) * (W_skip @ ys[b]) + (1/sqrt2) * y2a[b]          (wpsk_fwd = scale * W_skip, [Cout,Cin])
+            out = torch.baddbmm(y2a.view(B, cout, ho * wo), wpsk_fwd.unsqueeze(0).expand(B, cout, C), ys.view(B, C, ho * wo),
+                                beta=scale, alpha=scale).view(B, cout, ho, wo)
             del ys
-            out = torch.empty_like(sk)
-            _lib.call("cagc_add_scale", _lib.ptr(out), _lib.ptr(y2a), _lib.ptr(sk), out.numel(), scale)
         ctx.save_for_backward(y1, y2a, up1_bwd, wp2_bwd, wpsk_bwd, fir2, firsk)
         ctx.cfg = (B, C, H, W, cout, ho, wo, hb, wb, pitch, tuple(pad2), tuple(padsk))
         return out
@@ -632,8 +632,7 @@ class _ResBlockFrozen(Function):
             # skip branch: 1x1 data gradient, then the adjoint of the decimating FIR (the merge's 1/sqrt2 in its taps) added
             # onto gx in the same streaming pass.  (Adding it inside the Winograd kernel's store instead was measured: +0.4 ms
             # on that MFMA-bound kernel's un-overlapped epilogue for the 0.36 ms pass it saved — bench_r2_i.)
-            gy = torch.empty(B, C, ho, wo, dtype=g.dtype, device=dev)
-            _lib.call("cagc_modconv_dgrad", _lib.ptr(gy), None, _lib.ptr(g), _lib.ptr(wpsk_bwd), None, None, B, C, cout, ho, wo, 1)
+            gy = torch.matmul(wpsk_bwd, g.view(B, cout, ho * wo)).view(B, C, ho, wo)      # W_skip^T @ g[b]: library SGEMM
             gp = (4 - padsk[0] - 1, W - 2 * wo + padsk[0], 4 - padsk[0] - 1, H - 2 * ho + padsk[0])
             if gp == (2, 1, 2, 1) and W % 4 == 0:
                 _lib.call("cagc_fir4x4_up2_acc", _lib.ptr(gx), _lib.ptr(gy), _lib.ptr(_flipped_scaled(firsk, scale)), _lib.ptr(gx),
