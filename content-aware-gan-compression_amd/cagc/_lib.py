@@ -54,6 +54,8 @@ _PROTOS = {
     "cagc_conv3x3s2_dgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "cagc_torgb_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "cagc_torgb_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "cagc_fromrgb_fwd": [_p, _p, _p, _p, _i, _i, _i64, _f, _f, _f, _p],
+    "cagc_fromrgb_act_dgrad": [_p, _p, _p, _p, _i, _i, _i64, _f, _f, _f, _p],
     "cagc_masked_l1": [_p, _p, _p, _p, _p, _i, _i, _i64, _f, _p],
     "cagc_add_scale": [_p, _p, _p, _i64, _f, _p],
     "cagc_scale_reduce": [_p, _p, _p, _p, _i, _i, _i64, _p],

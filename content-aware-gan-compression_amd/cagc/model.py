@@ -627,6 +627,11 @@ class ConvLayer(nn.Sequential):
             conv, act = self[0], self[1]
             up_fwd, up_bwd = self._wino_weights(conv)
             return mc._Conv3x3Act.apply(input, conv.weight, act.bias, up_fwd, up_bwd, conv.scale)
+        # from-RGB layer with frozen weights (generator step): two streaming kernels (3 input channels is no GEMM)
+        if (self._fused_1x1 and mc.use_hip(input) and input.dtype == torch.float32 and input.shape[1] == 3
+                and (input.shape[2] * input.shape[3]) % 4 == 0 and self[1].bias is not None and self[1].negative_slope == 0.2
+                and not self[0].weight.requires_grad and not self[1].bias.requires_grad):
+            return mc._FromRGBFrozen.apply(input, self[0].weight, self[1].bias, self[0].scale)
         # 1x1 conv + FusedLeakyReLU (the discriminator's from-RGB layer), and the 3x3 ones too small for the Winograd tiling
         # (4^2 .. 16^2), as one implicit-GEMM launch with the bias + LeakyReLU epilogue
         if ((self._fused_1x1 or self._fused_s1) and mc.use_hip(input) and input.dtype == torch.float32

@@ -423,6 +423,37 @@ class _ConvActDirect(Function):
         return gx, gweight, gbias, None, None, None
 
 
+class _FromRGBFrozen(Function):
+    """Discriminator from-RGB layer with frozen weights (generator step): EqualConv2d(3 -> C, 1x1) -> FusedLeakyReLU as one
+    streaming kernel forward, and activation backward + 1x1 data gradient as one streaming kernel backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale):
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        C = weight.shape[0]
+        out = torch.empty(B, C, H, W, dtype=x.dtype, device=x.device)
+        w = weight.detach().reshape(C, 3).contiguous()
+        with _lib.on_device(x):
+            _lib.call("cagc_fromrgb_fwd", _lib.ptr(out), _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias.detach().contiguous()), B, C, H * W,
+                      float(scale), 0.2, SQRT2)
+        ctx.save_for_backward(out, w)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        out, w = ctx.saved_tensors
+        B, C, H, W = out.shape
+        gout = gout.contiguous()
+        gx = torch.empty(B, 3, H, W, dtype=gout.dtype, device=gout.device)
+        with _lib.on_device(gout):
+            _lib.call("cagc_fromrgb_act_dgrad", _lib.ptr(gx), _lib.ptr(gout), _lib.ptr(out), _lib.ptr(w), B, C, H * W, ctx.scale, 0.2,
+                      SQRT2)
+        return gx, None, None, None
+
+
 class _BlurConvS2(Function):
     """x [B,C,H,W] -> blur (4x4 FIR, pad (p0,p1)) -> 3x3 stride-2 conv.  The blurred (H+1)-wide intermediate lives
     only inside this op, at a 16-byte row pitch, so the MFMA conv stages it with 16-byte loads."""

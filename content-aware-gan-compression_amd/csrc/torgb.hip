@@ -287,3 +287,107 @@ extern "C" int cagc_torgb_bwd(float* gx, float* gws, const float* g, const float
                      nchunk, nsplit, scale);
   return check_launch(what);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Discriminator from-RGB layer (reference model.py:756: ConvLayer(3, C, 1) = EqualConv2d 1x1 -> FusedLeakyReLU) as two
+// streaming kernels.  With 3 input channels this is no GEMM (K = 3): the implicit-GEMM kernel pads K to a chunk of 8 and
+// spends its time writing the 128-channel output through the MFMA epilogue (0.45 ms at bs 16); as a stream it is bound by
+// that one write (537 MB) forward, and by one read of (gout, out) backward — the activation backward and the 1x1 data
+// gradient to 3 channels fused, so the intermediate gz is never written or re-read.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace cagc {
+
+// out[b,c,p] = lrelu(scale * sum_o w[c,o] x[b,o,p] + bias[c]) * act_scale;  thread = 4 pixels, loop over c
+__global__ __launch_bounds__(256) void k_fromrgb_fwd(float* __restrict__ out, const float* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ bias, int C,
+                                                     int64_t HW, int nstrip, float scale, float alpha, float act_scale) {
+  extern __shared__ __attribute__((aligned(16))) float frw[];   // [C][4]: w0 w1 w2 bias
+  const int b = blockIdx.x / nstrip, strip = blockIdx.x - b * nstrip;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    frw[4 * c + 0] = scale * w[3 * c + 0]; frw[4 * c + 1] = scale * w[3 * c + 1]; frw[4 * c + 2] = scale * w[3 * c + 2];
+    frw[4 * c + 3] = bias[c];
+  }
+  __syncthreads();
+  const int64_t p0 = (int64_t)strip * 1024 + threadIdx.x * 4;
+  if (p0 >= HW) return;
+  const float* xb = x + (int64_t)b * 3 * HW + p0;
+  const float4 x0 = *reinterpret_cast<const float4*>(xb), x1 = *reinterpret_cast<const float4*>(xb + HW),
+               x2 = *reinterpret_cast<const float4*>(xb + 2 * HW);
+  float* ob = out + (int64_t)b * C * HW + p0;
+#pragma unroll 4
+  for (int c = 0; c < C; ++c) {
+    const float4 wv = *reinterpret_cast<const float4*>(frw + 4 * c);
+    float4 v;
+    v.x = wv.x * x0.x + wv.y * x1.x + wv.z * x2.x + wv.w;
+    v.y = wv.x * x0.y + wv.y * x1.y + wv.z * x2.y + wv.w;
+    v.z = wv.x * x0.z + wv.y * x1.z + wv.z * x2.z + wv.w;
+    v.w = wv.x * x0.w + wv.y * x1.w + wv.z * x2.w + wv.w;
+    v.x = (v.x > 0.f ? v.x : v.x * alpha) * act_scale; v.y = (v.y > 0.f ? v.y : v.y * alpha) * act_scale;
+    v.z = (v.z > 0.f ? v.z : v.z * alpha) * act_scale; v.w = (v.w > 0.f ? v.w : v.w * alpha) * act_scale;
+    *reinterpret_cast<float4*>(ob + (int64_t)c * HW) = v;
+  }
+}
+
+// gx[b,o,p] = scale * sum_c w[c,o] * gout[b,c,p] * lrelu'(out[b,c,p])
+__global__ __launch_bounds__(256) void k_fromrgb_dgrad(float* __restrict__ gx, const float* __restrict__ gout,
+                                                       const float* __restrict__ act_out, const float* __restrict__ w, int C,
+                                                       int64_t HW, int nstrip, float scale, float alpha, float act_scale) {
+  extern __shared__ __attribute__((aligned(16))) float frw[];   // [C][4]: w0 w1 w2 -
+  const int b = blockIdx.x / nstrip, strip = blockIdx.x - b * nstrip;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    frw[4 * c + 0] = scale * w[3 * c + 0]; frw[4 * c + 1] = scale * w[3 * c + 1]; frw[4 * c + 2] = scale * w[3 * c + 2];
+    frw[4 * c + 3] = 0.f;
+  }
+  __syncthreads();
+  const int64_t p0 = (int64_t)strip * 1024 + threadIdx.x * 4;
+  if (p0 >= HW) return;
+  const float* gb = gout + (int64_t)b * C * HW + p0;
+  const float* ab = act_out + (int64_t)b * C * HW + p0;
+  const float hi = act_scale, lo = alpha * act_scale;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+#pragma unroll 4
+  for (int c = 0; c < C; ++c) {
+    const float4 g = *reinterpret_cast<const float4*>(gb + (int64_t)c * HW);
+    const float4 o = *reinterpret_cast<const float4*>(ab + (int64_t)c * HW);
+    const float4 wv = *reinterpret_cast<const float4*>(frw + 4 * c);
+    const float z0 = g.x * (o.x > 0.f ? hi : lo), z1 = g.y * (o.y > 0.f ? hi : lo), z2 = g.z * (o.z > 0.f ? hi : lo),
+                z3 = g.w * (o.w > 0.f ? hi : lo);
+    a0.x += wv.x * z0; a0.y += wv.x * z1; a0.z += wv.x * z2; a0.w += wv.x * z3;
+    a1.x += wv.y * z0; a1.y += wv.y * z1; a1.z += wv.y * z2; a1.w += wv.y * z3;
+    a2.x += wv.z * z0; a2.y += wv.z * z1; a2.z += wv.z * z2; a2.w += wv.z * z3;
+  }
+  float* xb = gx + (int64_t)b * 3 * HW + p0;
+  *reinterpret_cast<float4*>(xb) = a0;
+  *reinterpret_cast<float4*>(xb + HW) = a1;
+  *reinterpret_cast<float4*>(xb + 2 * HW) = a2;
+}
+
+}  // namespace cagc
+
+extern "C" int cagc_fromrgb_fwd(float* out, const float* x, const float* w, const float* bias, int B, int C, int64_t HW,
+                                float scale, float alpha, float act_scale, cagc_stream_t stream) {
+  if (B == 0) return CAGC_OK;
+  CAGC_REQUIRE(out && x && w && bias && B > 0 && C > 0 && HW > 0, "cagc_fromrgb_fwd: bad argument");
+  if (HW % 4 != 0 || (((uintptr_t)out | (uintptr_t)x) % 16) != 0 || (size_t)C * 16 > 48 * 1024) {
+    cagc::set_error("cagc_fromrgb_fwd: needs HW %% 4 == 0, 16-byte aligned tensors, C <= 3072");
+    return CAGC_ERR_UNSUPPORTED;
+  }
+  const int nstrip = cagc::cdiv(HW, 1024);
+  hipLaunchKernelGGL(cagc::k_fromrgb_fwd, dim3((unsigned)(B * nstrip)), dim3(256), (size_t)C * 16, cagc::as_stream(stream), out, x, w,
+                     bias, C, HW, nstrip, scale, alpha, act_scale);
+  return cagc::check_launch("cagc_fromrgb_fwd");
+}
+
+extern "C" int cagc_fromrgb_act_dgrad(float* gx, const float* gout, const float* act_out, const float* w, int B, int C,
+                                      int64_t HW, float scale, float alpha, float act_scale, cagc_stream_t stream) {
+  if (B == 0) return CAGC_OK;
+  CAGC_REQUIRE(gx && gout && act_out && w && B > 0 && C > 0 && HW > 0, "cagc_fromrgb_act_dgrad: bad argument");
+  if (HW % 4 != 0 || (((uintptr_t)gx | (uintptr_t)gout | (uintptr_t)act_out) % 16) != 0 || (size_t)C * 16 > 48 * 1024) {
+    cagc::set_error("cagc_fromrgb_act_dgrad: needs HW %% 4 == 0, 16-byte aligned tensors, C <= 3072");
+    return CAGC_ERR_UNSUPPORTED;
+  }
+  const int nstrip = cagc::cdiv(HW, 1024);
+  hipLaunchKernelGGL(cagc::k_fromrgb_dgrad, dim3((unsigned)(B * nstrip)), dim3(256), (size_t)C * 16, cagc::as_stream(stream), gx, gout,
+                     act_out, w, C, HW, nstrip, scale, alpha, act_scale);
+  return cagc::check_launch("cagc_fromrgb_act_dgrad");
+}

@@ -290,6 +290,19 @@ int cagc_torgb_bwd(float* gx, float* gws, const float* g, const float* x, const 
                    int B, int C, int H, int W, float scale, cagc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Discriminator from-RGB layer      replaces ConvLayer(3, C, 1) = EqualConv2d(1x1) -> FusedLeakyReLU (model.py:756,
+ *                                   694-716) with two streaming kernels (3 input channels is no GEMM).
+ * cagc_fromrgb_fwd:       out [B,C,HW] = lrelu(scale * w[C,3] . x[B,3,HW] + bias[C], alpha) * act_scale
+ * cagc_fromrgb_act_dgrad: gx [B,3,HW] = scale * sum_c w[c,:] * gout[b,c,p] * lrelu'(act_out[b,c,p])  — the activation's
+ *   backward and the 1x1 data gradient in one pass (frozen D: no bias / weight gradient).
+ * HW % 4 == 0 and 16-byte aligned tensors, else CAGC_ERR_UNSUPPORTED (the caller keeps the implicit-GEMM path).
+ * ---------------------------------------------------------------------------------------------- */
+int cagc_fromrgb_fwd(float* out, const float* x, const float* w, const float* bias, int B, int C, int64_t HW, float scale,
+                     float alpha, float act_scale, cagc_stream_t stream);
+int cagc_fromrgb_act_dgrad(float* gx, const float* gout, const float* act_out, const float* w, int B, int C, int64_t HW,
+                           float scale, float alpha, float act_scale, cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Content-mask distillation loss    replaces Get_Masked_Tensor + mean|T-S| (train.py:156-164,
  *                                   Util/content_aware_pruning.py:90-117) with one fused pass.
  * loss_sum[0] += sum |mask*(t - s)|  (caller zero-inits, divides by numel, multiplies by lambda);

@@ -771,3 +771,30 @@ def test_frozen_resblock_single_node_matches_layerwise_path(cfg):
             mc.FUSE_RESBLOCK = True
     assert_close(res[True][0], res[False][0], 1e-6, f"{cfg} frozen ResBlock output")   # same kernels; split-K atomics at small sizes
     assert_close(res[True][1], res[False][1], 5e-6, f"{cfg} frozen ResBlock input gradient")
+
+
+@pytest.mark.parametrize("cfg", [(2, 128, 64, 64), (3, 36, 20, 24), (16, 128, 256, 256)])
+def test_from_rgb_streaming_kernels_match_implicit_gemm_path(cfg):
+    """Frozen from-RGB layer (cagc_fromrgb_fwd / cagc_fromrgb_act_dgrad) vs the implicit-GEMM path with the fused-act
+    backward (trainable flags on), and vs float64."""
+    B, C, H, W = cfg
+    torch.manual_seed(14)
+    layer = M.ConvLayer(3, C, 1)
+    with torch.no_grad():
+        layer[1].bias.copy_(0.1 * torch.randn(C))
+    x = torch.randn(B, 3, H, W)
+    go = torch.randn(B, C, H, W)
+    xr = x.double().requires_grad_(True)
+    yr = ref_ops.fused_leaky_relu_ref(torch.nn.functional.conv2d(xr, layer[0].weight.detach().double() * layer[0].scale),
+                                      layer[1].bias.detach().double())
+    (gr,) = torch.autograd.grad(yr, xr, go.double())
+    lg = layer.to(DEV)
+    res = {}
+    for frozen in (True, False):
+        kd.requires_grad(lg, not frozen)
+        xg = cu(x).requires_grad_(True)
+        yg = lg(xg)
+        (gg,) = torch.autograd.grad(yg, xg, cu(go))
+        res[frozen] = (yg.detach(), gg)
+        assert_close(yg, yr, 2e-6, f"{cfg} from-RGB out (frozen={frozen})")
+        assert_close(gg, gr, 2e-5, f"{cfg} from-RGB input gradient (frozen={frozen})")
