@@ -797,4 +797,13 @@ def test_from_rgb_streaming_kernels_match_implicit_gemm_path(cfg):
         (gg,) = torch.autograd.grad(yg, xg, cu(go))
         res[frozen] = (yg.detach(), gg)
         assert_close(yg, yr, 2e-6, f"{cfg} from-RGB out (frozen={frozen})")
-        assert_close(gg, gr, 2e-5, f"{cfg} from-RGB input gradient (frozen={frozen})")
+        # a 1x1 layer's input gradient at a pixel depends only on that pixel's LeakyReLU gates: pixels where fp32 rounding put
+        # a gate on the other side of 0 than float64 (pre-activation ~1e-7, a dozen of 134M elements at the largest size)
+        # are excluded, and must be rare and at rounding level
+        flip = ((yg.detach().cpu() > 0) != (yr.detach() > 0))
+        assert int(flip.sum()) <= max(4, 1e-6 * flip.numel())
+        if flip.any():
+            assert float(yr.detach()[flip].abs().max()) < 1e-5 * float(yr.detach().abs().max())
+        keep = ~flip.any(1, keepdim=True)
+        err = ((gg.double().cpu() - gr).abs() * keep).max().item() / gr.abs().max().item()
+        assert err <= 2e-5, f"{cfg} from-RGB input gradient (frozen={frozen}): {err:.3e}"
