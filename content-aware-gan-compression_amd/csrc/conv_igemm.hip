@@ -79,6 +79,7 @@ struct ConvArgs {
   int osy, osx;                // output stride (2 for the data gradient of a stride-2 conv, else 1)
   int min_dy, min_dx;
   int nitems, ksplit, vec;     // vec: 16-byte staging loads are legal (Wpitch % 4 == 0)
+  int dbuf, a_sz, b_sz;        // dbuf: two LDS buffers of a_sz + b_sz floats, ONE barrier per K chunk (launches with <= 4 taps)
   int nblocks, mtiles;         // pixel-tile workgroups (incl. K splits) and channel tiles; grid = nblocks * mtiles
   int epi, noise_bstride_on;
   float alpha, act_scale;
@@ -98,8 +99,13 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
   constexpr int LDA = (MT % 32 == 0) ? MT + 16 : MT;
   constexpr int Q4M = MT / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* a_lds = smem;                        // [MAX_TAPS*CK][LDA]
-  float* b_lds = smem + MAX_TAPS * CK * LDA;  // [CK][PS]
+  // single-buffer layout: a [MAX_TAPS*CK][LDA] then b [CK][PS].  Double-buffer layout (A.dbuf): a [2][a_sz], b [2][b_sz].
+  const int dbuf = A.dbuf;
+  float* const a_base = smem;
+  float* const b_base = smem + (dbuf ? 2 * A.a_sz : MAX_TAPS * CK * LDA);
+  const int a_bs = dbuf ? A.a_sz : 0, b_bs = dbuf ? A.b_sz : 0;
+  const float* a_lds = a_base;
+  const float* b_lds = b_base;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -239,7 +245,9 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
         rw[t] = *reinterpret_cast<const float4*>(A.wp + wp_index(widx[t], kc + wc, m0 + wcol, A.Kp, A.Mp));
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int buf) {
+    float* bw = b_base + buf * b_bs;
+    float* aw = a_base + buf * a_bs;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       if (e_meta[i] & 0x40000000) {
@@ -247,25 +255,38 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
           float4 v = rin[i];
           const float s = rsc[i];
           v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-          *reinterpret_cast<float4*>(b_lds + e_loff[i]) = v;
+          *reinterpret_cast<float4*>(bw + e_loff[i]) = v;
         } else {
-          b_lds[e_loff[i]] = rin[i] * rsc[i];
+          bw[e_loff[i]] = rin[i] * rsc[i];
         }
       }
     }
     if (wq < CK * Q4M) {
 #pragma unroll
       for (int t = 0; t < MAX_TAPS; ++t)
-        if (t < ntaps) *reinterpret_cast<float4*>(a_lds + (t * CK + wc) * LDA + wcol) = rw[t];
+        if (t < ntaps) *reinterpret_cast<float4*>(aw + (t * CK + wc) * LDA + wcol) = rw[t];
     }
   };
 
+  // Single buffer: barrier, commit chunk k, barrier, prefetch k+1, MFMA k  (two barriers per chunk).
+  // Double buffer (<= 4-tap launches, whose MFMA phase per chunk is short against the barriers): MFMA k out of buffer
+  // `cur`, then commit chunk k+1 into the other buffer while the matrix pipe drains, prefetch k+2, ONE barrier.
   if (kc_lo < kc_hi) prefetch(kc_lo);
-  for (int kc = kc_lo; kc < kc_hi; kc += CK) {
-    __syncthreads();  // MFMA reads of the previous chunk are done
-    commit();
+  int cur = 0;
+  if (dbuf && kc_lo < kc_hi) {
+    commit(0);
+    if (kc_lo + CK < kc_hi) prefetch(kc_lo + CK);
     __syncthreads();
-    if (kc + CK < kc_hi) prefetch(kc + CK);  // in flight during the MFMAs below
+  }
+  for (int kc = kc_lo; kc < kc_hi; kc += CK) {
+    if (!dbuf) {
+      __syncthreads();  // MFMA reads of the previous chunk are done
+      commit(0);
+      __syncthreads();
+      if (kc + CK < kc_hi) prefetch(kc + CK);  // in flight during the MFMAs below
+    }
+    a_lds = a_base + cur * a_bs;
+    b_lds = b_base + cur * b_bs;
     // runtime tap loop (the tap's LDS offset is a scalar kernarg load): keeps address VGPRs at 8 + MB instead
     // of letting the compiler hoist one address per (tap, step, block) out of the K loop
     // one expansion per phase with a compile-time phase index -> static accumulator set (a rolled loop over phases
@@ -299,6 +320,14 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
     if constexpr (NPH > 2) CAGC_RUN_PHASE(2)
     if constexpr (NPH > 3) CAGC_RUN_PHASE(3)
 #undef CAGC_RUN_PHASE
+    if (dbuf) {
+      if (kc + CK < kc_hi) {
+        commit(cur ^ 1);                                   // registers hold chunk kc + CK
+        if (kc + 2 * CK < kc_hi) prefetch(kc + 2 * CK);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   // ---- epilogue: lane holds channels m0 + i*16 + 4g + r (r = 0..3) of pixel n ------------------------------
@@ -632,7 +661,22 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   CAGC_REQUIRE(in_elems < (1ll << 31), "%s: input tensor too large for 32-bit offsets", what);
   const int mtiles = cdiv(a.Mp, MT);
   const int ks = a.ksplit;
-  const size_t smem = sizeof(float) * ((size_t)MAX_TAPS * CONV_CK * LDA + (size_t)CONV_CK * max_ps);
+  size_t smem = sizeof(float) * ((size_t)MAX_TAPS * CONV_CK * LDA + (size_t)CONV_CK * max_ps);
+  {
+    // double-buffered variant for launches with few taps (transposed-conv phases, stride-2 data gradient, 1x1): their MFMA
+    // phase per 8-channel chunk (32 MFMAs per wave and tap) is short against two barriers + the LDS commit; two buffers
+    // need one barrier per chunk and let the commit overlap the draining matrix pipe.  Only while two workgroups still
+    // fit a CU (<= 80 KB each).
+    static const bool db_off = getenv("CAGC_NO_DBUF") != nullptr;
+    int mtaps = 0;
+    for (int p = 0; p < nitems; ++p) mtaps = raw[p].ntaps > mtaps ? raw[p].ntaps : mtaps;
+    const size_t a_sz = (size_t)mtaps * CONV_CK * LDA, b_sz = (size_t)CONV_CK * max_ps;
+    a.dbuf = 0; a.a_sz = 0; a.b_sz = 0;
+    if (!db_off && nph == 1 && mtaps <= 4 && nchunks >= 4 && 2 * (a_sz + b_sz) * sizeof(float) <= 80 * 1024) {
+      a.dbuf = 1; a.a_sz = (int)a_sz; a.b_sz = (int)b_sz;
+      smem = 2 * (a_sz + b_sz) * sizeof(float);
+    }
+  }
   CAGC_REQUIRE(smem <= 160 * 1024, "%s: LDS tile %zu B too large", what, smem);
   const int nv = cdiv(max_units, 256);
   // large staging footprints (stride-2 / multi-plane inputs) do not fit 2 waves / SIMD next to 8 channel blocks of
