@@ -557,6 +557,9 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   const int MT = mb * 16;
   const int LDA = (MT % 32 == 0) ? MT + 16 : MT;
   int max_ps = 0, max_units = 0, blocks = 0;
+  bool any_strip = false, any_main = false;
+  for (int p = 0; p < nitems; ++p) { if (raw[p].strip) any_strip = true; else any_main = true; }
+  const bool mixed = any_strip && any_main;
   for (int p = 0; p < nitems; ++p) {
     ConvItem& I = a.items[p];
     const RawItem& R = raw[p];
@@ -591,7 +594,17 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
     I.Q4 = I.IWp / 4;
     // multi-image tiles of multi-plane inputs can exceed the per-thread staging budget: take fewer images per
     // tile (lanes of the dropped images are masked)
-    while (I.IPB > 1 && CONV_CK * a.NPin * I.IPB * I.IH * (a.vec ? I.Q4 : I.IWp) > (a.vec ? 12 : 48) * 256) I.IPB /= 2;
+    // In a MIXED launch (edge strips riding along with the main regions) the strips must fit the main regions' small
+    // staging footprint (4 float4 per thread): fewer images per tile first, then shorter tiles.
+    const int limit = (mixed && R.strip && a.vec) ? 4 * 256 : (a.vec ? 12 : 48) * 256;
+    while (CONV_CK * a.NPin * I.IPB * I.IH * (a.vec ? I.Q4 : I.IWp) > limit) {
+      if (I.IPB > 1) I.IPB /= 2;
+      else if (mixed && R.strip && I.TH > 1) {
+        I.TH /= 2;
+        I.tiles_y = cdiv(R.Hv, I.TH);
+        I.IH = (I.TH - 1) * a.isy + (max_dy - min_dy) + 1;
+      } else break;
+    }
     int ps = a.NPin * I.IPB * I.IH * I.IWp;
     ps = ps + ((16 - (ps % 32)) + 32) % 32;  // == 16 (mod 32)
     I.PS = ps;
@@ -649,10 +662,17 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
         ks_max = k > ks_max ? k : ks_max;
       }
     }
+    if (mixed) {   // strips: 4-way K split (their regions are zeroed by the caller), main regions: none
+      int kss = 4;
+      if (kss > nchunks / 2) kss = nchunks / 2;
+      if (kss < 1) kss = 1;
+      ks = 1; ks_max = kss;
+      for (int p = 0; p < nitems; ++p) a.items[p].ks = raw[p].strip ? kss : 1;
+    }
     a.ksplit = ks_max;
     for (int p = 0; p < nitems; ++p) {
       ConvItem& I = a.items[p];
-      if (!by_taps) I.ks = ks;
+      if (!by_taps && !mixed) I.ks = ks;
       blocks += cdiv(a.B, I.IPB) * I.tiles_x * I.tiles_y * I.ks;
       I.block_end = blocks;
     }
@@ -776,6 +796,14 @@ static bool balanced_phases_ok(int B, int Hv, int Wv, int Mp) {
 }
 static int phase_mb(int ntaps) { return ntaps >= 4 ? 2 : (ntaps == 2 ? 4 : 8); }
 
+// Large transposed-conv style launches: main regions and edge strips in ONE launch (strips first: their long K loops start
+// early and the main regions' workgroups fill in behind them).  As two launches the strips' ~50-300 workgroups ran alone on
+// the chip: 226 us of the 1667 us of the 512->256 @64^2 layer for 3 % of its FLOPs (profiles/r02_upfwd_pmc.md).
+static bool combined_strips_ok(bool small, bool fused) {
+  static const bool off = getenv("CAGC_SPLIT_STRIPS") != nullptr;
+  return !off && !small && !fused;
+}
+
 static void base_args(ConvArgs& a, float* out, const float* in, const float* wp, int B, int K, int M) {
   memset(&a, 0, sizeof(a));
   a.in = in; a.out = out; a.wp = wp;
@@ -876,6 +904,16 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   bool small = (int64_t)B * H * W <= 32768;   // only small layers are ever split over K
   ConvArgs a2 = a;
   int rc;
+  if (combined_strips_ok(small, fused_phase_ok(B, H, W, a.Mp))) {
+    const int64_t planes = (int64_t)B * Cout * 4;
+    hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (H + 1 + W + 1), 256)), dim3(256), 0, st, t, planes, H + 1,
+                       W + 1, a.Wopitch, H, W);
+    RawItem all[12];
+    int n = 0;
+    for (int q = 0; q < ns; ++q) { all[n] = items[4 + q]; all[n].strip = 1; ++n; }
+    for (int ph = 0; ph < 4; ++ph) all[n++] = items[ph];
+    return run_conv(a, all, n, st, what, false, false);
+  }
   if (small && balanced_phases_ok(B, H, W, a.Mp)) {
     for (int ph = 0; ph < 4; ++ph) {
       ConvArgs ap = a;
@@ -905,6 +943,8 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   for (int q = 4; q < 4 + ns; ++q) items[q].strip = 1;
   return run_conv(a2, items + 4, ns, st, what, false, true);
 }
+
+
 
 extern "C" int cagc_modconv_dgrad(float* gx, float* gs, const float* gz, const float* wp, const float* s, const float* x,
                                   int B, int Cin, int Cout, int H, int W, int ksize, cagc_stream_t stream) {
@@ -1005,6 +1045,16 @@ extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_b
   // low-resolution layers: too few pixel tiles to fill the chip and a 64-chunk K loop per workgroup -> split K
   // (atomics), which needs the whole gradient zeroed first
   bool small = (int64_t)B * Ho * Wo <= 32768;
+  if (combined_strips_ok(small, fused_phase_ok(B, Ho, Wo, a.Mp))) {
+    const int64_t planes = (int64_t)B * Cin;
+    hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (Hin + Win), 256)), dim3(256), 0, st, gx, planes, Hin, Win,
+                       out_pitch, Hin - 1, Win - 1);
+    RawItem all[12];
+    int n = 0;
+    for (int q = 0; q < ns; ++q) { all[n] = strip_items[q]; all[n].strip = 1; ++n; }
+    for (int ph = 0; ph < 4; ++ph) all[n++] = main_items[ph];
+    return run_conv(a, all, n, st, what, false, false);
+  }
   if (small && balanced_phases_ok(B, Ho, Wo, a.Mp)) {
     for (int ph = 0; ph < 4; ++ph) {
       ConvArgs ap = a;

@@ -3,8 +3,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "content-aware-gan-compression_amd")]
 from cagc import _lib
 from cagc.op import modconv as mc
-B = 16
-for (cin, cout, H) in ([(512, 512, 4), (512, 512, 8), (512, 512, 16), (512, 512, 32), (512, 256, 64), (256, 128, 128), (154, 154, 4), (154, 154, 8), (154, 154, 16), (154, 154, 32), (154, 77, 64), (77, 39, 128)] if len(sys.argv) < 2 else [(512, 512, 4), (512, 512, 8), (512, 512, 16), (154, 154, 8), (154, 154, 16)]):
+B = int(os.environ.get("BS", "16"))
+_only = os.environ.get("ONLY")      # e.g. ONLY=512,256,64 : a single layer (PMC runs)
+for (cin, cout, H) in ([tuple(int(v) for v in _only.split(","))] if _only else [(512, 512, 4), (512, 512, 8), (512, 512, 16), (512, 512, 32), (512, 256, 64), (256, 128, 128), (154, 154, 4), (154, 154, 8), (154, 154, 16), (154, 154, 32), (154, 77, 64), (77, 39, 128)] if len(sys.argv) < 2 else [(512, 512, 4), (512, 512, 8), (512, 512, 16), (154, 154, 8), (154, 154, 16)]):
     x = torch.randn(B, cin, H, H, device="cuda"); w = torch.randn(1, cout, cin, 3, 3, device="cuda")
     s = torch.rand(B, cin, device="cuda") + 0.5
     wp_fwd, wp_bwd, wsq = mc.pack_weights(w, False)
