@@ -799,9 +799,13 @@ static int phase_mb(int ntaps) { return ntaps >= 4 ? 2 : (ntaps == 2 ? 4 : 8); }
 // Large transposed-conv style launches: main regions and edge strips in ONE launch (strips first: their long K loops start
 // early and the main regions' workgroups fill in behind them).  As two launches the strips' ~50-300 workgroups ran alone on
 // the chip: 226 us of the 1667 us of the 512->256 @64^2 layer for 3 % of its FLOPs (profiles/r02_upfwd_pmc.md).
+// MEASURED (gpurun_out/run23.log vs run21.log, bs 16): 512->256 @64^2 1597 -> 1637 us, 256->128 @128^2 1616 -> 1643 us,
+// stride-2 data gradient 256->512 @129^2 1560 -> 1626 us; only the student's 154->77 @64^2 gains (270 -> 231 us).  The strips,
+// cut down to the main regions' staging footprint (fewer images per tile, 4-way K split), become more and less efficient
+// workgroups that take CU slots from the main regions.  Off unless CAGC_COMBINED_STRIPS=1.
 static bool combined_strips_ok(bool small, bool fused) {
-  static const bool off = getenv("CAGC_SPLIT_STRIPS") != nullptr;
-  return !off && !small && !fused;
+  static const bool on = getenv("CAGC_COMBINED_STRIPS") != nullptr;
+  return on && !small && !fused;
 }
 
 static void base_args(ConvArgs& a, float* out, const float* in, const float* wp, int B, int K, int M) {
