@@ -807,3 +807,29 @@ def test_from_rgb_streaming_kernels_match_implicit_gemm_path(cfg):
         keep = ~flip.any(1, keepdim=True)
         err = ((gg.double().cpu() - gr).abs() * keep).max().item() / gr.abs().max().item()
         assert err <= 2e-5, f"{cfg} from-RGB input gradient (frozen={frozen}): {err:.3e}"
+
+
+@pytest.mark.parametrize("up", [False, True])
+def test_styled_conv_noise_gradient(up):
+    """A caller that optimises the per-layer noise maps (a projector) gets d out / d noise from the fused op: per-sample
+    [B,1,H,W] and shared [1,1,H,W] maps, vs the composed CPU formulation."""
+    torch.manual_seed(15)
+    m = M.StyledConv(20, 12, 3, 32, upsample=up)
+    with torch.no_grad():
+        m.noise.weight.fill_(0.3)
+        m.activate.bias.copy_(0.1 * torch.randn(12))
+    B, H = 3, 16
+    oh = 2 * H if up else H
+    x, w = torch.randn(B, 20, H, H), torch.randn(B, 32)
+    go = torch.randn(B, 12, oh, oh)
+    for nb in (B, 1):
+        noise = torch.randn(nb, 1, oh, oh)
+        nr = noise.clone().requires_grad_(True)
+        (gref,) = torch.autograd.grad(m(x, w, noise=nr), nr, go)
+        mg = M.StyledConv(20, 12, 3, 32, upsample=up)
+        mg.load_state_dict(m.state_dict())
+        mg = mg.to(DEV)
+        ng = cu(noise).requires_grad_(True)
+        (gg,) = torch.autograd.grad(mg(cu(x), cu(w), noise=ng), ng, cu(go))
+        assert tuple(gg.shape) == tuple(noise.shape)
+        assert_close(gg, gref, 2e-5, f"noise gradient (up={up}, noise batch {nb})")
