@@ -21,6 +21,8 @@ _PROTOS = {
     "cagc_fused_bias_act_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _p],
     "cagc_fused_bias_act_bwd2": [_p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _p],
     "cagc_upfirdn2d": [_p, _p, _p, _i64] + [_i] * 14 + [_p],
+    "cagc_fused_bias_act_any": [_p, _p, _p, _p, _i, _i, _i64, _i64, _i64, ctypes.c_double, ctypes.c_double, _p],
+    "cagc_upfirdn2d_any": [_p, _p, _p, _i, _i64] + [_i] * 14 + [_p],
     "cagc_fir4x4_up2_acc": [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _p],
     "cagc_pixelnorm_fwd": [_p, _p, _i64, _i, _p],
     "cagc_pixelnorm_bwd": [_p, _p, _p, _i64, _i, _p],
@@ -118,6 +120,17 @@ def ptr(t):
     if t is None:
         return None
     assert t.dtype == torch.float32 and t.is_contiguous(), "libcagc wants contiguous fp32"
+    return t.data_ptr()
+
+
+DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.float64: 2}     # CAGC_F32 / CAGC_F16 / CAGC_F64
+
+
+def ptr_any(t):
+    """data_ptr of a contiguous fp32 / fp16 / fp64 tensor for the *_any entry points (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.dtype in DTYPE_CODE and t.is_contiguous(), "libcagc *_any wants contiguous fp32 / fp16 / fp64"
     return t.data_ptr()
 
 

@@ -72,6 +72,54 @@ class _LReLU(Function):
         return gx, (gb if ctx.has_bias else None), None, None
 
 
+# ---------------------------------------------------------------------------------------------------
+# fp16 / fp64: the generic any-dtype kernels (cagc_fused_bias_act_any) with the same first- and second-order autograd
+# ---------------------------------------------------------------------------------------------------
+def _any(mode, a, bias, ref, negative_slope, scale):
+    a = a.contiguous()
+    out = torch.empty_like(a)
+    outer, C, inner = _view3(a)
+    with _lib.on_device(a):
+        _lib.call("cagc_fused_bias_act_any", _lib.ptr_any(out), _lib.ptr_any(a), _lib.ptr_any(bias), _lib.ptr_any(ref),
+                  _lib.DTYPE_CODE[a.dtype], mode, outer, C, inner, float(negative_slope), float(scale))
+    return out
+
+
+class _LReLUBackwardAny(Function):
+    @staticmethod
+    def forward(ctx, grad_output, out, has_bias, negative_slope, scale):
+        ctx.save_for_backward(out)
+        ctx.negative_slope, ctx.scale = negative_slope, scale
+        gx = _any(1, grad_output, None, out, negative_slope, scale)
+        dims = [0] + list(range(2, gx.ndim))
+        return gx, (gx.sum(dims) if has_bias else gx.new_empty(0))      # grad_bias as the reference: a separate sum (:33-39)
+
+    @staticmethod
+    def backward(ctx, gg_input, gg_bias):
+        (out,) = ctx.saved_tensors
+        ggb = gg_bias.contiguous() if (gg_bias is not None and gg_bias.numel() > 0) else None
+        return _any(2, gg_input, ggb, out, ctx.negative_slope, ctx.scale), None, None, None, None
+
+
+class _LReLUAny(Function):
+    @staticmethod
+    def forward(ctx, input, bias, negative_slope, scale):
+        b = bias.contiguous().to(input.dtype) if bias is not None else None
+        if b is not None and b.numel() != input.shape[1]:
+            raise RuntimeError(f"fused_leaky_relu: bias has {b.numel()} elements, input has {input.shape[1]} channels")
+        out = _any(0, input, b, None, negative_slope, scale)
+        ctx.save_for_backward(out)
+        ctx.has_bias = bias is not None
+        ctx.negative_slope, ctx.scale = negative_slope, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (out,) = ctx.saved_tensors
+        gx, gb = _LReLUBackwardAny.apply(grad_output, out, ctx.has_bias, ctx.negative_slope, ctx.scale)
+        return gx, (gb if ctx.has_bias else None), None, None
+
+
 def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5):
     if input.device.type == "cpu":
         if bias is not None:
@@ -79,8 +127,10 @@ def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5):
         # the reference's CPU branch pins the slope to 0.2 whatever is passed (op/fused_act.py:110,116);
         # every caller passes 0.2, so honouring the argument is equivalent and matches its GPU branch
         return F.leaky_relu(input, negative_slope=negative_slope) * scale
+    if input.dtype in (torch.float16, torch.float64):      # the reference dispatches fp32 / fp64 / fp16 (kernel.cu:79)
+        return _LReLUAny.apply(input, bias, negative_slope, scale)
     if input.dtype != torch.float32:
-        raise RuntimeError("fused_leaky_relu (HIP): fp32 only")
+        raise RuntimeError(f"fused_leaky_relu (HIP): unsupported dtype {input.dtype}")
     return _LReLU.apply(input, bias, negative_slope, scale)
 
 

@@ -20,6 +20,12 @@ def _launch(x4, kernel, up, down, pad, out_hw):
     kh, kw = kernel.shape
     oh, ow = out_hw
     out = torch.empty(n, c, oh, ow, dtype=x4.dtype, device=x4.device)
+    if x4.dtype != torch.float32:     # fp16 / fp64: generic any-dtype kernel, FIR taps in the tensors' element type
+        k = kernel.to(x4.dtype).contiguous()
+        with _lib.on_device(x4):
+            _lib.call("cagc_upfirdn2d_any", _lib.ptr_any(out), _lib.ptr_any(x4), _lib.ptr_any(k), _lib.DTYPE_CODE[x4.dtype], n * c,
+                      h, w, oh, ow, kh, kw, up[0], up[1], down[0], down[1], pad[0], pad[1], pad[2], pad[3])
+        return out
     with _lib.on_device(x4):
         _lib.call("cagc_upfirdn2d", _lib.ptr(out), _lib.ptr(x4), _lib.ptr(kernel), n * c, h, w, oh, ow, kh, kw, up[0],
                   up[1], down[0], down[1], pad[0], pad[1], pad[2], pad[3])
@@ -85,6 +91,6 @@ def _upfirdn2d_cpu(x, kernel, up, down, pad):
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     if input.device.type == "cpu":
         return _upfirdn2d_cpu(input, kernel, up, down, pad)
-    if input.dtype != torch.float32:
-        raise RuntimeError("upfirdn2d (HIP): fp32 only")
+    if input.dtype not in (torch.float32, torch.float16, torch.float64):
+        raise RuntimeError(f"upfirdn2d (HIP): unsupported dtype {input.dtype}")
     return _UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

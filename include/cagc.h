@@ -12,7 +12,8 @@
  *
  * Conventions
  *   - plain C, no torch / ATen types: raw device pointers, sizes, a hipStream_t passed as void*.
- *   - all tensors are fp32, contiguous, NCHW unless stated ("planes" = N*C flattened).
+ *   - all tensors are fp32, contiguous, NCHW unless stated ("planes" = N*C flattened); the two reference operators also
+ *     exist in an any-dtype form (fp32 / fp16 / fp64: cagc_fused_bias_act_any, cagc_upfirdn2d_any).
  *   - OWNERSHIP: the caller allocates every output and workspace (PyTorch caching allocator) and
  *     passes data_ptr(); the library never allocates, frees or retains a pointer.
  *   - ERRORS: every function returns CAGC_OK (0) or a negative code; the message is available from
@@ -39,6 +40,11 @@ extern "C" {
 
 typedef void* cagc_stream_t; /* hipStream_t */
 
+/* element types of the *_any entry points (the two operators the reference dispatches over all floating types) */
+#define CAGC_F32 0
+#define CAGC_F16 1
+#define CAGC_F64 2
+
 int cagc_abi_version(void);
 const char* cagc_last_error(void);
 /* "gfx950" — the only architecture the library is built for. */
@@ -64,6 +70,13 @@ int cagc_fused_bias_act_bwd2(float* ggout, const float* ggx, const float* ggbias
                              int64_t outer, int64_t C, int64_t inner, float alpha, float scale,
                              cagc_stream_t stream);
 
+/* Any-dtype form (fp32 / fp16 / fp64: AT_DISPATCH_FLOATING_TYPES_AND_HALF, op/fused_bias_act_kernel.cu:79).  mode = the
+ * reference's `grad` argument: 0 forward (a = x), 1 backward (a = gout, ref = out; no fused grad_bias — the caller sums, as
+ * op/fused_act.py:33-39 does), 2 double backward (a = ggx, bias = ggbias, ref = out).  Generic kernels: API completeness,
+ * fp32 callers use the tuned entry points above. */
+int cagc_fused_bias_act_any(void* out, const void* a, const void* bias, const void* ref, int dtype, int mode,
+                            int64_t outer, int64_t C, int64_t inner, double alpha, double scale, cagc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * upfirdn2d                         replaces upfirdn2d.upfirdn2d (op/upfirdn2d.cpp:12-23, kernels
  *                                   op/upfirdn2d_kernel.cu:49-207).  x [planes, in_h, in_w] ->
@@ -77,6 +90,11 @@ int cagc_fused_bias_act_bwd2(float* ggout, const float* ggx, const float* ggbias
 int cagc_upfirdn2d(float* out, const float* x, const float* kernel, int64_t planes, int in_h, int in_w,
                    int out_h, int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
                    int pad_x0, int pad_x1, int pad_y0, int pad_y1, cagc_stream_t stream);
+
+/* Any-dtype form (op/upfirdn2d_kernel.cu:311); `kernel` has the tensors' element type, as in the reference. */
+int cagc_upfirdn2d_any(void* out, const void* x, const void* kernel, int dtype, int64_t planes, int in_h, int in_w,
+                       int out_h, int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                       int pad_x1, int pad_y0, int pad_y1, cagc_stream_t stream);
 
 /* out [planes,2h,2w] = upfirdn2d(x [planes,h,w], kernel 4x4, up = 2, pad = (2,1)) + acc (acc may alias out): the adjoint
  * of the discriminator skip path's decimating blur (op/upfirdn2d.py:29-43) accumulated onto the gradient the ResBlock's

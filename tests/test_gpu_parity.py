@@ -833,3 +833,38 @@ def test_styled_conv_noise_gradient(up):
         (gg,) = torch.autograd.grad(mg(cu(x), cu(w), noise=ng), ng, cu(go))
         assert tuple(gg.shape) == tuple(noise.shape)
         assert_close(gg, gref, 2e-5, f"noise gradient (up={up}, noise batch {nb})")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float16, 2e-3)])
+def test_ops_fp64_fp16_dispatch(dtype, tol):
+    """The two reference operators dispatch over fp32 / fp64 / fp16 (op/fused_bias_act_kernel.cu:79, op/upfirdn2d_kernel.cu:311):
+    forward, backward and double backward of both on the any-dtype kernels vs the CPU formulation in float64."""
+    torch.manual_seed(16)
+    x = torch.randn(3, 7, 10, 9, dtype=torch.float64)
+    b = torch.randn(7, dtype=torch.float64)
+    go, ggi = torch.randn_like(x), torch.randn_like(x)
+
+    def act(x, b, go, ggi):
+        x, b, go = x.requires_grad_(True), b.requires_grad_(True), go.requires_grad_(True)
+        y = fused_leaky_relu(x, b)
+        gx, gb = torch.autograd.grad(y, [x, b], go, create_graph=True)
+        (ggo,) = torch.autograd.grad(gx, go, ggi)
+        return [y, gx, gb, ggo]
+
+    ref = act(x.clone(), b.clone(), go.clone(), ggi.clone())
+    got = act(cu(x).to(dtype), cu(b).to(dtype), cu(go).to(dtype), cu(ggi).to(dtype))
+    for nm, a, r in zip(("y", "gx", "gbias", "ggo"), got, ref):
+        assert a.dtype == dtype
+        assert_close(a, r, tol if nm != "gbias" else 10 * tol, f"fused_leaky_relu {dtype} {nm}")
+    k = M.make_kernel([1, 3, 3, 1]).double()
+    for up, down, pad in ((1, 1, (2, 2)), (2, 1, (2, 1)), (1, 2, (1, 1))):
+        xr = x.clone().requires_grad_(True)
+        yr = upfirdn2d(xr, k, up=up, down=down, pad=pad)
+        g2 = torch.randn_like(yr)
+        (gr,) = torch.autograd.grad(yr, xr, g2)
+        xg = cu(x).to(dtype).requires_grad_(True)
+        yg = upfirdn2d(xg, cu(k).to(dtype), up=up, down=down, pad=pad)
+        (gg,) = torch.autograd.grad(yg, xg, cu(g2).to(dtype))
+        assert yg.dtype == dtype
+        assert_close(yg, yr, tol, f"upfirdn2d {dtype} up{up} down{down}")
+        assert_close(gg, gr, tol, f"upfirdn2d {dtype} up{up} down{down} grad")
