@@ -573,11 +573,15 @@ struct Wg2Plan { int mb, nb; };
 static Wg2Plan wg2_plan(int Cout, int Cin) {
   // least padded work first; among equals prefer a plan that runs 2 waves / SIMD (<= 110 accumulator registers), then
   // the larger tile
-  static const Wg2Plan cands[] = {{1, 1}, {2, 2}, {3, 1}, {3, 3}, {5, 1}, {5, 2}, {2, 5}, {3, 5}, {5, 3}};
+  // {4,2} / {4,4}: the discriminator's channel counts (multiples of 64: 128 .. 512) — a 64-channel M tile halves the
+  // re-reads of the gradient operand against {2,2}; {4,2} still fits two waves / SIMD (80 accumulator registers)
+  static const Wg2Plan cands[] = {{1, 1}, {2, 2}, {3, 1}, {3, 3}, {4, 2}, {4, 4}, {5, 1}, {5, 2}, {2, 5}, {3, 5}, {5, 3}};
   auto occ2 = [](const Wg2Plan& c) { return ((9 * c.nb + 3) / 4) * c.mb * 4 <= 110; };
   Wg2Plan best = cands[0];
   long best_cost = -1;
+  static const bool no4 = getenv("CAGC_WGRAD_NO4") != nullptr;   // A/B switch for the 64-channel plans
   for (const Wg2Plan& c : cands) {
+    if (no4 && c.mb == 4) continue;
     const long cost = (long)cdiv(Cout, 16 * c.mb) * c.mb * cdiv(Cin, 16 * c.nb) * c.nb;
     bool better = best_cost < 0 || cost < best_cost;
     if (!better && cost == best_cost) {
@@ -791,6 +795,8 @@ extern "C" int cagc_modconv_wgrad_demod(float* gweight, float* workspace, const 
     const int key = pl.mb * 10 + pl.nb;
     if (key == 11) rc2 = launch_wgrad2<1, 1>(b, st2, what);
     else if (key == 22) rc2 = launch_wgrad2<2, 2>(b, st2, what);
+    else if (key == 42) rc2 = launch_wgrad2<4, 2>(b, st2, what);
+    else if (key == 44) rc2 = launch_wgrad2<4, 4>(b, st2, what);
     else if (key == 51) rc2 = launch_wgrad2<5, 1>(b, st2, what);
     else if (key == 31) rc2 = launch_wgrad2<3, 1>(b, st2, what);
     else if (key == 33) rc2 = launch_wgrad2<3, 3>(b, st2, what);
