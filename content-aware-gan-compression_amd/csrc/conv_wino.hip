@@ -32,6 +32,7 @@
 namespace cagc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WCK = 8;      // input channels per chunk
 constexpr int WTH = 8, WTW = 32;
@@ -54,8 +55,24 @@ struct WinoArgs {
   int tiles_x, tiles_y, nblocks, mtiles;
   int pmb;                 // channel blocks per PACKED tile of `up` (wino_mb of the layer); a SUB launch runs fewer per workgroup
   int epi, noise_bstride_on;
+  int wg_map;              // workgroup -> tile mapping, see k_wino
+  int wg_order;            // 1: round-1 phase order (slot-0 wave transforms first), for A/B measurements
   float alpha, act_scale;
 };
+
+// Phase timing of one workgroup (debug builds only: -DCAGC_WINO_TRACE, scripts/trace_wino.py): per wave, shader cycles spent
+// in [0] commit+prefetch, [1] transform before the multiply, [2] multiply, [3] transform after, [4] barrier.
+#ifndef CAGC_WINO_NOPRIO
+#define WINO_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define WINO_PRIO(p)
+#endif
+#ifdef CAGC_WINO_TRACE
+__device__ long long g_wino_trace[8][8];
+#define WINO_TR(k) do { const long long t_ = clock64(); tr[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define WINO_TR(k)
+#endif
 
 template <int MB, bool GATED, bool SUB = false>
 __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
@@ -77,14 +94,26 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   const int q = wave & 3, nh = wave >> 2;
   const int lm = lane & 15, g = lane >> 4;
 
+  // Workgroup -> (pixel tile, channel tile).  Workgroups are dealt round-robin to the 8 XCDs (w % 8), each with its own
+  // 4 MB L2.  map 1 (default): the channel-tile-major order is cut into 8 contiguous runs, one per XCD, so an XCD streams ONE
+  // transformed-weight slice (<= 2 MB) at a time and keeps it L2-resident — the latency-critical A-operand ring then hits L2,
+  // and the misses move to the input tiles, which are prefetched three chunks ahead.  map 0 (round 1): the 8 channel tiles
+  // of a pixel tile share an XCD (input L2-resident, weights re-streamed).
   int pix_id, mtile;
   {
     const int w = blockIdx.x, nx = A.nblocks, mt = A.mtiles;
-    const int full = (nx / 8) * 8;
-    const int s = w / 8, xcd = w - s * 8;
-    const int p = (s / mt) * 8 + xcd;
-    if (w < full * mt && p < full) { pix_id = p; mtile = s % mt; }
-    else { const int r = w - full * mt; pix_id = full + r / mt; mtile = r % mt; }
+    if (A.wg_map == 1) {
+      const int total = nx * mt, per = total / 8;
+      const int s = w >> 3, xcd = w & 7;
+      const int idx = (w < per * 8) ? xcd * per + s : w;
+      mtile = idx / nx; pix_id = idx - mtile * nx;
+    } else {
+      const int full = (nx / 8) * 8;
+      const int s = w / 8, xcd = w - s * 8;
+      const int p = (s / mt) * 8 + xcd;
+      if (w < full * mt && p < full) { pix_id = p; mtile = s % mt; }
+      else { const int r = w - full * mt; pix_id = full + r / mt; mtile = r % mt; }
+    }
   }
   const int tx_i = pix_id % A.tiles_x;
   const int ty_i = (pix_id / A.tiles_x) % A.tiles_y;
@@ -95,53 +124,62 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   const int nch = A.Kp / CK;
 
   // ---- staging descriptors: raw tile = CK x 10 rows x 10 float4 = 800 units -> 2 per thread ------------------
-  int e_goff[2], e_loff[2], e_meta[2];
+  // On this chip VALU instructions do NOT overlap the fp32 MFMA (scripts/micro/mfma_coissue.hip: every VALU instruction next
+  // to the MFMA stream costs its 4 issue cycles plus a switch bubble), so the loop is written to execute as few of them as
+  // possible.  Global loads are raw buffer loads: (uniform descriptor of the chunk) + (per-lane byte offset, constant over the
+  // chunks) — no address arithmetic in the vector ALU — and the descriptor's range check supplies every zero for free:
+  // units outside the image get an out-of-range offset, channels past Cin lie beyond num_records.
+  constexpr unsigned OOR = 0x80000000u;
+  unsigned e_boff[2], e_soff[2];   // byte offsets: input / gate tile unit, in_scale
+  int e_loff[2];
+  bool e_act[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int e = tid + 512 * i;
-    int goff = 0, loff = 0, meta = 0;
+    e_boff[i] = OOR; e_soff[i] = OOR; e_loff[i] = 0; e_act[i] = false;
     if (e < CK * W_IH * 10) {
       const int r = e / 10, q = e - r * 10;
       const int c = r / W_IH, iy = r - c * W_IH;
       const int gy = y0 - 1 + iy, gx = x0 - 4 + 4 * q;
       const bool ok = (gy >= 0) && (gy < A.H) && (gx >= 0) && (gx + 4 <= A.W);
-      goff = (b * A.Cin + c) * HW + gy * A.W + gx;
-      loff = c * RPS + iy * W_IWP + 4 * q;
-      meta = (ok ? 1 : 0) | (c << 1) | 0x40000000;
+      e_act[i] = true;
+      if (ok) e_boff[i] = 4u * (unsigned)(c * HW + gy * A.W + gx);
+      e_soff[i] = 4u * (unsigned)c;
+      e_loff[i] = c * RPS + iy * W_IWP + 4 * q;
     }
-    e_goff[i] = goff; e_loff[i] = loff; e_meta[i] = meta;
   }
   float4 rin[2];
   float4 rgt[GATED ? 2 : 1];
   float rsc[2];
-  auto prefetch = [&](int j) {   // global -> registers, chunk j (no-op past the end)
-    const int kc = j * CK;
+  const bool has_scale = A.in_scale != nullptr;
+  const int nfull = A.Cin / CK;
+  auto prefetch = [&](int j) {   // global -> registers, chunk j (padding chunks and chunks past the end: zeros)
+    const int nreal = j < nfull ? CK : (j == nfull ? A.Cin - nfull * CK : 0);   // uniform: real channels of this chunk (selects, not a clamp: stays on the scalar ALU)
+    const int64_t cbase = ((int64_t)b * A.Cin + (int64_t)j * CK) * HW;
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.in + cbase), 0, nreal * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_scale ? A.in_scale + (int64_t)b * A.Cin + j * CK : A.in), 0, has_scale ? nreal * 4 : 0, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int meta = e_meta[i];
-      const int c = (meta >> 1) & 127;
-      const bool ok = (meta & 1) && (kc + c < A.Cin);
-      rin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      rsc[i] = 1.f;
-      if (GATED) rgt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        rin[i] = *reinterpret_cast<const float4*>(A.in + (int64_t)e_goff[i] + (int64_t)kc * HW);
-        if (GATED) rgt[i] = *reinterpret_cast<const float4*>(A.gate + (int64_t)e_goff[i] + (int64_t)kc * HW);
-        if (A.in_scale) rsc[i] = A.in_scale[b * A.Cin + kc + c];
+      rin[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ri, e_boff[i], 0, 0));
+      if (GATED) {
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.gate + cbase), 0, nreal * HW * 4, 0x00020000);
+        rgt[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rg, e_boff[i], 0, 0));
       }
+      rsc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, e_soff[i], 0, 0));
     }
   };
   auto commit = [&](float* rbuf) {   // registers -> raw tile in LDS
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      if (e_meta[i] & 0x40000000) {
+      if (e_act[i]) {
         float4 v = rin[i];
-        const float s = rsc[i];
         if (GATED) {   // fused LeakyReLU backward: the conv input is gout * lrelu'(out)
           const float4 gt = rgt[i];
           const float hi = A.gate_scale, lo = A.gate_alpha * A.gate_scale;
           v.x *= gt.x > 0.f ? hi : lo; v.y *= gt.y > 0.f ? hi : lo; v.z *= gt.z > 0.f ? hi : lo; v.w *= gt.w > 0.f ? hi : lo;
         }
+        const float s = has_scale ? rsc[i] : 1.f;
         v.x *= s; v.y *= s; v.z *= s; v.w *= s;
         *reinterpret_cast<float4*>(rbuf + e_loff[i]) = v;
       }
@@ -174,6 +212,46 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
     }
   };
 
+  // The same transform for the main loop, in three slices that ride between this wave's MFMA steps: [0] the 16 LDS reads,
+  // [1] all the arithmetic as 16 packed-fp32 adds (v_pk_add_f32 with op_sel / neg modifiers: two results per instruction —
+  // the VALU work is bunched so that the MFMA stream is interrupted once, not sixteen times), [2]-[3] the 16 LDS writes.
+  f32x2 td[4][2], to[4][2];
+  const int tr_src = wave * RPS + (2 * (lane >> 4)) * W_IWP + 3 + 2 * (lane & 15);
+  const int tr_dst = wave * W_VS + (lane >> 5) * 32 + (lane & 15) * 2 + ((lane >> 4) & 1);
+  auto tslice = [&](const int sl, const float* rbuf, float* vbuf) {
+    if (sl == 0) {
+      const float* p = rbuf + tr_src;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) td[r][h] = (f32x2){p[r * W_IWP + 2 * h], p[r * W_IWP + 2 * h + 1]};
+    } else if (sl == 1) {
+      f32x2 tt[4][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {   // rows: B^T d, two columns at a time
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(tt[0][h]) : "v"(td[0][h]), "v"(td[2][h]));
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(tt[1][h]) : "v"(td[1][h]), "v"(td[2][h]));
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(tt[2][h]) : "v"(td[2][h]), "v"(td[1][h]));
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(tt[3][h]) : "v"(td[1][h]), "v"(td[3][h]));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // columns: (t0 - t2, t1 + t2) and (t2 - t1, t1 - t3) from the pairs (t0,t1), (t2,t3)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(to[r][0]) : "v"(tt[r][0]), "v"(tt[r][1]));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(to[r][1]) : "v"(tt[r][0]), "v"(tt[r][1]));
+      }
+    } else if (sl <= 3) {
+      float* vp = vbuf + tr_dst;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * (sl - 2) + rr;
+        vp[((4 * r + 0) * CK) * W_VS] = to[r][0].x;
+        vp[((4 * r + 1) * CK) * W_VS] = to[r][0].y;
+        vp[((4 * r + 2) * CK) * W_VS] = to[r][1].x;
+        vp[((4 * r + 3) * CK) * W_VS] = to[r][1].y;
+      }
+    }
+  };
+
   // ---- A operand (transformed weights): straight from global / L2 into MFMA register layout, no LDS ------------------
   // packed as [mtile][xi][Kp/4][lane = (k % 4, m % 16)][4 channel blocks]: one 16-byte load per lane feeds 2*MB MFMAs.
   // Stream order of this wave: chunk j, grid column c4 = 0..3, K-step s = 0..1  ->  slot t = 2*c4 + s;  the ring holds
@@ -185,19 +263,20 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   const int gb0 = mtile * MB;
   const int ptile = SUB ? gb0 / A.pmb : mtile;
   const int slot0 = SUB ? gb0 - ptile * A.pmb : 0;
-  const float4* ua = reinterpret_cast<const float4*>(A.up) + ((int64_t)ptile * 16 + q * 4) * KQ * 64 + lane;
-  auto load_a = [&](int64_t off4) {   // -> float4 whose first MB components are this workgroup's channel blocks
-    if constexpr (!SUB) return ua[off4];
+  // raw buffer loads: descriptor = this wave's row of positions, scalar offset = (position, K-step), lane offset constant
+  const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(A.up) + (((int64_t)ptile * 16 + q * 4) * KQ * 64) * 4, 0, 0x7fffffff, 0x00020000);
+  const unsigned ua_lane = (unsigned)lane * 16u + (SUB ? (unsigned)slot0 * 4u : 0u);
+  auto load_a = [&](int off4) {   // -> float4 whose first MB components are this workgroup's channel blocks
+    if constexpr (!SUB) return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, ua_lane, off4 * 16, 0));
     else if constexpr (MB == 2) {
-      const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(ua + off4) + slot0);
+      const float2 v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ru, ua_lane, off4 * 16, 0));
       return make_float4(v.x, v.y, 0.f, 0.f);
     } else {
-      return make_float4(reinterpret_cast<const float*>(ua + off4)[slot0], 0.f, 0.f, 0.f);
+      return make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ru, ua_lane, off4 * 16, 0)), 0.f, 0.f, 0.f);
     }
   };
-  float4 ring[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) ring[t] = load_a(((int64_t)(t >> 1) * KQ + (t & 1)) * 64);
+  float4 ring[8];   // filled at the end of the prologue (see there)
 
   f32x4 acc[4][MB][2];
 #pragma unroll
@@ -208,8 +287,17 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
       acc[c4][i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-  auto gemms = [&](const float* vbuf, int j) {   // this wave's 4 of the 16 GEMMs on chunk j
+  // One chunk = 8 K-steps of 2*MB MFMAs.  Everything else the chunk needs rides in the shadow of THIS wave's MFMAs: a wave
+  // streaming MFMAs starves the VALU/LDS instructions of the other wave on its SIMD (measured: ~1 foreign instruction per
+  // MFMA, scripts/micro/mfma_mix.hip, scripts/trace_wino.py), but its own non-MFMA instructions issue freely while its MFMA
+  // executes.  So steps 0-4 carry the slices of the NEXT chunk's input transform, step 7 the raw-tile commit + prefetch, and
+  // every step the refill of its A-ring slot; both waves of a SIMD run the same stream and the matrix pipe never waits
+  // for a transform phase.
+  auto chunk = [&](const int j, const int cur) {
     const int jn = (j + 1 < nch) ? j + 1 : j;   // last chunk: re-read valid data instead of branching (keeps vmcnt exact)
+    const float* vbuf = v_lds + cur * VSZ;
+    const float* rnext = raw + (cur ^ 1) * RSZ;     // chunk j+1, committed during iteration j-1
+    float* vnext = v_lds + (cur ^ 1) * VSZ;
     const float2* vb = reinterpret_cast<const float2*>(vbuf + (q * 4 * CK + g) * W_VS + nh * 32 + lm * 2);
     float2 bv = vb[0];
 #pragma unroll
@@ -218,7 +306,6 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
       float2 bvn = make_float2(0.f, 0.f);
       if (t < 7) bvn = vb[((((t + 1) >> 1) * CK + 4 * ((t + 1) & 1)) * W_VS) / 2];   // B operand one step ahead
       const float4 a4 = ring[t];
-      ring[t] = load_a(((int64_t)c4 * KQ + 2 * jn + s) * 64);
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
@@ -226,7 +313,19 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
         acc[c4][i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv.y, acc[c4][i][1], 0, 0, 0);
       }
       bv = bvn;
-      __builtin_amdgcn_sched_barrier(0);   // keep the ring load a chunk ahead of its use (the scheduler sinks it otherwise)
+      if (t == 0) tslice(0, rnext, vnext);
+      else if (t == 2) tslice(1, rnext, vnext);
+      else if (t == 3) tslice(2, rnext, vnext);
+      else if (t == 4) tslice(3, rnext, vnext);
+      else if (t == 7) {   // raw[cur] (chunk j) was transformed during iteration j-1: refill it with chunk j+2, fetch chunk j+3
+        commit(raw + cur * RSZ);
+        prefetch(j + 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // refill the slot only after its MFMAs have issued: the new value lands in the SAME registers, so the ring needs no
+      // copy (and no vmcnt(0)) on the loop's back edge; it is consumed a whole chunk later
+      ring[t] = load_a((c4 * KQ + 2 * jn + s) * 64);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -237,18 +336,35 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   __syncthreads();
   transform(raw, v_lds);
   commit(raw + RSZ);
+  // The VMEM stream of the prologue ends like a loop iteration (ring slots 0-6, raw prefetch, ring slot 7): the compiler's
+  // vmcnt bookkeeping merges the loop-entry and back-edge states, and with the same order on both it waits for exactly the
+  // loads it needs instead of vmcnt(0).
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 7; ++t) ring[t] = load_a(((t >> 1) * KQ + (t & 1)) * 64);
+  __builtin_amdgcn_sched_barrier(0);
   prefetch(2);
+  __builtin_amdgcn_sched_barrier(0);
+  ring[7] = load_a((3 * KQ + 1) * 64);
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
-  for (int j = 0; j < nch; ++j) {
-    const int cur = j & 1;
-    // raw[cur] (chunk j) was consumed during iteration j-1: refill it with chunk j+2, fetch chunk j+3
-    commit(raw + cur * RSZ);
-    prefetch(j + 3);
-    if (nh == 0 && j + 1 < nch) transform(raw + (cur ^ 1) * RSZ, v_lds + (cur ^ 1) * VSZ);
-    gemms(v_lds + cur * VSZ, j);
-    if (nh != 0 && j + 1 < nch) transform(raw + (cur ^ 1) * RSZ, v_lds + (cur ^ 1) * VSZ);
+#ifdef CAGC_WINO_TRACE
+  long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
+  for (int j = 0; j < nch; j += 2) {   // unrolled by two (Kp is a multiple of 16): LDS buffer addresses are immediates
+    chunk(j, 0);
+    WINO_TR(2);
     __syncthreads();
+    WINO_TR(4);
+    chunk(j + 1, 1);
+    WINO_TR(2);
+    __syncthreads();
+    WINO_TR(4);
   }
+#ifdef CAGC_WINO_TRACE
+  if (blockIdx.x == gridDim.x / 2 && lane == 0)
+    for (int k = 0; k < 8; ++k) g_wino_trace[wave][k] = tr[k];
+#endif
 
   // ---- output transform Y = A^T M A.  Row q of the position grid lives in wave (q, nh): the column direction is done
   // in registers,  z[0] = M[q][0] + M[q][1] + M[q][2],  z[1] = M[q][1] - M[q][2] - M[q][3],  the row direction
@@ -345,6 +461,8 @@ static int launch_wino(WinoArgs& a, hipStream_t st, const char* what) {
     attr[dev] = true;
   }
   a.mtiles = cdiv(a.Cout, MT);
+  { static const int wm = getenv("CAGC_WINO_MAP") ? atoi(getenv("CAGC_WINO_MAP")) : 1; a.wg_map = wm; }
+  { static const int wo = getenv("CAGC_WINO_ORDER") ? atoi(getenv("CAGC_WINO_ORDER")) : 0; a.wg_order = wo; }
   CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
   hipLaunchKernelGGL((k_wino<MB, GATED, SUB>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(512), smem, st, a);
   return check_launch(what);
@@ -354,19 +472,25 @@ static int launch_wino(WinoArgs& a, hipStream_t st, const char* what) {
 
 using namespace cagc;
 
+#ifdef CAGC_WINO_TRACE
+extern "C" int cagc_wino_trace_dump(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cagc::g_wino_trace), sizeof(long long) * 64);
+}
+#endif
+
 extern "C" int cagc_wino_eligible(int H, int W) { return (H % WTH == 0 && W % WTW == 0) ? 1 : 0; }
 
 extern "C" int64_t cagc_wino_packed_elems(int K, int M) {
   if (K <= 0 || M <= 0) return 0;
   const int mb = wino_mb(M);
-  return (int64_t)cdiv(M, mb * 16) * 16 * round_up(K, WCK) * 64;
+  return (int64_t)cdiv(M, mb * 16) * 16 * wino_kp(K) * 64;
 }
 
 extern "C" int cagc_wino_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad,
                               cagc_stream_t stream) {
   CAGC_REQUIRE(up && weight && Cout > 0 && Cin > 0, "cagc_wino_prep: bad argument");
   const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
-  const int Kp = round_up(K, WCK), mb = wino_mb(M), mtiles = cdiv(M, mb * 16);
+  const int Kp = wino_kp(K), mb = wino_mb(M), mtiles = cdiv(M, mb * 16);
   hipLaunchKernelGGL(k_wino_pack, dim3(cdiv((int64_t)mtiles * Kp * 64, 256)), dim3(256), 0, as_stream(stream), up, weight,
                      Cout, Cin, Kp, mtiles, mb, scale, dgrad);
   return check_launch("cagc_wino_prep");
@@ -390,7 +514,7 @@ extern "C" int cagc_wino_conv3x3(float* out, const float* x, const float* up, co
   WinoArgs a;
   memset(&a, 0, sizeof(a));
   a.in = x; a.out = out; a.up = up; a.in_scale = s; a.out_scale = out_scale; a.noise = noise; a.noise_w = noise_w; a.bias = bias;
-  a.B = B; a.Cin = Cin; a.Kp = round_up(Cin, WCK); a.Cout = Cout; a.Mp = round_up(Cout, 16); a.H = H; a.W = W;
+  a.B = B; a.Cin = Cin; a.Kp = wino_kp(Cin); a.Cout = Cout; a.Mp = round_up(Cout, 16); a.H = H; a.W = W;
   a.tiles_x = W / WTW; a.tiles_y = H / WTH; a.nblocks = B * a.tiles_x * a.tiles_y;
   a.epi = epi; a.noise_bstride_on = (noise_batch == B) ? 1 : 0; a.alpha = alpha; a.act_scale = act_scale;
   hipStream_t st = as_stream(stream);
@@ -423,7 +547,7 @@ extern "C" int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const f
   memset(&a, 0, sizeof(a));
   CAGC_REQUIRE(!residual || ((uintptr_t)residual % 8) == 0, "%s: unaligned residual", what);
   a.in = gout; a.gate = act_out; a.gate_alpha = alpha; a.gate_scale = act_scale; a.out = gx; a.up = up; a.residual = residual;
-  a.B = B; a.Cin = Cout; a.Kp = round_up(Cout, WCK); a.Cout = Cin; a.Mp = round_up(Cin, 16); a.H = H; a.W = W;
+  a.B = B; a.Cin = Cout; a.Kp = wino_kp(Cout); a.Cout = Cin; a.Mp = round_up(Cin, 16); a.H = H; a.W = W;
   a.tiles_x = W / WTW; a.tiles_y = H / WTH; a.nblocks = B * a.tiles_x * a.tiles_y;
   a.epi = CAGC_EPI_LINEAR; a.alpha = alpha; a.act_scale = 1.f;
   hipStream_t st = as_stream(stream);

@@ -66,6 +66,9 @@ __device__ __forceinline__ void wino_pack_elem(float* __restrict__ up, const flo
   }
 }
 
+// K (reduction channels) of the Winograd packing: two K-chunks of 8 per main-loop iteration of k_wino, zero-padded
+inline int wino_kp(int K) { return round_up(K, 16); }
+
 // channel blocks (of 16) per Winograd workgroup tile for M output channels: 4, or fewer when that wastes less of the last tile
 inline int wino_mb(int M) {
   const int nblk = cdiv(M, 16);

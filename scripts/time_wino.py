@@ -5,7 +5,7 @@ from cagc import _lib
 if len(sys.argv) > 1:
     _lib.LIB_PATH = os.path.join(ROOT, "content-aware-gan-compression_amd", "cagc", sys.argv[1])
 from cagc.op import modconv as mc
-B, C, H = 16, 512, 64
+B, C, H = int(os.environ.get("B", 16)), int(os.environ.get("C", 512)), int(os.environ.get("H", 64))
 x = torch.randn(B, C, H, H, device="cuda"); w = torch.randn(C, C, 3, 3, device="cuda")
 up = mc.pack_wino(w, 0.01, False); out = torch.empty_like(x)
 def run():
@@ -15,4 +15,4 @@ torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(10): run()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
 fl = 2.0 * B * C * C * 9 * H * H
-print(sys.argv[1:] or "default", f"{dt*1e3:.3f} ms  direct-equiv {fl/dt/1e12:.1f} TF  mfma {fl*4/9/dt/1e12:.1f} TF")
+print(sys.argv[1:] or "default", (B, C, H), f"{dt*1e3:.3f} ms  direct-equiv {fl/dt/1e12:.1f} TF  mfma {fl*4/9/dt/1e12:.1f} TF")
