@@ -132,21 +132,18 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   constexpr unsigned OOR = 0x80000000u;
   unsigned e_boff[2], e_soff[2];   // byte offsets: input / gate tile unit, in_scale
   int e_loff[2];
-  bool e_act[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int e = tid + 512 * i;
-    e_boff[i] = OOR; e_soff[i] = OOR; e_loff[i] = 0; e_act[i] = false;
-    if (e < CK * W_IH * 10) {
-      const int r = e / 10, q = e - r * 10;
-      const int c = r / W_IH, iy = r - c * W_IH;
-      const int gy = y0 - 1 + iy, gx = x0 - 4 + 4 * q;
-      const bool ok = (gy >= 0) && (gy < A.H) && (gx >= 0) && (gx + 4 <= A.W);
-      e_act[i] = true;
-      if (ok) e_boff[i] = 4u * (unsigned)(c * HW + gy * A.W + gx);
-      e_soff[i] = 4u * (unsigned)c;
-      e_loff[i] = c * RPS + iy * W_IWP + 4 * q;
-    }
+    int e = tid + 512 * i;
+    if (e >= CK * W_IH * 10) e -= 512;     // the 224 spare lanes of the second round repeat a unit of the first (same value to
+                                           // the same LDS address): no divergent branch around the commit
+    const int r = e / 10, q = e - r * 10;
+    const int c = r / W_IH, iy = r - c * W_IH;
+    const int gy = y0 - 1 + iy, gx = x0 - 4 + 4 * q;
+    const bool ok = (gy >= 0) && (gy < A.H) && (gx >= 0) && (gx + 4 <= A.W);
+    e_boff[i] = ok ? 4u * (unsigned)(c * HW + gy * A.W + gx) : OOR;
+    e_soff[i] = 4u * (unsigned)c;
+    e_loff[i] = c * RPS + iy * W_IWP + 4 * q;
   }
   float4 rin[2];
   float4 rgt[GATED ? 2 : 1];
@@ -171,8 +168,7 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   };
   auto commit = [&](float* rbuf) {   // registers -> raw tile in LDS
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      if (e_act[i]) {
+    for (int i = 0; i < 2; ++i) {
         float4 v = rin[i];
         if (GATED) {   // fused LeakyReLU backward: the conv input is gout * lrelu'(out)
           const float4 gt = rgt[i];
@@ -304,7 +300,11 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
     for (int t = 0; t < 8; ++t) {
       const int c4 = t >> 1, s = t & 1;
       float2 bvn = make_float2(0.f, 0.f);
+#if defined(CAGC_WINO_ABL) && (CAGC_WINO_ABL & 4)
+      bvn = bv;
+#else
       if (t < 7) bvn = vb[((((t + 1) >> 1) * CK + 4 * ((t + 1) & 1)) * W_VS) / 2];   // B operand one step ahead
+#endif
       const float4 a4 = ring[t];
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
@@ -313,18 +313,28 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
         acc[c4][i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv.y, acc[c4][i][1], 0, 0, 0);
       }
       bv = bvn;
+      // CAGC_WINO_ABL (debug builds, wrong results): bit 0 drops the transform slices, 1 the A-ring refills, 2 the B reads,
+      // 3 the raw-tile commit + prefetch — what each costs next to the MFMA stream
+#if !(defined(CAGC_WINO_ABL) && (CAGC_WINO_ABL & 1))
       if (t == 0) tslice(0, rnext, vnext);
       else if (t == 2) tslice(1, rnext, vnext);
       else if (t == 3) tslice(2, rnext, vnext);
       else if (t == 4) tslice(3, rnext, vnext);
-      else if (t == 7) {   // raw[cur] (chunk j) was transformed during iteration j-1: refill it with chunk j+2, fetch chunk j+3
+#endif
+#if defined(CAGC_WINO_ABL) && (CAGC_WINO_ABL & 8)
+      if (false) {
+#else
+      if (t == 7) {
+#endif   // raw[cur] (chunk j) was transformed during iteration j-1: refill it with chunk j+2, fetch chunk j+3
         commit(raw + cur * RSZ);
         prefetch(j + 3);
       }
       __builtin_amdgcn_sched_barrier(0);
       // refill the slot only after its MFMAs have issued: the new value lands in the SAME registers, so the ring needs no
       // copy (and no vmcnt(0)) on the loop's back edge; it is consumed a whole chunk later
+#if !(defined(CAGC_WINO_ABL) && (CAGC_WINO_ABL & 2))
       ring[t] = load_a((c4 * KQ + 2 * jn + s) * 64);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
