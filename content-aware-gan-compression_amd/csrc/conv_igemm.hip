@@ -165,14 +165,25 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
 
   // ---- per-thread staging descriptors (computed once) -----------------------------------------------------
   // element e = tid + 256*i  ->  (row r, column unit q);  row r -> (c, plane, img, iy)
-  int e_goff[NV], e_loff[NV], e_meta[NV];  // meta: bit0 valid, bits 1..7 c, bits 8.. img
+  // VEC path (every hot launch): on gfx950 VALU instructions do not overlap the fp32 MFMA (scripts/micro/mfma_coissue.hip),
+  // so the staging is written to execute as few of them as possible.  Loads are raw buffer loads: (uniform descriptor of
+  // the chunk) + (per-lane byte offset, constant over the chunks); a unit that must read as zero (padding, image >= B,
+  // channel >= Cin) gets an out-of-range offset and the descriptor's range check supplies the zero — no divergent
+  // branches, no 64-bit address arithmetic.  Spare lanes of the last round repeat a unit (same value, same LDS address).
+  constexpr unsigned OOR = 0x80000000u;
+  int e_goff[NV], e_loff[NV], e_meta[NV];  // scalar path: meta bit0 valid, bits 1..7 c, bits 8.. img.  VEC path: e_goff = input byte
+                                           // offset (or OOR), e_meta = in_scale byte offset, e_loff = LDS float offset
+  int e_kmax[VEC ? NV : 1];                // VEC path: unit is real while kc < e_kmax (= Cin - c)
+  int n_rounds = NV;
   {
     const int upr = VEC ? I.Q4 : IWp;      // units per row
     const int total = I.rows * upr;
+    if (VEC) n_rounds = (total + 255) >> 8;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int e = tid + 256 * i;
+      int e = tid + 256 * i;
       int goff = 0, loff = 0, meta = 0;
+      if (VEC) e = e % total;
       if (e < total) {
         const int r = e / upr, q = e - r * upr;
         int t2 = r;
@@ -185,9 +196,15 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
         bool ok = (gy >= 0) && (gy < A.Hin) && (b < A.B);
         if (VEC) ok = ok && (gx >= 0) && (gx + 4 <= A.Wpitch);
         else ok = ok && (gx >= 0) && (gx < A.Win);
-        goff = ((b * A.Cin + c) * A.NPin + pl) * HWp + gy * A.Wpitch + gx;
         loff = c * PS + ((pl * IPB + img) * IH + iy) * IWp + (VEC ? 4 * q : q);
-        meta = (ok ? 1 : 0) | (c << 1) | (img << 8) | 0x40000000;  // bit30: element exists (must be written)
+        if constexpr (VEC) {
+          goff = ok ? 4 * (((img * A.Cin + c) * A.NPin + pl) * HWp + gy * A.Wpitch + gx) : (int)OOR;
+          meta = 4 * (img * A.Cin + c);
+          e_kmax[i] = A.Cin - c;
+        } else {
+          goff = ((b * A.Cin + c) * A.NPin + pl) * HWp + gy * A.Wpitch + gx;
+          meta = (ok ? 1 : 0) | (c << 1) | (img << 8) | 0x40000000;  // bit30: element exists (must be written)
+        }
       }
       e_goff[i] = goff; e_loff[i] = loff; e_meta[i] = meta;
     }
@@ -222,19 +239,44 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
   const int wc = wq / Q4M, wcol = (wq - wc * Q4M) * 4;
   const bool w_thread = (wq < CK * Q4M) && (m0 + wcol < A.Mp);
 
+  // weights: float4 (tap t, k = kc + wc, m0 + wcol .. +3) of [t][Kp/4][Mp/16][k % 4][m % 16]; kc is a multiple of 8, so the
+  // address splits into a per-lane constant and a uniform (tap, chunk) term -> raw buffer load, scalar offset
+  const unsigned w_lane = w_thread ? 4u * (unsigned)((((wc >> 2) * (A.Mp >> 4) + ((m0 + wcol) >> 4)) << 6) + ((wc & 3) << 4) + ((m0 + wcol) & 15)) : OOR;
+  const int w_kmax = A.Kp - wc;          // the slab row is real while kc < w_kmax
+  const int w_tap_stride = (A.Kp >> 2) * (A.Mp >> 4) * 256;     // bytes between taps
+  const int w_chunk_stride = 2 * (A.Mp >> 4) * 256;             // bytes between K chunks of 8
+  const bool has_scale = A.in_scale != nullptr;
+
   auto prefetch = [&](int kc) {
+    if constexpr (VEC) {
+      const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(A.in) + ((int64_t)b0 * A.Cin + kc) * chan_stride, 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(has_scale ? A.in_scale + (int64_t)b0 * A.Cin + kc : A.in), 0, has_scale ? 0x7fffffff : 0, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (i < n_rounds) {                                                    // uniform
+          const unsigned off = (kc < e_kmax[i]) ? (unsigned)e_goff[i] : OOR;
+          rin[i] = __builtin_bit_cast(in_t, __builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, 0));
+          rsc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)e_meta[i], 0, 0));
+        }
+      const __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.wp), 0, 0x7fffffff, 0x00020000);
+      const unsigned woff = (kc < w_kmax) ? w_lane : OOR;
+      const int wbase = (kc >> 3) * w_chunk_stride;
+#pragma unroll
+      for (int t = 0; t < MAX_TAPS; ++t)
+        if (t < ntaps) rw[t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rwd, woff, widx[t] * w_tap_stride + wbase, 0));
+    } else {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int meta = e_meta[i];
       const int c = (meta >> 1) & 127;
       const bool ok = (meta & 1) && (kc + c < A.Cin);
-      if (VEC) rin[i] = in_t{};
-      else rin[i] = in_t{};
+      rin[i] = in_t{};
       rsc[i] = 1.f;
       if (ok) {
         const float* src = A.in + (int64_t)e_goff[i] + (int64_t)kc * chan_stride;
-        if (VEC) rin[i] = *reinterpret_cast<const in_t*>(src);
-        else rin[i] = *reinterpret_cast<const in_t*>(src);
+        rin[i] = *reinterpret_cast<const in_t*>(src);
         if (A.in_scale) rsc[i] = A.in_scale[(b0 + ((meta >> 8) & 0x3fffff)) * A.Cin + kc + c];
       }
     }
@@ -244,21 +286,22 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
       if (t < ntaps && w_thread && kc + wc < A.Kp)
         rw[t] = *reinterpret_cast<const float4*>(A.wp + wp_index(widx[t], kc + wc, m0 + wcol, A.Kp, A.Mp));
     }
+    }
   };
   auto commit = [&](int buf) {
     float* bw = b_base + buf * b_bs;
     float* aw = a_base + buf * a_bs;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      if (e_meta[i] & 0x40000000) {
-        if constexpr (VEC) {
+      if constexpr (VEC) {
+        if (i < n_rounds) {                                                    // uniform
           float4 v = rin[i];
-          const float s = rsc[i];
+          const float s = has_scale ? rsc[i] : 1.f;
           v.x *= s; v.y *= s; v.z *= s; v.w *= s;
           *reinterpret_cast<float4*>(bw + e_loff[i]) = v;
-        } else {
-          bw[e_loff[i]] = rin[i] * rsc[i];
         }
+      } else {
+        if (e_meta[i] & 0x40000000) bw[e_loff[i]] = rin[i] * rsc[i];
       }
     }
     if (wq < CK * Q4M) {
