@@ -173,7 +173,6 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
   constexpr unsigned OOR = 0x80000000u;
   int e_goff[NV], e_loff[NV], e_meta[NV];  // scalar path: meta bit0 valid, bits 1..7 c, bits 8.. img.  VEC path: e_goff = input byte
                                            // offset (or OOR), e_meta = in_scale byte offset, e_loff = LDS float offset
-  int e_kmax[VEC ? NV : 1];                // VEC path: unit is real while kc < e_kmax (= Cin - c)
   int n_rounds = NV;
   {
     const int upr = VEC ? I.Q4 : IWp;      // units per row
@@ -200,7 +199,6 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
         if constexpr (VEC) {
           goff = ok ? 4 * (((img * A.Cin + c) * A.NPin + pl) * HWp + gy * A.Wpitch + gx) : (int)OOR;
           meta = 4 * (img * A.Cin + c);
-          e_kmax[i] = A.Cin - c;
         } else {
           goff = ((b * A.Cin + c) * A.NPin + pl) * HWp + gy * A.Wpitch + gx;
           meta = (ok ? 1 : 0) | (c << 1) | (img << 8) | 0x40000000;  // bit30: element exists (must be written)
@@ -249,16 +247,20 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
 
   auto prefetch = [&](int kc) {
     if constexpr (VEC) {
+      // Channels past Cin in the last chunk are NOT masked: they read whatever follows (the next image's channels — finite
+      // activations) and meet the zero rows k >= Cin of the packed weights; the descriptor ends with the tensor, so past the
+      // last image they read as zero.
+      const int64_t left = ((int64_t)(A.B - b0) * A.Cin - kc) * chan_stride * 4;            // bytes to the end of the tensor
       const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(A.in) + ((int64_t)b0 * A.Cin + kc) * chan_stride, 0, 0x7fffffff, 0x00020000);
+          const_cast<float*>(A.in) + ((int64_t)b0 * A.Cin + kc) * chan_stride, 0, left > 0x7fffffff ? 0x7fffffff : (left > 0 ? (int)left : 0), 0x00020000);
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(has_scale ? A.in_scale + (int64_t)b0 * A.Cin + kc : A.in), 0, has_scale ? 0x7fffffff : 0, 0x00020000);
+          const_cast<float*>(has_scale ? A.in_scale + (int64_t)b0 * A.Cin + kc : A.in), 0,
+          has_scale ? ((A.B - b0) * A.Cin - kc > 0 ? ((A.B - b0) * A.Cin - kc) * 4 : 0) : 0, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NV; ++i)
         if (i < n_rounds) {                                                    // uniform
-          const unsigned off = (kc < e_kmax[i]) ? (unsigned)e_goff[i] : OOR;
-          rin[i] = __builtin_bit_cast(in_t, __builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, 0));
-          rsc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)e_meta[i], 0, 0));
+          rin[i] = __builtin_bit_cast(in_t, __builtin_amdgcn_raw_buffer_load_b128(ri, (unsigned)e_goff[i], 0, 0));
+          if (has_scale) rsc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)e_meta[i], 0, 0));
         }
       const __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.wp), 0, 0x7fffffff, 0x00020000);
       const unsigned woff = (kc < w_kmax) ? w_lane : OOR;
@@ -296,8 +298,10 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
       if constexpr (VEC) {
         if (i < n_rounds) {                                                    // uniform
           float4 v = rin[i];
-          const float s = has_scale ? rsc[i] : 1.f;
-          v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+          if (has_scale) {                                                     // uniform
+            const float s = rsc[i];
+            v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+          }
           *reinterpret_cast<float4*>(bw + e_loff[i]) = v;
         }
       } else {
