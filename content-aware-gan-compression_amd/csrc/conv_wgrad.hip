@@ -206,6 +206,72 @@ struct Wg2Args {
   signed char pair_tap[4][12], pair_nb[4][12], pair_newa[4][12];
 };
 
+// MFMA phase of one pixel tile [TH][TW] (TW % 4 == 0) for the v2 kernels: K-steps of 4 pixels, taken in groups of 4.
+// On gfx950 VALU instructions do not overlap the fp32 MFMA (scripts/micro/mfma_coissue.hip), so the loop keeps ONE running
+// LDS address per A channel block and per (tap, block) pair, bumps them once per group (the steps of a group are immediate
+// offsets) and issues a group's LDS reads ahead of its MFMAs: ~0.15 VALU instructions per MFMA instead of 1.2 (one address
+// add per ds_read and an lgkmcnt(0) wait in front of every 5 MFMAs in the first version).
+template <int MB, int PPW, int U>
+__device__ __forceinline__ void wgrad2_group(f32x4 (&acc)[PPW][MB], const float* a_lds, const float* b_lds, const int (&oa)[MB],
+                                             const int (&ob)[PPW], const int (&p_aoff)[PPW], const bool (&p_ok)[PPW],
+                                             const bool (&p_newa)[PPW]) {
+  float bv[PPW][U], av[U][MB];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q)
+    if (p_ok[q]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) bv[q][u] = b_lds[ob[q] + 4 * u];
+    }
+#pragma unroll
+  for (int q = 0; q < PPW; ++q)
+    if (p_ok[q]) {
+      if (q == 0 || p_newa[q]) {   // (a wave's first pair always loads its A fragments)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          const int ao = oa[i] + p_aoff[q];
+#pragma unroll
+          for (int u = 0; u < U; ++u) av[u][i] = a_lds[ao + 4 * u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[q][u], acc[q][i], 0, 0, 0);
+    }
+}
+
+// (LDS offsets, not pointers: arrays of pointers lose the LDS address space and turn the reads into flat loads)
+template <int MB, int PPW>
+__device__ __forceinline__ void wgrad2_mfma_tile(f32x4 (&acc)[PPW][MB], const float* a_lds, const float* b_lds, int ACS, int BCS, int TH,
+                                                 int QA, int BWp, const int (&p_aoff)[PPW], const int (&p_boff)[PPW],
+                                                 const bool (&p_ok)[PPW], const bool (&p_newa)[PPW], int lm, int g) {
+  int oa[MB], ob[PPW];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) oa[i] = (i * 16 + lm) * ACS + g;        // A rows are contiguous (row stride TW = 4 * QA)
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) ob[q] = lm * BCS + p_boff[q] + g;
+  const int bskip = BWp - 4 * QA;                                      // B row stride BWp > TW: the halo columns
+  for (int row = 0; row < TH; ++row) {
+    int s4 = 0;
+    for (; s4 + 4 <= QA; s4 += 4) {
+      wgrad2_group<MB, PPW, 4>(acc, a_lds, b_lds, oa, ob, p_aoff, p_ok, p_newa);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) oa[i] += 16;
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) ob[q] += 16;
+    }
+    for (; s4 < QA; ++s4) {
+      wgrad2_group<MB, PPW, 1>(acc, a_lds, b_lds, oa, ob, p_aoff, p_ok, p_newa);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) oa[i] += 4;
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) ob[q] += 4;
+    }
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) ob[q] += bskip;
+  }
+}
+
 // AFF: affine staging map (a thread owns one float4 position of the per-channel tile and walks over channels: no index
 // arithmetic per load, row / column masks once per tile).  PMC on the 39->39 @256^2 layer showed 4.8 VALU instructions
 // per MFMA with the generic row-indexed map (profiles/r02_wgrad_pmc.md) — the staging loops' float->int index math.
@@ -353,25 +419,7 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)
     }   // !AFF
     __syncthreads();
     // ---- MFMA over the tile's pixels -------------------------------------------------------------------
-    for (int row = 0; row < TH; ++row) {
-      for (int s4 = 0; s4 < QA; ++s4) {
-        const int px = 4 * s4 + g;
-        const int ao = row * TW + px, bo = row * A.BWp + px;
-        float av[MB];
-#pragma unroll
-        for (int q = 0; q < PPW; ++q) {
-          if (p_ok[q]) {
-            if (p_newa[q]) {
-#pragma unroll
-              for (int i = 0; i < MB; ++i) av[i] = a_lds[(i * 16 + lm) * A.ACS + p_aoff[q] + ao];
-            }
-            const float bv = b_lds[lm * A.BCS + p_boff[q] + bo];
-#pragma unroll
-            for (int i = 0; i < MB; ++i) acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[q][i], 0, 0, 0);
-          }
-        }
-      }
-    }
+    wgrad2_mfma_tile<MB, PPW>(acc, a_lds, b_lds, A.ACS, A.BCS, TH, QA, A.BWp, p_aoff, p_boff, p_ok, p_newa, lm, g);
   }
   // ---- each wave owns its (tap, nb) pairs: write the partial slab ws[sp][t][Mp][Np] ----------------------
   float* slab = A.ws + (int64_t)sp * A.ntaps * A.Mp * A.Np;
@@ -518,25 +566,7 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 + (4 * MB + 4 * 
     store_tile();
     __syncthreads();
     if (tile + A.nsplit < A.ntiles) load_tile(tile + A.nsplit);   // in flight during the MFMA phase below
-    for (int row = 0; row < TH; ++row) {
-      for (int s4 = 0; s4 < QA; ++s4) {
-        const int px = 4 * s4 + g;
-        const int ao = row * TW + px, bo = row * A.BWp + px;
-        float av[MB];
-#pragma unroll
-        for (int q = 0; q < PPW; ++q) {
-          if (p_ok[q]) {
-            if (p_newa[q]) {
-#pragma unroll
-              for (int i = 0; i < MB; ++i) av[i] = a_lds[(i * 16 + lm) * A.ACS + p_aoff[q] + ao];
-            }
-            const float bv = b_lds[lm * A.BCS + p_boff[q] + bo];
-#pragma unroll
-            for (int i = 0; i < MB; ++i) acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[q][i], 0, 0, 0);
-          }
-        }
-      }
-    }
+    wgrad2_mfma_tile<MB, PPW>(acc, a_lds, b_lds, A.ACS, A.BCS, TH, QA, A.BWp, p_aoff, p_boff, p_ok, p_newa, lm, g);
   }
   float* slab = A.ws + (int64_t)sp * A.ntaps * A.Mp * A.Np;
 #pragma unroll
