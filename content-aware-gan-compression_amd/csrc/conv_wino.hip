@@ -76,6 +76,9 @@ __device__ long long g_wino_trace[8][8];
 
 template <int MB, bool GATED, bool SUB = false>
 __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
+#ifdef CAGC_WINO_TRACE
+  const long long t_entry = clock64();
+#endif
   constexpr int CK = WCK;
   constexpr int MT = MB * 16;
   constexpr int RPS = W_IH * W_IWP + 16;            // raw channel-plane stride
@@ -289,21 +292,37 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   // executes.  So steps 0-4 carry the slices of the NEXT chunk's input transform, step 7 the raw-tile commit + prefetch, and
   // every step the refill of its A-ring slot; both waves of a SIMD run the same stream and the matrix pipe never waits
   // for a transform phase.
+  // The chunk's barrier sits IN FRONT of its last K-step, not behind it: by then every wave has issued its last read of this
+  // chunk's V slab (the B operand is read one step ahead) and its writes of the next one (transform slices end at step 4,
+  // the raw-tile commit is step 5).  Behind the barrier the wave immediately issues the next chunk's first B read and the
+  // LDS reads of its transform slice 0, so their latency hides behind the last step's MFMAs instead of stalling both waves of
+  // the SIMD right after a barrier at the chunk boundary.
+#ifdef CAGC_WINO_TRACE
+  long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
+  float2 bv_carry;      // B operand of step 0 of the next chunk
   auto chunk = [&](const int j, const int cur) {
     const int jn = (j + 1 < nch) ? j + 1 : j;   // last chunk: re-read valid data instead of branching (keeps vmcnt exact)
     const float* vbuf = v_lds + cur * VSZ;
-    const float* rnext = raw + (cur ^ 1) * RSZ;     // chunk j+1, committed during iteration j-1
-    float* vnext = v_lds + (cur ^ 1) * VSZ;
+    float* vnext = v_lds + (cur ^ 1) * VSZ;         // chunk j+1: its transform slices 1-3 run in this chunk (slice 0 = reads, issued in chunk j-1)
+    const float* rafter = raw + cur * RSZ;          // chunk j+2 once step 5 has committed it
     const float2* vb = reinterpret_cast<const float2*>(vbuf + (q * 4 * CK + g) * W_VS + nh * 32 + lm * 2);
-    float2 bv = vb[0];
+    const float2* vbn = reinterpret_cast<const float2*>(vnext + (q * 4 * CK + g) * W_VS + nh * 32 + lm * 2);
+    float2 bv = bv_carry;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int c4 = t >> 1, s = t & 1;
+      if (t == 7) {
+        WINO_TR(2);
+        __syncthreads();
+        WINO_TR(4);
+      }
       float2 bvn = make_float2(0.f, 0.f);
 #if defined(CAGC_WINO_ABL) && (CAGC_WINO_ABL & 4)
       bvn = bv;
 #else
       if (t < 7) bvn = vb[((((t + 1) >> 1) * CK + 4 * ((t + 1) & 1)) * W_VS) / 2];   // B operand one step ahead
+      else bvn = vbn[0];
 #endif
       const float4 a4 = ring[t];
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
@@ -316,15 +335,15 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
       // CAGC_WINO_ABL (debug builds, wrong results): bit 0 drops the transform slices, 1 the A-ring refills, 2 the B reads,
       // 3 the raw-tile commit + prefetch — what each costs next to the MFMA stream
 #if !(defined(CAGC_WINO_ABL) && (CAGC_WINO_ABL & 1))
-      if (t == 0) tslice(0, rnext, vnext);
-      else if (t == 2) tslice(1, rnext, vnext);
-      else if (t == 3) tslice(2, rnext, vnext);
-      else if (t == 4) tslice(3, rnext, vnext);
+      if (t == 2) tslice(1, nullptr, vnext);
+      else if (t == 3) tslice(2, nullptr, vnext);
+      else if (t == 4) tslice(3, nullptr, vnext);
+      else if (t == 7) tslice(0, rafter, nullptr);    // reads for the transform of chunk j+2 (done during chunk j+1)
 #endif
 #if defined(CAGC_WINO_ABL) && (CAGC_WINO_ABL & 8)
       if (false) {
 #else
-      if (t == 7) {
+      if (t == 5) {
 #endif   // raw[cur] (chunk j) was transformed during iteration j-1: refill it with chunk j+2, fetch chunk j+3
         commit(raw + cur * RSZ);
         prefetch(j + 3);
@@ -337,6 +356,7 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
+    bv_carry = bv;
   };
 
   // ---- pipeline: raw tiles two chunks ahead in LDS (+ one more in registers), V slabs one chunk ahead ----------------
@@ -346,35 +366,30 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   __syncthreads();
   transform(raw, v_lds);
   commit(raw + RSZ);
-  // The VMEM stream of the prologue ends like a loop iteration (ring slots 0-6, raw prefetch, ring slot 7): the compiler's
+  // The VMEM stream of the prologue ends like a loop iteration (ring slots 0-4, raw prefetch, ring slots 5-7): the compiler's
   // vmcnt bookkeeping merges the loop-entry and back-edge states, and with the same order on both it waits for exactly the
   // loads it needs instead of vmcnt(0).
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int t = 0; t < 7; ++t) ring[t] = load_a(((t >> 1) * KQ + (t & 1)) * 64);
+  for (int t = 0; t < 5; ++t) ring[t] = load_a(((t >> 1) * KQ + (t & 1)) * 64);
   __builtin_amdgcn_sched_barrier(0);
   prefetch(2);
   __builtin_amdgcn_sched_barrier(0);
-  ring[7] = load_a((3 * KQ + 1) * 64);
+#pragma unroll
+  for (int t = 5; t < 8; ++t) ring[t] = load_a(((t >> 1) * KQ + (t & 1)) * 64);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  bv_carry = reinterpret_cast<const float2*>(v_lds + (q * 4 * CK + g) * W_VS + nh * 32 + lm * 2)[0];
+  tslice(0, raw + RSZ, nullptr);      // chunk 1, transformed during chunk 0
 #ifdef CAGC_WINO_TRACE
-  long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+  tlast = clock64();
+  tr[5] = tlast - t_entry;   // prologue
 #endif
   for (int j = 0; j < nch; j += 2) {   // unrolled by two (Kp is a multiple of 16): LDS buffer addresses are immediates
     chunk(j, 0);
-    WINO_TR(2);
-    __syncthreads();
-    WINO_TR(4);
     chunk(j + 1, 1);
-    WINO_TR(2);
-    __syncthreads();
-    WINO_TR(4);
   }
-#ifdef CAGC_WINO_TRACE
-  if (blockIdx.x == gridDim.x / 2 && lane == 0)
-    for (int k = 0; k < 8; ++k) g_wino_trace[wave][k] = tr[k];
-#endif
+  __syncthreads();   // the exchange buffer below aliases the V / raw buffers other waves may still be pre-reading
 
   // ---- output transform Y = A^T M A.  Row q of the position grid lives in wave (q, nh): the column direction is done
   // in registers,  z[0] = M[q][0] + M[q][1] + M[q][2],  z[1] = M[q][1] - M[q][2] - M[q][3],  the row direction
@@ -436,6 +451,11 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
       }
     }
   }
+#ifdef CAGC_WINO_TRACE
+  tr[6] = clock64() - tlast;   // epilogue
+  if (blockIdx.x == gridDim.x / 2 && lane == 0)
+    for (int k = 0; k < 8; ++k) g_wino_trace[wave][k] = tr[k];
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_wino_pack(float* __restrict__ up, const float* __restrict__ w, int Cout, int Cin,

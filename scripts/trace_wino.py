@@ -22,4 +22,5 @@ names = ["commit+prefetch", "transform(before)", "multiply", "transform(after)",
 print(f"B {B} C {C} H {H}: {nch} chunks; shader cycles per chunk, per wave (wave w and w+4 share a SIMD)")
 for wv in range(8):
     row = [buf[wv * 8 + k] / nch for k in range(5)]
-    print(f"wave {wv}: " + "  ".join(f"{n} {v:7.0f}" for n, v in zip(names, row)) + f"   total {sum(row):7.0f}")
+    print(f"wave {wv}: " + "  ".join(f"{n} {v:7.0f}" for n, v in zip(names, row)) + f"   total {sum(row):7.0f}"
+          + f"   | whole kernel: prologue {buf[wv * 8 + 5]} main {sum(buf[wv * 8 + k] for k in range(5))} epilogue {buf[wv * 8 + 6]} cycles")
