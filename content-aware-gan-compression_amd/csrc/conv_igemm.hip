@@ -812,7 +812,8 @@ static RawItem fused_phase_item(RawTap* taps9, int H, int W, bool planar_out) {
 static bool fused_phase_ok(int B, int H, int W, int Mp) {
   // Measured on MI355X (bench_11 vs bench_10): the fused-phase variant needs 4 accumulator sets -> 1 wave / SIMD and
   // 64-channel tiles, and loses to the per-phase launches at 2 waves / SIMD (up_fwd 7.6 vs 7.0 ms, s2 dgrad 7.5 vs
-  // 6.7 ms per step).  Kept selectable for tuning, off by default.
+  // 6.7 ms per step).  Re-measured in round 2 with the low-VALU staging: 1743 us vs 1453 us per-phase on 512->256 @64^2, and
+  // 1682 us with 32-channel tiles at 2 waves / SIMD.  Kept selectable for tuning, off by default.
   static const bool enabled = getenv("CAGC_FUSED_PHASES") != nullptr;
   if (!enabled) return false;
   if (W % 4 != 0 || W < 16) return false;
