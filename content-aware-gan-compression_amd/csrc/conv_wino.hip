@@ -35,9 +35,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WCK = 8;      // input channels per chunk
-constexpr int WTH = 8, WTW = 32;
-constexpr int W_IH = WTH + 2, W_IWP = 40;   // raw tile rows / padded row (LDS col 0 <-> global col x0 - 4)
-constexpr int W_VS = 80;    // V row stride: 64 tiles, == 16 (mod 32)
+constexpr int WTW = 32, W_IWP = 40;          // tile width; padded raw row (LDS col 0 <-> global col x0 - 4)
+// NH = halves of 4 pixel rows per workgroup: NH = 2 -> 8 waves, tile 8 x 32 pixels (64 Winograd tiles); NH = 1 -> 4 waves, tile
+// 4 x 32 (32 tiles) and TWO workgroups per CU, each wave alone on its SIMD slot: one workgroup's prologue / epilogue (4-15 %
+// of its life) runs under the other's MFMA stream.  Same per-wave instruction stream in both.
+constexpr int wino_th(int NH) { return 4 * NH; }                 // tile height
+constexpr int wino_ih(int NH) { return 4 * NH + 2; }             // raw tile rows
+constexpr int wino_vs(int NH) { return NH == 2 ? 80 : 48; }      // V row stride: 32 * NH tiles, == 16 (mod 32)
 
 struct WinoArgs {
   const float* in;
@@ -74,13 +78,14 @@ __device__ long long g_wino_trace[8][8];
 #define WINO_TR(k)
 #endif
 
-template <int MB, bool GATED, bool SUB = false>
-__global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
+template <int MB, bool GATED, bool SUB = false, int NH = 2>
+__global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
 #ifdef CAGC_WINO_TRACE
   const long long t_entry = clock64();
 #endif
   constexpr int CK = WCK;
   constexpr int MT = MB * 16;
+  constexpr int WTH = wino_th(NH), W_IH = wino_ih(NH), W_VS = wino_vs(NH), NT = 256 * NH;
   constexpr int RPS = W_IH * W_IWP + 16;            // raw channel-plane stride
   constexpr int VSZ = 16 * CK * W_VS, RSZ = CK * RPS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   int e_loff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int e = tid + 512 * i;
-    if (e >= CK * W_IH * 10) e -= 512;     // the 224 spare lanes of the second round repeat a unit of the first (same value to
+    int e = tid + NT * i;
+    if (e >= CK * W_IH * 10) e -= NT;     // the spare lanes of the second round repeat a unit of the first (same value to
                                            // the same LDS address): no divergent branch around the commit
     const int r = e / 10, q = e - r * 10;
     const int c = r / W_IH, iy = r - c * W_IH;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   };
   // input transform V = B^T d B, one (channel, tile) patch per thread (512 = CK * 64): raw tile -> V slab
   auto transform = [&](const float* rbuf, float* vbuf) {
-    const int c = wave, tile = lane;
+    const int c = tid / (32 * NH), tile = tid % (32 * NH);
     const int ty = tile >> 4, tx = tile & 15;
     const float* p = rbuf + c * RPS + (2 * ty) * W_IWP + 3 + 2 * tx;   // patch origin: row y0-1+2ty, col x0-1+2tx
     float d[4][4];
@@ -215,8 +220,9 @@ __global__ __launch_bounds__(512, 2) void k_wino(const WinoArgs A) {
   // [1] all the arithmetic as 16 packed-fp32 adds (v_pk_add_f32 with op_sel / neg modifiers: two results per instruction —
   // the VALU work is bunched so that the MFMA stream is interrupted once, not sixteen times), [2]-[3] the 16 LDS writes.
   f32x2 td[4][2], to[4][2];
-  const int tr_src = wave * RPS + (2 * (lane >> 4)) * W_IWP + 3 + 2 * (lane & 15);
-  const int tr_dst = wave * W_VS + (lane >> 5) * 32 + (lane & 15) * 2 + ((lane >> 4) & 1);
+  const int tr_c = tid / (32 * NH), tr_t = tid % (32 * NH);       // (channel, tile) of this thread's patch
+  const int tr_src = tr_c * RPS + (2 * (tr_t >> 4)) * W_IWP + 3 + 2 * (tr_t & 15);
+  const int tr_dst = tr_c * W_VS + (tr_t >> 5) * 32 + (tr_t & 15) * 2 + ((tr_t >> 4) & 1);
   auto tslice = [&](const int sl, const float* rbuf, float* vbuf) {
     if (sl == 0) {
       const float* p = rbuf + tr_src;
@@ -477,25 +483,53 @@ static int wino_run_mb(int pmb, int M, int nblocks) {
   return mb;
 }
 
-template <int MB, bool GATED = false, bool SUB = false>
-static int launch_wino(WinoArgs& a, hipStream_t st, const char* what) {
+template <int MB, bool GATED, bool SUB, int NH>
+static int launch_wino_nh(WinoArgs& a, hipStream_t st, const char* what) {
   constexpr int MT = MB * 16;
-  size_t smem = sizeof(float) * ((size_t)2 * 16 * WCK * W_VS + (size_t)2 * WCK * (W_IH * W_IWP + 16));
-  const size_t exch = sizeof(float) * 2 * (size_t)8 * MB * 2 * 4 * 64;   // row-direction output transform across the q waves
+  size_t smem = sizeof(float) * ((size_t)2 * 16 * WCK * wino_vs(NH) + (size_t)2 * WCK * (wino_ih(NH) * W_IWP + 16));
+  const size_t exch = sizeof(float) * 2 * (size_t)4 * NH * MB * 2 * 4 * 64;   // row-direction output transform across the q waves
   if (smem < exch) smem = exch;
   static bool attr[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino<MB, GATED, SUB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino<MB, GATED, SUB, NH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr[dev] = true;
   }
   a.mtiles = cdiv(a.Cout, MT);
   { static const int wm = getenv("CAGC_WINO_MAP") ? atoi(getenv("CAGC_WINO_MAP")) : 1; a.wg_map = wm; }
-  { static const int wo = getenv("CAGC_WINO_ORDER") ? atoi(getenv("CAGC_WINO_ORDER")) : 0; a.wg_order = wo; }
   CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
-  hipLaunchKernelGGL((k_wino<MB, GATED, SUB>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(512), smem, st, a);
+  hipLaunchKernelGGL((k_wino<MB, GATED, SUB, NH>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(256 * NH), smem, st, a);
   return check_launch(what);
+}
+
+// Tile geometry + variant selection shared by the two entry points.  NH (pixel-row halves per workgroup, see wino_th):
+// measured (scripts/time_wino.py, bs 16): 128 -> 128 @256^2 1.392 ms (NH 2) vs 1.352 (NH 1) — a 16-chunk tile is 15 % prologue +
+// epilogue, which the second workgroup on the CU covers; 512 -> 512 @64^2 1.222 vs 1.236 — at 64 chunks per tile the larger
+// tile's smaller halo wins; under-filled launches (512 -> 512 @32^2 at batch 4: 0.097 vs 0.090) want the finer tiles.
+static int wino_nh(int Kp, int64_t wgs_nh2) {
+  static const int v = getenv("CAGC_WINO_NH") ? atoi(getenv("CAGC_WINO_NH")) : 0;
+  if (v == 1 || v == 2) return v;
+  return (Kp <= 128 || wgs_nh2 < 1024) ? 1 : 2;
+}
+
+template <bool GATED, int NH>
+static int wino_dispatch_nh(WinoArgs& a, int M, hipStream_t st, const char* what) {
+  a.tiles_x = a.W / WTW; a.tiles_y = a.H / wino_th(NH); a.nblocks = a.B * a.tiles_x * a.tiles_y;
+  a.pmb = wino_mb(M);
+  const int rmb = wino_run_mb(a.pmb, M, a.nblocks);
+  if (rmb != a.pmb) return rmb == 2 ? launch_wino_nh<2, GATED, true, NH>(a, st, what) : launch_wino_nh<1, GATED, true, NH>(a, st, what);
+  switch (a.pmb) {
+    case 1: return launch_wino_nh<1, GATED, false, NH>(a, st, what);
+    case 2: return launch_wino_nh<2, GATED, false, NH>(a, st, what);
+    case 3: return launch_wino_nh<3, GATED, false, NH>(a, st, what);
+    default: return launch_wino_nh<4, GATED, false, NH>(a, st, what);
+  }
+}
+template <bool GATED>
+static int wino_dispatch(WinoArgs& a, int M, hipStream_t st, const char* what) {
+  const int64_t wgs2 = (int64_t)a.B * (a.W / WTW) * (a.H / wino_th(2)) * cdiv(M, wino_mb(M) * 16);
+  return wino_nh(a.Kp, wgs2) == 2 ? wino_dispatch_nh<GATED, 2>(a, M, st, what) : wino_dispatch_nh<GATED, 1>(a, M, st, what);
 }
 
 }  // namespace cagc
@@ -508,7 +542,7 @@ extern "C" int cagc_wino_trace_dump(long long* host) {
 }
 #endif
 
-extern "C" int cagc_wino_eligible(int H, int W) { return (H % WTH == 0 && W % WTW == 0) ? 1 : 0; }
+extern "C" int cagc_wino_eligible(int H, int W) { return (H % 8 == 0 && W % WTW == 0) ? 1 : 0; }
 
 extern "C" int64_t cagc_wino_packed_elems(int K, int M) {
   if (K <= 0 || M <= 0) return 0;
@@ -545,18 +579,8 @@ extern "C" int cagc_wino_conv3x3(float* out, const float* x, const float* up, co
   memset(&a, 0, sizeof(a));
   a.in = x; a.out = out; a.up = up; a.in_scale = s; a.out_scale = out_scale; a.noise = noise; a.noise_w = noise_w; a.bias = bias;
   a.B = B; a.Cin = Cin; a.Kp = wino_kp(Cin); a.Cout = Cout; a.Mp = round_up(Cout, 16); a.H = H; a.W = W;
-  a.tiles_x = W / WTW; a.tiles_y = H / WTH; a.nblocks = B * a.tiles_x * a.tiles_y;
   a.epi = epi; a.noise_bstride_on = (noise_batch == B) ? 1 : 0; a.alpha = alpha; a.act_scale = act_scale;
-  hipStream_t st = as_stream(stream);
-  a.pmb = wino_mb(Cout);
-  const int rmb = wino_run_mb(a.pmb, Cout, a.nblocks);
-  if (rmb != a.pmb) return rmb == 2 ? launch_wino<2, false, true>(a, st, what) : launch_wino<1, false, true>(a, st, what);
-  switch (a.pmb) {
-    case 1: return launch_wino<1>(a, st, what);
-    case 2: return launch_wino<2>(a, st, what);
-    case 3: return launch_wino<3>(a, st, what);
-    default: return launch_wino<4>(a, st, what);
-  }
+  return wino_dispatch<false>(a, Cout, as_stream(stream), what);
 }
 
 // Data gradient of `conv3x3 -> + bias -> LeakyReLU * act_scale` (the discriminator's ConvLayer, model.py:694-716) in ONE
@@ -578,16 +602,6 @@ extern "C" int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const f
   CAGC_REQUIRE(!residual || ((uintptr_t)residual % 8) == 0, "%s: unaligned residual", what);
   a.in = gout; a.gate = act_out; a.gate_alpha = alpha; a.gate_scale = act_scale; a.out = gx; a.up = up; a.residual = residual;
   a.B = B; a.Cin = Cout; a.Kp = wino_kp(Cout); a.Cout = Cin; a.Mp = round_up(Cin, 16); a.H = H; a.W = W;
-  a.tiles_x = W / WTW; a.tiles_y = H / WTH; a.nblocks = B * a.tiles_x * a.tiles_y;
   a.epi = CAGC_EPI_LINEAR; a.alpha = alpha; a.act_scale = 1.f;
-  hipStream_t st = as_stream(stream);
-  a.pmb = wino_mb(Cin);
-  const int rmb = wino_run_mb(a.pmb, Cin, a.nblocks);
-  if (rmb != a.pmb) return rmb == 2 ? launch_wino<2, true, true>(a, st, what) : launch_wino<1, true, true>(a, st, what);
-  switch (a.pmb) {
-    case 1: return launch_wino<1, true>(a, st, what);
-    case 2: return launch_wino<2, true>(a, st, what);
-    case 3: return launch_wino<3, true>(a, st, what);
-    default: return launch_wino<4, true>(a, st, what);
-  }
+  return wino_dispatch<true>(a, Cin, as_stream(stream), what);
 }
