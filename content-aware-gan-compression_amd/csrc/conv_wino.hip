@@ -7,18 +7,20 @@
 // 9 (2.25x fewer MFMA flops than the direct implicit GEMM of conv_igemm.hip).  All arithmetic is fp32 (exact-fp32 MFMA
 // v_mfma_f32_16x16x4_f32; the transforms use the coefficients 0, +-1, +-1/2 only).
 //
-// Workgroup = 512 threads = 8 waves; tile = MB*16 output channels x (8 x 32 output pixels = 4 x 16 Winograd tiles).
-// Wave (q, nh) owns row q of the 4x4 grid of Winograd positions (xi = 4q..4q+3) for half nh of the tiles (2 MFMA
-// N-blocks) and all MB channel blocks: accumulators acc[4][MB][2] (4 VGPRs each) -> 2 waves / SIMD.  Per K-chunk of 8
-// input channels:
-//   A operand: transformed weights U, pre-packed in MFMA register order, go global/L2 -> VGPRs directly (one 16-byte
-//     load per lane feeds 2*MB MFMAs; the ring holds a whole chunk ahead) — they never touch LDS, which was the
-//     co-bottleneck of the first version (LDS cycles per chunk ~= MFMA cycles per chunk);
-//   B operand: raw halo tile [8][10][40] --(registers, 3 chunks ahead)--> LDS (2 buffers) --transform, 1 (channel,tile)
-//     patch per thread--> V[16*8][64 tiles] in LDS (2 buffers; tiles stored [ty/2][tx][ty%2] so one ds_read_b64 feeds
-//     both N-blocks of a wave; row stride == 16 mod 32);
-//   one barrier per chunk; of the two waves sharing a SIMD one transforms chunk j+1 before multiplying chunk j, the
-//   other after, so the matrix pipe has work while the other wave is in the VALU/LDS phase.
+// Workgroup = NH*256 threads = 4*NH waves (NH = 1 | 2, chosen per launch); tile = MB*16 output channels x (4*NH x 32 output
+// pixels = 2*NH x 16 Winograd tiles).  Wave (q, nh) owns row q of the 4x4 grid of Winograd positions (xi = 4q..4q+3) for the
+// two tile rows 2nh, 2nh+1 (2 MFMA N-blocks) and all MB channel blocks: accumulators acc[4][MB][2] (4 VGPRs each) -> 2 waves
+// per SIMD (one 8-wave workgroup, or two 4-wave workgroups that cover each other's prologue / epilogue).  K runs in chunks
+// of 8 input channels (zero-padded to a multiple of 16: two chunks per loop iteration, immediate LDS addresses):
+//   A operand: transformed weights U, pre-packed in MFMA register order, go global/L2 -> VGPRs directly (raw buffer load,
+//     16 bytes per lane feed 2*MB MFMAs; the ring holds a whole chunk ahead and is refilled in place) — never through LDS;
+//   B operand: raw halo tile [8][4*NH+2][40] --(registers)--> LDS (2 buffers) --transform, 1 (channel,tile) patch per
+//     thread--> V[16*8][32*NH tiles] in LDS (2 buffers; tiles stored [ty/2][tx][ty%2] so one ds_read_b64 feeds both
+//     N-blocks of a wave; row stride == 16 mod 32).
+// gfx950's fp32 MFMA does not overlap VALU instructions (scripts/micro/mfma_coissue.hip), so there is no
+// "transform phase": the next chunk's transform (16 packed adds), the raw-tile commit and every load are slices inside each
+// wave's own stream of 64 MFMAs per chunk, written to cost as few VALU instructions as possible (22 per chunk); one
+// barrier per chunk, in front of its last K-step.
 // Output transform A^T M A: column direction in registers, row direction across the four q waves through LDS, every
 // lane then stores 2x2 pixels (8-byte stores, 128 B contiguous per 16-lane group).
 // The per-sample modulation s[b,c] is applied to the staged input, demodulation / noise / bias / LeakyReLU in the
@@ -60,7 +62,6 @@ struct WinoArgs {
   int pmb;                 // channel blocks per PACKED tile of `up` (wino_mb of the layer); a SUB launch runs fewer per workgroup
   int epi, noise_bstride_on;
   int wg_map;              // workgroup -> tile mapping, see k_wino
-  int wg_order;            // 1: round-1 phase order (slot-0 wave transforms first), for A/B measurements
   float alpha, act_scale;
 };
 

@@ -253,7 +253,7 @@ int cagc_torgb_bwd_finish(float* gw, float* gs, const float* gws, const float* s
  *                                   H % 8 == 0 and W % 32 == 0 (cagc_wino_eligible): 16 GEMMs on transformed 4x4
  *                                   tiles, 2.25x fewer fp32 MFMA flops than the direct implicit GEMM; all fp32.
  * cagc_wino_prep: weight [Cout,Cin,3,3] -> up = scale * G g G^T in MFMA A-operand order [Mtiles][16][Kp/4][64][4]
- *   (Kp = round_up(K,8); opaque to callers, size from cagc_wino_packed_elems).  dgrad = 0: K = Cin, M = Cout
+ *   (Kp = round_up(K,16), zero rows past K; opaque to callers, size from cagc_wino_packed_elems).  dgrad = 0: K = Cin, M = Cout
  *   (forward);  dgrad = 1: flipped taps, K = Cout, M = Cin — cagc_wino_conv3x3 on that packing with
  *   (Cin, Cout) swapped IS the data gradient of the conv.
  * ---------------------------------------------------------------------------------------------- */
