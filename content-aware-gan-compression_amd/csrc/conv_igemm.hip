@@ -29,12 +29,20 @@
 #include "common.h"
 #include "prep_device.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <type_traits>
 
 namespace cagc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// debug builds only (-DCAGC_IGEMM_ABL=bits, wrong results): 1 no B reads, 2 no A reads, 4 no tap-offset load, 8 no staging, 16 no commit, 32 no prefetch, 64 one barrier
+#ifdef CAGC_IGEMM_ABL
+#define CAGC_ABL(bit) ((CAGC_IGEMM_ABL & (bit)) != 0)
+#else
+#define CAGC_ABL(bit) false
+#endif
 
 constexpr int CONV_CK = 8;
 constexpr int MAX_TAPS = 9;
@@ -328,9 +336,9 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
   for (int kc = kc_lo; kc < kc_hi; kc += CK) {
     if (!dbuf) {
       __syncthreads();  // MFMA reads of the previous chunk are done
-      commit(0);
-      __syncthreads();
-      if (kc + CK < kc_hi) prefetch(kc + CK);  // in flight during the MFMAs below
+      if (!CAGC_ABL(8) && !CAGC_ABL(16)) commit(0);
+      if (!CAGC_ABL(64)) __syncthreads();
+      if (!CAGC_ABL(8) && !CAGC_ABL(32) && kc + CK < kc_hi) prefetch(kc + CK);  // in flight during the MFMAs below
     }
     a_lds = a_base + cur * a_bs;
     b_lds = b_base + cur * b_bs;
@@ -344,16 +352,16 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
       const int np = (NPH == 1) ? ntaps : ph_nt[P];                                                              \
       _Pragma("unroll 1") for (int tt = 0; tt < np; ++tt) {                                                      \
         const int t = tbase + tt;                                                                                \
-        const int to = I.taps[t].lds_off;                                                                        \
+        const int to = CAGC_ABL(4) ? 0 : I.taps[t].lds_off;                                                     \
         float bv[CK / 4][NBW];                                                                                   \
         _Pragma("unroll") for (int s = 0; s < CK / 4; ++s)                                                       \
-          _Pragma("unroll") for (int j = 0; j < NBW; ++j) bv[s][j] = b_lds[(4 * s + g) * PS + lb[j] + to];       \
+          _Pragma("unroll") for (int j = 0; j < NBW; ++j) bv[s][j] = CAGC_ABL(1) ? (float)(lm + s + j) : b_lds[(4 * s + g) * PS + lb[j] + to]; \
         const float* ap = a_lds + (t * CK + g) * LDA + lm;                                                       \
-        float a_cur = ap[0];                                                                                     \
+        float a_cur = CAGC_ABL(2) ? (float)lm : ap[0];                                                           \
         _Pragma("unroll") for (int u = 0; u < (CK / 4) * MB; ++u) {   /* A fragment one group of MFMAs ahead */  \
           const int s = u / MB, i = u - s * MB;                                                                  \
           float a_nxt = 0.f;                                                                                     \
-          if (u + 1 < (CK / 4) * MB) a_nxt = ap[4 * ((u + 1) / MB) * LDA + ((u + 1) % MB) * 16];                 \
+          if (u + 1 < (CK / 4) * MB) a_nxt = CAGC_ABL(2) ? a_cur + 1.f : ap[4 * ((u + 1) / MB) * LDA + ((u + 1) % MB) * 16]; \
           _Pragma("unroll") for (int j = 0; j < NBW; ++j)                                                        \
             acc[P][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, bv[s][j], acc[P][i][j], 0, 0, 0);         \
           a_cur = a_nxt;                                                                                         \
@@ -756,6 +764,11 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   a.nblocks = blocks; a.mtiles = mtiles;
   CAGC_REQUIRE((int64_t)blocks * mtiles < (1ll << 31), "%s: grid too large", what);
   dim3 grid((unsigned)(blocks * mtiles), 1, 1);
+  {   // CAGC_CONV_DEBUG=1: one line per launch (tile plan, LDS, grid) on stderr
+    static const bool dbg = getenv("CAGC_CONV_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[cagc] %s: items %d taps %d mb %d nv %d smem %zu B (%d WG/CU by LDS) grid %d ksplit %d dbuf %d K %d M %d\n", what, nitems,
+                     raw[0].ntaps, mb, nv, smem, (int)(160 * 1024 / smem), blocks * mtiles, ks, a.dbuf, a.Kp, a.Mp);
+  }
   int rc;
   if (nph == 4) {
     CAGC_REQUIRE(a.vec && nv <= 4 && !a.gs, "%s: fused-phase path needs the aligned small-tile configuration", what);
