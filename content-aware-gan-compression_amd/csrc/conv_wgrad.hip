@@ -600,7 +600,11 @@ static bool wgrad2_pf_ok(const Wg2Args& a, int mb, int nb) {
 }
 
 struct Wg2Plan { int mb, nb; };
-static Wg2Plan wg2_plan(int Cout, int Cin) {
+static Wg2Plan wg2_plan(int Cout, int Cin, int up = 0) {
+  if (up) {   // tuning: CAGC_WGRAD_PLAN_UP="mb,nb" forces the transposed-conv mode's tile plan
+    static const char* e = getenv("CAGC_WGRAD_PLAN_UP");
+    if (e && e[0] && e[1] == ',' && e[2]) return Wg2Plan{e[0] - '0', e[2] - '0'};
+  }
   // least padded work first; among equals prefer a plan that runs 2 waves / SIMD (<= 110 accumulator registers), then
   // the larger tile
   // {4,2} / {4,4}: the discriminator's channel counts (multiples of 64: 128 .. 512) — a 64-channel M tile halves the
@@ -642,7 +646,8 @@ static void wgrad2_geometry(Wg2Args& a, Wg2Plan pl, int B, int Cin, int Cout, in
     }
   }
   a.TW = tw;
-  a.TH = (up ? 64 : 128) / tw;
+  static const int up_pix = getenv("CAGC_WGRAD_UP_PIX") ? atoi(getenv("CAGC_WGRAD_UP_PIX")) : 64;   // tuning: K pixels per staged tile, up mode
+  a.TH = (up ? up_pix : 128) / tw;
   if (a.TH > 16) a.TH = 16;
   if (a.TH < 1) a.TH = 1;
   a.tiles_x = cdiv(a.Wk, a.TW); a.tiles_y = cdiv(a.Hk, a.TH);
@@ -793,7 +798,7 @@ extern "C" int64_t cagc_modconv_wgrad_workspace(int B, int Cin, int Cout, int H,
   int64_t n = (int64_t)a.nsplit * a.ntaps * a.Mp32 * a.Np32;
   if (ksize == 3 && W % 4 == 0) {   // the caller's pointers decide v1/v2 at launch: size for the larger
     Wg2Args b;
-    wgrad2_geometry(b, wg2_plan(Cout, Cin), B, Cin, Cout, H, W, ksize, up);
+    wgrad2_geometry(b, wg2_plan(Cout, Cin, up), B, Cin, Cout, H, W, ksize, up);
     const int64_t n2 = (int64_t)b.nsplit * b.ntaps * b.Mp * b.Np;
     if (n2 > n) n = n2;
   }
@@ -817,7 +822,7 @@ extern "C" int cagc_modconv_wgrad_demod(float* gweight, float* workspace, const 
   CAGC_REQUIRE(ksize == 3 || (ksize == 1 && !up), "%s: unsupported ksize/up", what);
   if (wgrad_use_v2(W, ksize, g, x)) {
     hipStream_t st2 = as_stream(stream);
-    const Wg2Plan pl = wg2_plan(Cout, Cin);
+    const Wg2Plan pl = wg2_plan(Cout, Cin, up);
     Wg2Args b;
     wgrad2_geometry(b, pl, B, Cin, Cout, H, W, ksize, up);
     b.ga = g; b.x = x; b.s = s; b.ws = workspace;
