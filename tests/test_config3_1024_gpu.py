@@ -131,8 +131,11 @@ def test_kd_step_1024_properties():
         if a is None:
             continue
         assert torch.isfinite(a).all(), p[0]
-        # fp32 atomics make single runs differ at 1e-4 of a tensor's scale; additivity must hold to that
-        assert_close(a, b + c, 5e-4 if a.numel() > 1 else 2e-2, "additivity " + p[0])   # single-element sums of 10^7 atomically accumulated terms
+        # Three separate forward passes: the split-K layers accumulate with fp32 atomics, so two runs differ at 1e-6 of a
+        # tensor's scale, which flips a handful of the 10^8 LeakyReLU gates of the student / discriminator between the runs
+        # (one flipped gate moves a 3x3 patch of a gradient by O(1e-3) of its scale).  Observed over repeated runs
+        # of this test: 1e-5 .. 9e-4; the bound is the parity bar's order, not a rounding bound.
+        assert_close(a, b + c, 3e-3 if a.numel() > 1 else 2e-2, "additivity " + p[0])   # single-element sums of 10^7 atomically accumulated terms
     with torch.no_grad():
         one = student([z[1:2] for z in zs], inject_index=7, noise=[n[1:2] for n in sn])
         assert_close(one, img[1:2], 1e-5, "student batch independence")

@@ -868,3 +868,58 @@ def test_ops_fp64_fp16_dispatch(dtype, tol):
         assert yg.dtype == dtype
         assert_close(yg, yr, tol, f"upfirdn2d {dtype} up{up} down{down}")
         assert_close(gg, gr, tol, f"upfirdn2d {dtype} up{up} down{down} grad")
+
+
+_WINO_SHAPES_SCRIPT = r"""
+import os, sys, torch
+import torch.nn.functional as F
+sys.path[:0] = [sys.argv[1], os.path.join(sys.argv[1], "content-aware-gan-compression_amd")]
+from cagc import _lib
+from cagc.op import modconv as mc
+torch.manual_seed(0)
+worst = 0.0
+for (B, Cin, Cout, H, W, styled) in [(2, 128, 128, 64, 64, 0), (1, 160, 200, 32, 64, 1), (3, 20, 36, 32, 32, 1), (1, 11, 7, 8, 32, 0),
+                                     (2, 39, 39, 16, 96, 1)]:
+    x = torch.randn(B, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda")
+    s = torch.rand(B, Cin, device="cuda") + 0.5
+    d = torch.rand(B, Cout, device="cuda") + 0.5
+    noise = torch.randn(B, 1, H, W, device="cuda"); nw = torch.tensor([0.3], device="cuda"); bias = torch.randn(Cout, device="cuda")
+    up = mc.pack_wino(w, 1.0, False); out = torch.full((B, Cout, H, W), float("nan"), device="cuda")
+    if styled:
+        _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(x), _lib.ptr(up), _lib.ptr(s), B, Cin, Cout, H, W, 1, _lib.ptr(d), _lib.ptr(noise), B,
+                  _lib.ptr(nw), _lib.ptr(bias), 0.2, 2 ** 0.5)
+        ref = F.conv2d((x * s[:, :, None, None]).double(), w.double(), padding=1) * d[:, :, None, None].double()
+        ref = F.leaky_relu(ref + 0.3 * noise.double() + bias.double()[None, :, None, None], 0.2) * 2 ** 0.5
+    else:
+        _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(x), _lib.ptr(up), None, B, Cin, Cout, H, W, 0, None, None, 0, None, None, 0.2, 1.0)
+        ref = F.conv2d(x.double(), w.double(), padding=1)
+    err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err == err and err < 5e-6, (B, Cin, Cout, H, W, styled, err)
+    worst = max(worst, err)
+# gated variant: data gradient of conv3x3 + bias + LeakyReLU in one launch (frozen discriminator layer), with the residual add
+for (B, Cin, Cout, H, W) in [(2, 64, 128, 32, 64), (1, 24, 40, 16, 32)]:
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda"); gout = torch.randn(B, Cout, H, W, device="cuda")
+    act = torch.randn(B, Cout, H, W, device="cuda"); res = torch.randn(B, Cin, H, W, device="cuda")
+    upb = mc.pack_wino(w, 1.0, True); gx = torch.full((B, Cin, H, W), float("nan"), device="cuda")
+    _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(gout), _lib.ptr(act), _lib.ptr(upb), _lib.ptr(res), B, Cin, Cout, H, W, 0.2, 2 ** 0.5)
+    gin = gout.double() * torch.where(act > 0, 1.0, 0.2).double() * 2 ** 0.5
+    ref = F.conv_transpose2d(gin, w.double(), padding=1) + res.double()
+    err = ((gx.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err == err and err < 5e-6, ("gated", B, Cin, Cout, H, W, err)
+    worst = max(worst, err)
+print("WINO_OK %.3e" % worst)
+"""
+
+
+@pytest.mark.parametrize("nh", ["1", "2"])
+def test_winograd_both_workgroup_shapes_vs_float64(nh, tmp_path):
+    """The Winograd kernel picks 4-wave (NH 1) or 8-wave (NH 2) workgroups per launch (conv_wino.hip wino_nh); the choice
+    is read once per process, so each shape is forced in its own interpreter: linear and styled epilogues, ragged channel
+    counts (K padded to 16, M to the channel tile), against a float64 direct convolution (5e-6 of the output scale)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "wino_shapes.py"
+    script.write_text(_WINO_SHAPES_SCRIPT)
+    env = dict(os.environ, CAGC_WINO_NH=nh)
+    r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "WINO_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
