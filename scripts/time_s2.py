@@ -6,7 +6,7 @@ from cagc import _lib
 if os.environ.get("LIB"):      # A/B against another build of the library (e.g. an ablation build)
     _lib.LIB_PATH = os.path.join(ROOT, "content-aware-gan-compression_amd", "cagc", os.environ["LIB"])
 from cagc.op import modconv as mc
-B = 16
+B = int(os.environ.get("BS", "16"))
 def timeit(f):
     for _ in range(3): f()
     torch.cuda.synchronize(); t = time.perf_counter()
