@@ -65,13 +65,8 @@ struct WinoArgs {
   float alpha, act_scale;
 };
 
-// Phase timing of one workgroup (debug builds only: -DCAGC_WINO_TRACE, scripts/trace_wino.py): per wave, shader cycles spent
-// in [0] commit+prefetch, [1] transform before the multiply, [2] multiply, [3] transform after, [4] barrier.
-#ifndef CAGC_WINO_NOPRIO
-#define WINO_PRIO(p) __builtin_amdgcn_s_setprio(p)
-#else
-#define WINO_PRIO(p)
-#endif
+// Timing of one workgroup (debug builds only: -DCAGC_WINO_TRACE, scripts/trace_wino.py): per wave, shader cycles per chunk
+// in [2] the K-steps in front of the barrier, [4] barrier + last K-step's issue; [5] prologue, [6] epilogue of the workgroup.
 #ifdef CAGC_WINO_TRACE
 __device__ long long g_wino_trace[8][8];
 #define WINO_TR(k) do { const long long t_ = clock64(); tr[k] += t_ - tlast; tlast = t_; } while (0)
@@ -93,11 +88,10 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   float* v_lds = smem;                         // [2][16*CK][W_VS]
   float* raw = v_lds + 2 * VSZ;                // [2][CK][RPS]
 
-  // 8 wavefronts: wave (q, nh) owns row q of the 4x4 grid of Winograd positions (xi = 4q .. 4q+3) for half nh of the
-  // tiles (2 MFMA N-blocks = Winograd-tile rows 2nh, 2nh+1) and all MB channel blocks: acc[4][MB][2].  Every K-step
-  // is one 16-byte global load (A, 4 channel blocks) + one 8-byte LDS read (B, 2 tile rows) for 2*MB MFMAs.
-  // Waves w and w+4 = (q, 0) and (q, 1) share a SIMD (and their A stream): the nh = 0 wave transforms the next chunk
-  // first and multiplies second, the nh = 1 wave the other way round, so the MFMA pipe always has a wave feeding it.
+  // 4*NH wavefronts: wave (q, nh) owns row q of the 4x4 grid of Winograd positions (xi = 4q .. 4q+3) for the Winograd-tile
+  // rows 2nh, 2nh+1 (2 MFMA N-blocks) and all MB channel blocks: acc[4][MB][2].  Every K-step is one 16-byte buffer load (A, 4
+  // channel blocks) + one 8-byte LDS read (B, 2 tile rows) for 2*MB MFMAs.  Waves w and w+4 share a SIMD (scripts/micro/
+  // hwid.hip); all waves run the same instruction stream (no transform / multiply phases, see the main loop).
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = wave & 3, nh = wave >> 2;
@@ -106,7 +100,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   // Workgroup -> (pixel tile, channel tile).  Workgroups are dealt round-robin to the 8 XCDs (w % 8), each with its own
   // 4 MB L2.  map 1 (default): the channel-tile-major order is cut into 8 contiguous runs, one per XCD, so an XCD streams ONE
   // transformed-weight slice (<= 2 MB) at a time and keeps it L2-resident — the latency-critical A-operand ring then hits L2,
-  // and the misses move to the input tiles, which are prefetched three chunks ahead.  map 0 (round 1): the 8 channel tiles
+  // and the misses move to the input tiles, whose loads are a whole chunk ahead of their commit.  map 0 (round 1): the 8 channel tiles
   // of a pixel tile share an XCD (input L2-resident, weights re-streamed).
   int pix_id, mtile;
   {
@@ -132,7 +126,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   const int HW = A.H * A.W;
   const int nch = A.Kp / CK;
 
-  // ---- staging descriptors: raw tile = CK x 10 rows x 10 float4 = 800 units -> 2 per thread ------------------
+  // ---- staging descriptors: raw tile = CK x (4*NH+2) rows x 10 float4 = 800 / 480 units -> 2 rounds of the workgroup ----
   // On this chip VALU instructions do NOT overlap the fp32 MFMA (scripts/micro/mfma_coissue.hip: every VALU instruction next
   // to the MFMA stream costs its 4 issue cycles plus a switch bubble), so the loop is written to execute as few of them as
   // possible.  Global loads are raw buffer loads: (uniform descriptor of the chunk) + (per-lane byte offset, constant over the
@@ -178,18 +172,18 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   auto commit = [&](float* rbuf) {   // registers -> raw tile in LDS
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        float4 v = rin[i];
-        if (GATED) {   // fused LeakyReLU backward: the conv input is gout * lrelu'(out)
-          const float4 gt = rgt[i];
-          const float hi = A.gate_scale, lo = A.gate_alpha * A.gate_scale;
-          v.x *= gt.x > 0.f ? hi : lo; v.y *= gt.y > 0.f ? hi : lo; v.z *= gt.z > 0.f ? hi : lo; v.w *= gt.w > 0.f ? hi : lo;
-        }
-        const float s = has_scale ? rsc[i] : 1.f;
-        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-        *reinterpret_cast<float4*>(rbuf + e_loff[i]) = v;
+      float4 v = rin[i];
+      if (GATED) {   // fused LeakyReLU backward: the conv input is gout * lrelu'(out)
+        const float4 gt = rgt[i];
+        const float hi = A.gate_scale, lo = A.gate_alpha * A.gate_scale;
+        v.x *= gt.x > 0.f ? hi : lo; v.y *= gt.y > 0.f ? hi : lo; v.z *= gt.z > 0.f ? hi : lo; v.w *= gt.w > 0.f ? hi : lo;
       }
+      const float s = has_scale ? rsc[i] : 1.f;
+      v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+      *reinterpret_cast<float4*>(rbuf + e_loff[i]) = v;
+    }
   };
-  // input transform V = B^T d B, one (channel, tile) patch per thread (512 = CK * 64): raw tile -> V slab
+  // input transform V = B^T d B, one (channel, tile) patch per thread (CK * 32 * NH patches): raw tile -> V slab (prologue only)
   auto transform = [&](const float* rbuf, float* vbuf) {
     const int c = tid / (32 * NH), tile = tid % (32 * NH);
     const int ty = tile >> 4, tx = tile & 15;
