@@ -90,6 +90,7 @@ def stream_bytes(name, a):
 # dominant-entry-point -> device symbol (for the PMC traffic lookup) and MFMA instruction
 KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false, false", "cagc_wino_conv3x3_act_dgrad[k_wino<4, true>]": "k_wino<4, true, false",
              "cagc_wino_conv3x3[k_wino<3, false>]": "k_wino<3, false, false",
+             "cagc_wino_conv3x3[k_wino<4, false, NH3>]": "k_wino<4, false, false, 3>", "cagc_wino_conv3x3_act_dgrad[k_wino<4, true, NH3>]": "k_wino<4, true, false, 3>",
              "cagc_wino_conv3x3[k_wino<4, false, NH2>]": "k_wino<4, false, false, 2>", "cagc_wino_conv3x3[k_wino<4, false, NH1>]": "k_wino<4, false, false, 1>",
              "cagc_wino_conv3x3[k_wino<3, false, NH1>]": "k_wino<3, false, false, 1>", "cagc_wino_conv3x3[k_wino<3, false, NH2>]": "k_wino<3, false, false, 2>",
              "cagc_wino_conv3x3_act_dgrad[k_wino<4, true, NH2>]": "k_wino<4, true, false, 2>", "cagc_wino_conv3x3_act_dgrad[k_wino<4, true, NH1>]": "k_wino<4, true, false, 1>",
@@ -148,7 +149,7 @@ class KernelTimer:
                 # 4-wave (NH 1) or 8-wave (NH 2) workgroups: conv_wino.hip wino_nh()
                 Bq, K, Hq, Wq = (args[5], args[7], args[8], args[9]) if gated else (args[4], args[5], args[7], args[8])
                 wgs2 = Bq * (Wq // 32) * (Hq // 8) * -(-args[6] // (mb * 16))
-                nh = 1 if (-(-K // 16) * 16 <= 128 or wgs2 < 1024) else 2
+                nh = 1 if (-(-K // 16) * 16 <= 128 or wgs2 < 1024) else (3 if (mb == 4 and args[6] % 128 == 0) else 2)   # 3: wide shape
                 key = f"{name}[k_wino<{mb}, {'true' if gated else 'false'}, NH{nh}>]"
             self.records.append((key, s, e, conv_flops(name, args), stream_bytes(name, args)))
         self.lib_mod.call = timed

@@ -7,8 +7,8 @@
 // 9 (2.25x fewer MFMA flops than the direct implicit GEMM of conv_igemm.hip).  All arithmetic is fp32 (exact-fp32 MFMA
 // v_mfma_f32_16x16x4_f32; the transforms use the coefficients 0, +-1, +-1/2 only).
 //
-// Workgroup = NH*256 threads = 4*NH waves (NH = 1 | 2, chosen per launch); tile = MB*16 output channels x (4*NH x 32 output
-// pixels = 2*NH x 16 Winograd tiles).  Wave (q, nh) owns row q of the 4x4 grid of Winograd positions (xi = 4q..4q+3) for the
+// Workgroup = NH*256 threads = 4*NH waves (NH = 1 | 2, chosen per launch; NH = 3: the wide shape, see wino_geo); tile = MB*16
+// output channels x (4*NH x 32 output pixels = 2*NH x 16 Winograd tiles).  Wave (q, nh) owns row q of the 4x4 grid of Winograd positions (xi = 4q..4q+3) for the
 // two tile rows 2nh, 2nh+1 (2 MFMA N-blocks) and all MB channel blocks: accumulators acc[4][MB][2] (4 VGPRs each) -> 2 waves
 // per SIMD (one 8-wave workgroup, or two 4-wave workgroups that cover each other's prologue / epilogue).  K runs in chunks
 // of 8 input channels (zero-padded to a multiple of 16: two chunks per loop iteration, immediate LDS addresses):
@@ -41,9 +41,14 @@ constexpr int WTW = 32, W_IWP = 40;          // tile width; padded raw row (LDS 
 // NH = halves of 4 pixel rows per workgroup: NH = 2 -> 8 waves, tile 8 x 32 pixels (64 Winograd tiles); NH = 1 -> 4 waves, tile
 // 4 x 32 (32 tiles) and TWO workgroups per CU, each wave alone on its SIMD slot: one workgroup's prologue / epilogue (4-15 %
 // of its life) runs under the other's MFMA stream.  Same per-wave instruction stream in both.
-constexpr int wino_th(int NH) { return 4 * NH; }                 // tile height
-constexpr int wino_ih(int NH) { return 4 * NH + 2; }             // raw tile rows
-constexpr int wino_vs(int NH) { return NH == 2 ? 80 : 48; }      // V row stride: 32 * NH tiles, == 16 (mod 32)
+// NH = 3 ("wide"): the 4 x 32 pixel tile of NH = 1, but 8 waves = (position row q) x (64-channel half mh): the workgroup covers
+// TWO packed channel tiles (128 output channels) with ONE staged / transformed input tile — half the transform, commit and
+// raw-tile traffic per MFMA (on this chip that VALU work is MFMA time).
+constexpr int wino_geo(int NH) { return NH == 2 ? 2 : 1; }                  // pixel-row halves of the tile geometry
+constexpr int wino_threads(int NH) { return NH == 1 ? 256 : 512; }
+constexpr int wino_th(int NH) { return 4 * wino_geo(NH); }                  // tile height
+constexpr int wino_ih(int NH) { return 4 * wino_geo(NH) + 2; }              // raw tile rows
+constexpr int wino_vs(int NH) { return wino_geo(NH) == 2 ? 80 : 48; }       // V row stride: 32 * geo tiles, == 16 (mod 32)
 
 struct WinoArgs {
   const float* in;
@@ -75,13 +80,16 @@ __device__ long long g_wino_trace[8][8];
 #endif
 
 template <int MB, bool GATED, bool SUB = false, int NH = 2>
-__global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
+__global__ __launch_bounds__(wino_threads(NH), 2) void k_wino(const WinoArgs A) {
 #ifdef CAGC_WINO_TRACE
   const long long t_entry = clock64();
 #endif
   constexpr int CK = WCK;
   constexpr int MT = MB * 16;
-  constexpr int WTH = wino_th(NH), W_IH = wino_ih(NH), W_VS = wino_vs(NH), NT = 256 * NH;
+  constexpr int WTH = wino_th(NH), W_IH = wino_ih(NH), W_VS = wino_vs(NH), NT = wino_threads(NH), GEO = wino_geo(NH);
+  constexpr bool WIDE = NH == 3;
+  constexpr int NU = (CK * W_IH * 10 + NT - 1) / NT;   // raw-tile units (float4) per thread: 2, or 1 in the wide shape
+  static_assert(!(WIDE && SUB), "the wide shape takes whole packed channel tiles");
   constexpr int RPS = W_IH * W_IWP + 16;            // raw channel-plane stride
   constexpr int VSZ = 16 * CK * W_VS, RSZ = CK * RPS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -94,7 +102,9 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   // hwid.hip); all waves run the same instruction stream (no transform / multiply phases, see the main loop).
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q = wave & 3, nh = wave >> 2;
+  const int q = wave & 3, hi = wave >> 2;
+  const int nh = WIDE ? 0 : hi;          // tile-row half (NH = 2)
+  const int mh = WIDE ? hi : 0;          // 64-channel half (wide shape)
   const int lm = lane & 15, g = lane >> 4;
 
   // Workgroup -> (pixel tile, channel tile).  Workgroups are dealt round-robin to the 8 XCDs (w % 8), each with its own
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   const int ty_i = (pix_id / A.tiles_x) % A.tiles_y;
   const int b = pix_id / (A.tiles_x * A.tiles_y);
   const int x0 = tx_i * WTW, y0 = ty_i * WTH;
-  const int m0 = mtile * MT;
+  const int m0 = WIDE ? (2 * mtile + mh) * MT : mtile * MT;   // wide: mtile counts 128-channel tiles = pairs of packed tiles
   const int HW = A.H * A.W;
   const int nch = A.Kp / CK;
 
@@ -133,13 +143,13 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   // chunks) — no address arithmetic in the vector ALU — and the descriptor's range check supplies every zero for free:
   // units outside the image get an out-of-range offset, channels past Cin lie beyond num_records.
   constexpr unsigned OOR = 0x80000000u;
-  unsigned e_boff[2], e_soff[2];   // byte offsets: input / gate tile unit, in_scale
-  int e_loff[2];
+  unsigned e_boff[NU], e_soff[NU];   // byte offsets: input / gate tile unit, in_scale
+  int e_loff[NU];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NU; ++i) {
     int e = tid + NT * i;
-    if (e >= CK * W_IH * 10) e -= NT;     // the spare lanes of the second round repeat a unit of the first (same value to
-                                           // the same LDS address): no divergent branch around the commit
+    if (e >= CK * W_IH * 10) e -= CK * W_IH * 10;   // spare lanes repeat a unit (same value to the same LDS address): no
+                                                    // divergent branch around the commit
     const int r = e / 10, q = e - r * 10;
     const int c = r / W_IH, iy = r - c * W_IH;
     const int gy = y0 - 1 + iy, gx = x0 - 4 + 4 * q;
@@ -148,9 +158,9 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
     e_soff[i] = 4u * (unsigned)c;
     e_loff[i] = c * RPS + iy * W_IWP + 4 * q;
   }
-  float4 rin[2];
-  float4 rgt[GATED ? 2 : 1];
-  float rsc[2];
+  float4 rin[NU];
+  float4 rgt[GATED ? NU : 1];
+  float rsc[NU];
   const bool has_scale = A.in_scale != nullptr;
   const int nfull = A.Cin / CK;
   auto prefetch = [&](int j) {   // global -> registers, chunk j (padding chunks and chunks past the end: zeros)
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(has_scale ? A.in_scale + (int64_t)b * A.Cin + j * CK : A.in), 0, has_scale ? nreal * 4 : 0, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NU; ++i) {
       rin[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ri, e_boff[i], 0, 0));
       if (GATED) {
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.gate + cbase), 0, nreal * HW * 4, 0x00020000);
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   };
   auto commit = [&](float* rbuf) {   // registers -> raw tile in LDS
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NU; ++i) {
       float4 v = rin[i];
       if (GATED) {   // fused LeakyReLU backward: the conv input is gout * lrelu'(out)
         const float4 gt = rgt[i];
@@ -185,7 +195,8 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   };
   // input transform V = B^T d B, one (channel, tile) patch per thread (CK * 32 * NH patches): raw tile -> V slab (prologue only)
   auto transform = [&](const float* rbuf, float* vbuf) {
-    const int c = tid / (32 * NH), tile = tid % (32 * NH);
+    const int pt = WIDE ? (tid & 255) : tid;
+    const int c = pt / (32 * GEO), tile = pt % (32 * GEO);
     const int ty = tile >> 4, tx = tile & 15;
     const float* p = rbuf + c * RPS + (2 * ty) * W_IWP + 3 + 2 * tx;   // patch origin: row y0-1+2ty, col x0-1+2tx
     float d[4][4];
@@ -215,7 +226,8 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   // [1] all the arithmetic as 16 packed-fp32 adds (v_pk_add_f32 with op_sel / neg modifiers: two results per instruction —
   // the VALU work is bunched so that the MFMA stream is interrupted once, not sixteen times), [2]-[3] the 16 LDS writes.
   f32x2 td[4][2], to[4][2];
-  const int tr_c = tid / (32 * NH), tr_t = tid % (32 * NH);       // (channel, tile) of this thread's patch
+  const int tr_p = WIDE ? (tid & 255) : tid;                      // wide: the two channel halves take turns (by chunk parity)
+  const int tr_c = tr_p / (32 * GEO), tr_t = tr_p % (32 * GEO);   // (channel, tile) of this thread's patch
   const int tr_src = tr_c * RPS + (2 * (tr_t >> 4)) * W_IWP + 3 + 2 * (tr_t & 15);
   const int tr_dst = tr_c * W_VS + (tr_t >> 5) * 32 + (tr_t & 15) * 2 + ((tr_t >> 4) & 1);
   auto tslice = [&](const int sl, const float* rbuf, float* vbuf) {
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   // A.pmb blocks; this workgroup's MB (1 or 2) blocks start at slot0 inside the packed float4, so each lane loads just those
   // 4 / 8 bytes.  Regular launches: MB == pmb, slot0 = 0, one 16-byte load per lane.
   const int gb0 = mtile * MB;
-  const int ptile = SUB ? gb0 / A.pmb : mtile;
+  const int ptile = SUB ? gb0 / A.pmb : (WIDE ? 2 * mtile + mh : mtile);
   const int slot0 = SUB ? gb0 - ptile * A.pmb : 0;
   // raw buffer loads: descriptor = this wave's row of positions, scalar offset = (position, K-step), lane offset constant
   const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
@@ -336,10 +348,13 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
       // CAGC_WINO_ABL (debug builds, wrong results): bit 0 drops the transform slices, 1 the A-ring refills, 2 the B reads,
       // 3 the raw-tile commit + prefetch — what each costs next to the MFMA stream
 #if !(defined(CAGC_WINO_ABL) && (CAGC_WINO_ABL & 1))
-      if (t == 2) tslice(1, nullptr, vnext);
-      else if (t == 3) tslice(2, nullptr, vnext);
-      else if (t == 4) tslice(3, nullptr, vnext);
-      else if (t == 7) tslice(0, rafter, nullptr);    // reads for the transform of chunk j+2 (done during chunk j+1)
+      // wide shape: 256 patches for 512 threads — the waves of channel half mh == (chunk parity) transform during this chunk
+      if (!WIDE || mh == cur) {
+        if (t == 2) tslice(1, nullptr, vnext);
+        else if (t == 3) tslice(2, nullptr, vnext);
+        else if (t == 4) tslice(3, nullptr, vnext);
+      }
+      if (t == 7 && (!WIDE || mh == (cur ^ 1))) tslice(0, rafter, nullptr);    // reads for the transform of chunk j+2 (done during chunk j+1)
 #endif
 #if defined(CAGC_WINO_ABL) && (CAGC_WINO_ABL & 8)
       if (false) {
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   bv_carry = reinterpret_cast<const float2*>(v_lds + (q * 4 * CK + g) * W_VS + nh * 32 + lm * 2)[0];
-  tslice(0, raw + RSZ, nullptr);      // chunk 1, transformed during chunk 0
+  if (!WIDE || mh == 0) tslice(0, raw + RSZ, nullptr);      // chunk 1, transformed during chunk 0
 #ifdef CAGC_WINO_TRACE
   tlast = clock64();
   tr[5] = tlast - t_entry;   // prologue
@@ -405,7 +420,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a0 = acc[0][i][nbl][r], a1 = acc[1][i][nbl][r], a2 = acc[2][i][nbl][r], a3 = acc[3][i][nbl][r];
-        ex[(((((nh * 4 + q) * MB + i) * 2 + nbl) * 4 + r) << 6) + lane] = make_float2(a0 + a1 + a2, a1 - a2 - a3);
+        ex[(((((hi * 4 + q) * MB + i) * 2 + nbl) * 4 + r) << 6) + lane] = make_float2(a0 + a1 + a2, a1 - a2 - a3);
       }
   __syncthreads();
   const bool styled = (A.epi == CAGC_EPI_STYLED);
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(256 * NH, 2) void k_wino(const WinoArgs A) {
         const int m = m0 + i * 16 + 4 * g + r;
         float2 z[4];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) z[qq] = ex[(((((nh * 4 + qq) * MB + i) * 2 + nbl_f) * 4 + r) << 6) + lane];
+        for (int qq = 0; qq < 4; ++qq) z[qq] = ex[(((((hi * 4 + qq) * MB + i) * 2 + nbl_f) * 4 + r) << 6) + lane];
         if (m < A.Cout) {
           const float osc = A.out_scale ? A.out_scale[b * A.Cout + m] : 1.f;
           const float bs = styled ? A.bias[m] : 0.f;
@@ -482,7 +497,7 @@ template <int MB, bool GATED, bool SUB, int NH>
 static int launch_wino_nh(WinoArgs& a, hipStream_t st, const char* what) {
   constexpr int MT = MB * 16;
   size_t smem = sizeof(float) * ((size_t)2 * 16 * WCK * wino_vs(NH) + (size_t)2 * WCK * (wino_ih(NH) * W_IWP + 16));
-  const size_t exch = sizeof(float) * 2 * (size_t)4 * NH * MB * 2 * 4 * 64;   // row-direction output transform across the q waves
+  const size_t exch = sizeof(float) * 2 * (size_t)(wino_threads(NH) / 64) * MB * 2 * 4 * 64;   // row-direction output transform across the q waves
   if (smem < exch) smem = exch;
   static bool attr[64] = {};
   int dev = 0;
@@ -491,10 +506,10 @@ static int launch_wino_nh(WinoArgs& a, hipStream_t st, const char* what) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino<MB, GATED, SUB, NH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr[dev] = true;
   }
-  a.mtiles = cdiv(a.Cout, MT);
+  a.mtiles = cdiv(a.Cout, NH == 3 ? 2 * MT : MT);
   { static const int wm = getenv("CAGC_WINO_MAP") ? atoi(getenv("CAGC_WINO_MAP")) : 1; a.wg_map = wm; }
   CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
-  hipLaunchKernelGGL((k_wino<MB, GATED, SUB, NH>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(256 * NH), smem, st, a);
+  hipLaunchKernelGGL((k_wino<MB, GATED, SUB, NH>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(wino_threads(NH)), smem, st, a);
   return check_launch(what);
 }
 
@@ -521,10 +536,23 @@ static int wino_dispatch_nh(WinoArgs& a, int M, hipStream_t st, const char* what
     default: return launch_wino_nh<4, GATED, false, NH>(a, st, what);
   }
 }
+// wide shape: whole 64-channel packed tiles in pairs, and enough workgroups left to fill the chip
+template <bool GATED>
+static int wino_dispatch_wide(WinoArgs& a, int M, hipStream_t st, const char* what) {
+  a.tiles_x = a.W / WTW; a.tiles_y = a.H / wino_th(3); a.nblocks = a.B * a.tiles_x * a.tiles_y;
+  a.pmb = 4;
+  return launch_wino_nh<4, GATED, false, 3>(a, st, what);
+}
 template <bool GATED>
 static int wino_dispatch(WinoArgs& a, int M, hipStream_t st, const char* what) {
   const int64_t wgs2 = (int64_t)a.B * (a.W / WTW) * (a.H / wino_th(2)) * cdiv(M, wino_mb(M) * 16);
-  return wino_nh(a.Kp, wgs2) == 2 ? wino_dispatch_nh<GATED, 2>(a, M, st, what) : wino_dispatch_nh<GATED, 1>(a, M, st, what);
+  // measured (scripts/time_wino.py, bs 16): 512 -> 512 @64^2 1.215 -> 1.190 ms, 256 -> 256 @128^2 1.284 -> 1.251 against the 8-wave
+  // shape; 128 -> 128 @256^2 1.362 = the 4-wave shape's 1.364 — so it replaces the 8-wave shape wherever the packed channel tiles pair up
+  static const int wide = getenv("CAGC_WINO_WIDE") ? atoi(getenv("CAGC_WINO_WIDE")) : 1;   // 0: off, 2: wherever legal (tests)
+  const bool wide_ok = wino_mb(M) == 4 && M % 128 == 0;
+  const int nh = wino_nh(a.Kp, wgs2);
+  if (wide && wide_ok && (nh == 2 || wide == 2)) return wino_dispatch_wide<GATED>(a, M, st, what);
+  return nh == 2 ? wino_dispatch_nh<GATED, 2>(a, M, st, what) : wino_dispatch_nh<GATED, 1>(a, M, st, what);
 }
 
 }  // namespace cagc

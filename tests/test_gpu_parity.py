@@ -878,7 +878,7 @@ from cagc import _lib
 from cagc.op import modconv as mc
 torch.manual_seed(0)
 worst = 0.0
-for (B, Cin, Cout, H, W, styled) in [(2, 128, 128, 64, 64, 0), (1, 160, 200, 32, 64, 1), (3, 20, 36, 32, 32, 1), (1, 11, 7, 8, 32, 0),
+for (B, Cin, Cout, H, W, styled) in [(2, 128, 128, 64, 64, 0), (1, 160, 200, 32, 64, 1), (1, 72, 256, 16, 64, 1), (2, 40, 384, 8, 32, 0), (3, 20, 36, 32, 32, 1), (1, 11, 7, 8, 32, 0),
                                      (2, 39, 39, 16, 96, 1)]:
     x = torch.randn(B, Cin, H, W, device="cuda"); w = torch.randn(Cout, Cin, 3, 3, device="cuda")
     s = torch.rand(B, Cin, device="cuda") + 0.5
@@ -897,7 +897,7 @@ for (B, Cin, Cout, H, W, styled) in [(2, 128, 128, 64, 64, 0), (1, 160, 200, 32,
     assert err == err and err < 5e-6, (B, Cin, Cout, H, W, styled, err)
     worst = max(worst, err)
 # gated variant: data gradient of conv3x3 + bias + LeakyReLU in one launch (frozen discriminator layer), with the residual add
-for (B, Cin, Cout, H, W) in [(2, 64, 128, 32, 64), (1, 24, 40, 16, 32)]:
+for (B, Cin, Cout, H, W) in [(2, 64, 128, 32, 64), (1, 24, 40, 16, 32), (1, 256, 72, 16, 64)]:
     w = torch.randn(Cout, Cin, 3, 3, device="cuda"); gout = torch.randn(B, Cout, H, W, device="cuda")
     act = torch.randn(B, Cout, H, W, device="cuda"); res = torch.randn(B, Cin, H, W, device="cuda")
     upb = mc.pack_wino(w, 1.0, True); gx = torch.full((B, Cin, H, W), float("nan"), device="cuda")
@@ -911,15 +911,15 @@ print("WINO_OK %.3e" % worst)
 """
 
 
-@pytest.mark.parametrize("nh", ["1", "2"])
+@pytest.mark.parametrize("nh", ["1", "2", "wide"])
 def test_winograd_both_workgroup_shapes_vs_float64(nh, tmp_path):
-    """The Winograd kernel picks 4-wave (NH 1) or 8-wave (NH 2) workgroups per launch (conv_wino.hip wino_nh); the choice
+    """The Winograd kernel picks 4-wave (NH 1), 8-wave (NH 2) or wide (128-channel, NH 3) workgroups per launch (conv_wino.hip); the choice
     is read once per process, so each shape is forced in its own interpreter: linear and styled epilogues, ragged channel
     counts (K padded to 16, M to the channel tile), against a float64 direct convolution (5e-6 of the output scale)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "wino_shapes.py"
     script.write_text(_WINO_SHAPES_SCRIPT)
-    env = dict(os.environ, CAGC_WINO_NH=nh)
+    env = dict(os.environ, CAGC_WINO_NH="2", CAGC_WINO_WIDE="2") if nh == "wide" else dict(os.environ, CAGC_WINO_NH=nh, CAGC_WINO_WIDE="0")
     r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "WINO_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
