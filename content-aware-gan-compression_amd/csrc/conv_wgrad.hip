@@ -195,7 +195,8 @@ struct Wg2Args {
   float* ws;
   int B, Cin, Cout, H, W;      // x dims
   int Hk, Wk;                  // K grid
-  int NPA, AHg, APitch;        // A planes per channel, plane rows, row pitch
+  int NPA, AHg, APitch;        // A planes per channel STAGED per tile, plane rows, row pitch
+  int NPG;                     // A planes per channel in global memory (4 when `ga` points at one plane of a phase-planar tensor)
   int TH, TW, tiles_x, tiles_y, ntiles, nsplit;
   int ACS, BCS, BH, BWp, QB;   // LDS channel strides; B tile rows / padded row / float4 per row
   int b_y0;                    // B tile row 0 relative to the tile origin (-1)
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)
   const int f_aq = f_apos % QA, f_arow = f_apos / QA;
   const int f_apl = f_arow / TH, f_aiy = f_arow - f_apl * TH;
   const int f_agpos = (f_apl * A.AHg + f_aiy) * A.APitch + 4 * f_aq, f_alpos = f_arow * TW + 4 * f_aq;
-  const int f_acs = A.NPA * A.AHg * A.APitch;
+  const int f_acs = A.NPG * A.AHg * A.APitch;
   const int f_PB = A.BH * A.QB, f_cpb = AFF ? 256 / f_PB : 1;
   const int f_bpos = tid % f_PB, f_bc0 = tid / f_PB;
   const bool f_bon = f_bc0 < f_cpb;
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 <= 110) ? 2 : 1)
       const int gy = y0 + iy, gx = x0 + 4 * aq, o = o0 + oc;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (o < A.Cout && gy < A.Hk && gx + 4 <= A.APitch)
-        v = *reinterpret_cast<const float4*>(A.ga + (((int64_t)(b * A.Cout + o) * A.NPA + pl) * A.AHg + gy) * A.APitch + gx);
+        v = *reinterpret_cast<const float4*>(A.ga + (((int64_t)(b * A.Cout + o) * A.NPG + pl) * A.AHg + gy) * A.APitch + gx);
       if (gx + 3 >= A.Wk) {  // mask the pitch padding / tile overhang
         if (gx + 0 >= A.Wk) v.x = 0.f;
         if (gx + 1 >= A.Wk) v.y = 0.f;
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(256, ((((9 * NB + 3) / 4) * MB * 4 + (4 * MB + 4 * 
   const int a_pl = a_row / TH, a_iy = a_row - a_pl * TH;
   const int a_gpos = (a_pl * A.AHg + a_iy) * A.APitch + 4 * a_q;
   const int a_lpos = a_row * TW + 4 * a_q;
-  const int a_cstride = A.NPA * A.AHg * A.APitch;
+  const int a_cstride = A.NPG * A.AHg * A.APitch;
   // B: PB = BH*QB positions per channel
   const int PB = A.BH * A.QB, cpb = 256 / PB;
   const int b_pos = tid % PB, b_c0 = tid / PB;
@@ -627,11 +628,20 @@ static Wg2Plan wg2_plan(int Cout, int Cin, int up = 0) {
   return best;
 }
 
-static void wgrad2_geometry(Wg2Args& a, Wg2Plan pl, int B, int Cin, int Cout, int H, int W, int ksize, int up) {
+// Transposed-conv mode by planes (CAGC_WGRAD_UP_PLANES=1; MEASURED NEGATIVE, off by default): the four phase planes of the
+// gradient as FOUR launches, each a plain-mode weight gradient of its own taps (plane (ky&1, kx&1): 4 / 2 / 2 / 1 taps) on one
+// staged plane — a quarter of the A tile in LDS, so 128 K-pixels per staged tile instead of 64.  The launches write disjoint
+// tap slabs of one workspace; one reduce.  Results identical, but 154->77 @64^2 328 -> 437 us, 77->39 @128^2 389 -> 772 us, the
+// discriminator's stride-2 weight gradient 3.5 -> 4.7 ms: the B operand is staged four times and the 1- / 2-tap planes leave
+// waves without a (tap, block) pair.
+static bool wgrad_up_by_planes() { static const bool v = getenv("CAGC_WGRAD_UP_PLANES") && atoi(getenv("CAGC_WGRAD_UP_PLANES")) == 1; return v; }
+
+static void wgrad2_geometry(Wg2Args& a, Wg2Plan pl, int B, int Cin, int Cout, int H, int W, int ksize, int up, int plane = -1) {
+  const bool by_plane = up && plane >= 0;
   memset(&a, 0, sizeof(a));
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.Hk = up ? H + 1 : H; a.Wk = up ? W + 1 : W;
-  a.NPA = up ? 4 : 1; a.AHg = a.Hk; a.APitch = up ? ((W + 1 + 3) & ~3) : W;
+  a.NPA = (up && !by_plane) ? 4 : 1; a.NPG = up ? 4 : 1; a.AHg = a.Hk; a.APitch = up ? ((W + 1 + 3) & ~3) : W;
   int tw = 4;
   while (tw < a.Wk && tw < 32) tw <<= 1;
   if (up) {   // odd K grid (W + 1 columns): the multiple of 4 in [16, 44] (or the whole padded row) that wastes least
@@ -647,7 +657,7 @@ static void wgrad2_geometry(Wg2Args& a, Wg2Plan pl, int B, int Cin, int Cout, in
   }
   a.TW = tw;
   static const int up_pix = getenv("CAGC_WGRAD_UP_PIX") ? atoi(getenv("CAGC_WGRAD_UP_PIX")) : 64;   // tuning: K pixels per staged tile, up mode
-  a.TH = (up ? up_pix : 128) / tw;
+  a.TH = ((up && !by_plane) ? up_pix : 128) / tw;
   if (a.TH > 16) a.TH = 16;
   if (a.TH < 1) a.TH = 1;
   a.tiles_x = cdiv(a.Wk, a.TW); a.tiles_y = cdiv(a.Hk, a.TH);
@@ -667,7 +677,7 @@ static void wgrad2_geometry(Wg2Args& a, Wg2Plan pl, int B, int Cin, int Cout, in
     for (int kx = 0; kx < ksize; ++kx) {
       const int t = ky * ksize + kx;
       if (up) {
-        a.a_off[t] = ((ky & 1) * 2 + (kx & 1)) * a.TH * a.TW;
+        a.a_off[t] = by_plane ? 0 : ((ky & 1) * 2 + (kx & 1)) * a.TH * a.TW;
         a.b_off[t] = (1 - ky / 2) * a.BWp + 4 - kx / 2;          // xs[m - ky/2, n - kx/2]; LDS row 0 = m0 - 1
       } else {
         a.a_off[t] = 0;
@@ -684,11 +694,12 @@ static void wgrad2_geometry(Wg2Args& a, Wg2Plan pl, int B, int Cin, int Cout, in
   a.nsplit = ns;
   // pairs sorted by A plane (LDS offset of the tap's A operand), dealt to the 4 waves in consecutive runs
   int order[9], no = 0;
-  for (int t = 0; t < a.ntaps; ++t) order[no++] = t;
+  for (int t = 0; t < a.ntaps; ++t)
+    if (!by_plane || (((t / ksize) & 1) * 2 + ((t % ksize) & 1)) == plane) order[no++] = t;
   for (int i = 1; i < no; ++i)
     for (int j = i; j > 0 && a.a_off[order[j]] < a.a_off[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
   memset(a.pair_tap, -1, sizeof(a.pair_tap));
-  const int npairs = a.ntaps * pl.nb;
+  const int npairs = no * pl.nb;
   int next = 0;
   for (int w = 0; w < 4; ++w) {
     const int cnt = npairs / 4 + (w < npairs % 4 ? 1 : 0);
@@ -798,7 +809,7 @@ extern "C" int64_t cagc_modconv_wgrad_workspace(int B, int Cin, int Cout, int H,
   int64_t n = (int64_t)a.nsplit * a.ntaps * a.Mp32 * a.Np32;
   if (ksize == 3 && W % 4 == 0) {   // the caller's pointers decide v1/v2 at launch: size for the larger
     Wg2Args b;
-    wgrad2_geometry(b, wg2_plan(Cout, Cin, up), B, Cin, Cout, H, W, ksize, up);
+    wgrad2_geometry(b, wg2_plan(Cout, Cin, up), B, Cin, Cout, H, W, ksize, up, (up && wgrad_up_by_planes()) ? 0 : -1);
     const int64_t n2 = (int64_t)b.nsplit * b.ntaps * b.Mp * b.Np;
     if (n2 > n) n = n2;
   }
@@ -824,21 +835,25 @@ extern "C" int cagc_modconv_wgrad_demod(float* gweight, float* workspace, const 
     hipStream_t st2 = as_stream(stream);
     const Wg2Plan pl = wg2_plan(Cout, Cin, up);
     Wg2Args b;
-    wgrad2_geometry(b, pl, B, Cin, Cout, H, W, ksize, up);
-    b.ga = g; b.x = x; b.s = s; b.ws = workspace;
-    int rc2;
+    int rc2 = 0;
     const int key = pl.mb * 10 + pl.nb;
-    if (key == 11) rc2 = launch_wgrad2<1, 1>(b, st2, what);
-    else if (key == 22) rc2 = launch_wgrad2<2, 2>(b, st2, what);
-    else if (key == 42) rc2 = launch_wgrad2<4, 2>(b, st2, what);
-    else if (key == 44) rc2 = launch_wgrad2<4, 4>(b, st2, what);
-    else if (key == 51) rc2 = launch_wgrad2<5, 1>(b, st2, what);
-    else if (key == 31) rc2 = launch_wgrad2<3, 1>(b, st2, what);
-    else if (key == 33) rc2 = launch_wgrad2<3, 3>(b, st2, what);
-    else if (key == 52) rc2 = launch_wgrad2<5, 2>(b, st2, what);
-    else if (key == 25) rc2 = launch_wgrad2<2, 5>(b, st2, what);
-    else if (key == 35) rc2 = launch_wgrad2<3, 5>(b, st2, what);
-    else rc2 = launch_wgrad2<5, 3>(b, st2, what);
+    const bool planes = up && wgrad_up_by_planes();
+    for (int plane = planes ? 0 : -1; plane < (planes ? 4 : 0) && !rc2; ++plane) {
+      wgrad2_geometry(b, pl, B, Cin, Cout, H, W, ksize, up, plane);
+      b.ga = g + (plane > 0 ? (int64_t)plane * b.AHg * b.APitch : 0);     // plane p of [B][Cout][4][Hk][pitch]
+      b.x = x; b.s = s; b.ws = workspace;
+      if (key == 11) rc2 = launch_wgrad2<1, 1>(b, st2, what);
+      else if (key == 22) rc2 = launch_wgrad2<2, 2>(b, st2, what);
+      else if (key == 42) rc2 = launch_wgrad2<4, 2>(b, st2, what);
+      else if (key == 44) rc2 = launch_wgrad2<4, 4>(b, st2, what);
+      else if (key == 51) rc2 = launch_wgrad2<5, 1>(b, st2, what);
+      else if (key == 31) rc2 = launch_wgrad2<3, 1>(b, st2, what);
+      else if (key == 33) rc2 = launch_wgrad2<3, 3>(b, st2, what);
+      else if (key == 52) rc2 = launch_wgrad2<5, 2>(b, st2, what);
+      else if (key == 25) rc2 = launch_wgrad2<2, 5>(b, st2, what);
+      else if (key == 35) rc2 = launch_wgrad2<3, 5>(b, st2, what);
+      else rc2 = launch_wgrad2<5, 3>(b, st2, what);
+    }
     if (rc2) return rc2;
     const int64_t n2 = (int64_t)Cout * Cin * b.ntaps;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n2, 256)), dim3(256), 0, st2, gweight, workspace, Cout, Cin, b.ntaps, b.Mp,
