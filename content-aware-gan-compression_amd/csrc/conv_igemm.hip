@@ -28,6 +28,7 @@
 // workgroups; partial sums are combined with fp32 atomics and the non-linear epilogue runs as a separate pass.
 #include "common.h"
 #include "prep_device.h"
+#include "conv_plan.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -43,56 +44,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #else
 #define CAGC_ABL(bit) false
 #endif
-
-constexpr int CONV_CK = 8;
-constexpr int MAX_TAPS = 9;
-constexpr int MAX_ITEMS = 12;
-constexpr int NBW = 4;                 // pixel blocks (of 16) per wavefront
-constexpr int CONV_NT = 4 * NBW * 16;  // 256 pixels per workgroup tile
-
-struct ConvTap {
-  int lds_off;  // float offset inside one channel's LDS plane
-  int widx;     // tap index into the packed weights
-};
-struct ConvItem {
-  int ntaps, out_plane;
-  int vy_base, vx_base, Hv, Wv;  // region of virtual pixels [vy_base, vy_base+Hv) x [vx_base, vx_base+Wv)
-  int TH, TW, IPB, tiles_x, tiles_y;
-  int IH, IWp, Q4, PS, rows;     // LDS tile: rows per (c,plane,img), padded row (floats), float4 per row,
-                                 // channel-plane stride, rows per chunk (= CK*NPin*IPB*IH)
-  int xoff;                      // LDS column of the tile's first needed input column (alignment slack)
-  int ooy, oox;                  // output pixel = (vy*osy + ooy, vx*osx + oox)
-  int ks;                        // K split of this item: ks workgroups per tile, partial sums combined with atomics
-  // multi-phase items (NPH = 4: all output parities of a stride-2 transposed conv in ONE workgroup, sharing the
-  // staged input tile): taps are ordered by phase, phase p owns ph_ntaps[p] consecutive taps
-  int ph_ntaps[4], ph_out_plane[4], ph_ooy[4], ph_oox[4];
-  int block_end;                 // cumulative workgroup count (exclusive) along grid.x
-  ConvTap taps[MAX_TAPS];
-};
-struct ConvArgs {
-  const float* in;
-  float* out;
-  const float* wp;
-  const float* in_scale;   // [B,Cin] or null
-  const float* out_scale;  // [B,Cout] or null
-  const float* noise;
-  const float* noise_w;
-  const float* bias;
-  const float* aux_x;  // dgrad: x at the output positions, for the gs reduction
-  float* gs;           // [B,Cout-of-this-GEMM], accumulated
-  int B, Cin, Kp, Cout, Mp;
-  int NPin, Hin, Win, Wpitch;  // input planes per channel, valid plane dims, row pitch (floats)
-  int isy, isx;
-  int NPout, Hout, Wout, Wopitch;
-  int osy, osx;                // output stride (2 for the data gradient of a stride-2 conv, else 1)
-  int min_dy, min_dx;
-  int nitems, ksplit, vec;     // vec: 16-byte staging loads are legal (Wpitch % 4 == 0)
-  int dbuf, a_sz, b_sz;        // dbuf: two LDS buffers of a_sz + b_sz floats, ONE barrier per K chunk (launches with <= 4 taps)
-  int nblocks, mtiles;         // pixel-tile workgroups (incl. K splits) and channel tiles; grid = nblocks * mtiles
-  int epi, noise_bstride_on;
-  float alpha, act_scale;
-  ConvItem items[MAX_ITEMS];
-};
 
 // float index of element (tap t, k, m) in the packed weights [t][Kp/4][Mp/16][k % 4][m % 16] (k_pack_weights)
 __device__ __forceinline__ int64_t wp_index(int t, int k, int m, int Kp, int Mp) {
@@ -529,7 +480,7 @@ __global__ __launch_bounds__(256) void k_styled_epilogue(float* __restrict__ out
 __global__ __launch_bounds__(256) void k_pack_weights(float* __restrict__ wp, const float* __restrict__ w, int Cout,
                                                       int Cin, int kk, int Kp, int Mp, float scale, int transpose) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)kk * Kp * Mp) return;
+  if (idx >= igemm_packed_total(kk, Kp, Mp)) return;
   pack_weights_elem(wp, w, idx, Cout, Cin, kk, Kp, Mp, scale, transpose);
 }
 __global__ __launch_bounds__(256) void k_wsq(float* __restrict__ wsq, const float* __restrict__ w, int64_t n, int kk,
@@ -544,14 +495,6 @@ __global__ __launch_bounds__(256) void k_wsq(float* __restrict__ wsq, const floa
 // -------------------------------------------------------------------------------------------------
 static int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static int floor4(int v) { return (v >= 0) ? (v & ~3) : -(((-v) + 3) & ~3); }
-
-struct RawTap { int plane, dy, dx, widx; };
-struct RawItem {
-  int ntaps; const RawTap* taps; int out_plane, vy_base, vx_base, Hv, Wv, ooy = 0, oox = 0;
-  int nph = 1;                                       // 4: fused-phase item, taps ordered by phase
-  int strip = 0;                                     // thin edge strip: own K split (caller zeroes the region)
-  int ph_ntaps[4] = {0, 0, 0, 0}, ph_out_plane[4] = {0, 0, 0, 0}, ph_ooy[4] = {0, 0, 0, 0}, ph_oox[4] = {0, 0, 0, 0};
-};
 
 template <int MB, int NV, bool VEC, bool GS, int NPH = 1>
 static int launch_conv(ConvArgs& a, size_t smem, dim3 grid, hipStream_t st, const char* what) {
@@ -588,6 +531,10 @@ static int launch_conv_nv(ConvArgs& a, int nv, size_t smem, dim3 grid, hipStream
 static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, const char* what, bool zero_out = true,
                     bool allow_split = true, int force_mb = 0) {
   CAGC_REQUIRE(nitems <= MAX_ITEMS, "%s: too many work items", what);
+  if (!force_mb) {   // launches that fill the chip without a K split: the register-direct kernel (conv_rd.hip)
+    const int rd = run_conv_rd(a, raw, nitems, st, what);
+    if (rd != CAGC_RD_DECLINED) return rd;
+  }
   int min_dy = 1 << 20, max_dy = -(1 << 20), min_dx = 1 << 20, max_dx = -(1 << 20);
   for (int p = 0; p < nitems; ++p)
     for (int t = 0; t < raw[p].ntaps; ++t) {
@@ -869,10 +816,10 @@ static bool combined_strips_ok(bool small, bool fused) {
   return on && !small && !fused;
 }
 
-static void base_args(ConvArgs& a, float* out, const float* in, const float* wp, int B, int K, int M) {
+static void base_args(ConvArgs& a, float* out, const float* in, const float* wp, int B, int K, int M, int kk) {
   memset(&a, 0, sizeof(a));
   a.in = in; a.out = out; a.wp = wp;
-  a.B = B; a.Cin = K; a.Kp = round_up(K, 4); a.Cout = M; a.Mp = round_up(M, 16);
+  a.B = B; a.Cin = K; a.Kp = igemm_kp(K); a.Cout = M; a.Mp = round_up(M, 16); a.kk = kk;
   a.NPin = 1; a.NPout = 1; a.isy = 1; a.isx = 1; a.osy = 1; a.osx = 1;
   a.alpha = 0.2f; a.act_scale = 1.f;
 }
@@ -884,7 +831,7 @@ using namespace cagc;
 extern "C" int cagc_phase_pitch(int W) { return round_up(W + 1, 4); }
 
 extern "C" int64_t cagc_modconv_packed_elems(int K, int M, int ksize) {
-  return (int64_t)ksize * ksize * round_up(K, 4) * round_up(M, 16);
+  return igemm_packed_total(ksize * ksize, igemm_kp(K), round_up(M, 16));
 }
 
 extern "C" int cagc_modconv_prep(float* wp_fwd, float* wp_bwd, float* wsq, const float* weight, int Cout, int Cin,
@@ -893,13 +840,13 @@ extern "C" int cagc_modconv_prep(float* wp_fwd, float* wp_bwd, float* wsq, const
   hipStream_t st = as_stream(stream);
   const int kk = ksize * ksize;
   if (wp_fwd) {
-    const int Kp = round_up(Cin, 4), Mp = round_up(Cout, 16);
-    const int64_t total = (int64_t)kk * Kp * Mp;
+    const int Kp = igemm_kp(Cin), Mp = round_up(Cout, 16);
+    const int64_t total = igemm_packed_total(kk, Kp, Mp);
     hipLaunchKernelGGL(k_pack_weights, dim3(cdiv(total, 256)), dim3(256), 0, st, wp_fwd, weight, Cout, Cin, kk, Kp, Mp, scale, 0);
   }
   if (wp_bwd) {
-    const int Kp = round_up(Cout, 4), Mp = round_up(Cin, 16);
-    const int64_t total = (int64_t)kk * Kp * Mp;
+    const int Kp = igemm_kp(Cout), Mp = round_up(Cin, 16);
+    const int64_t total = igemm_packed_total(kk, Kp, Mp);
     hipLaunchKernelGGL(k_pack_weights, dim3(cdiv(total, 256)), dim3(256), 0, st, wp_bwd, weight, Cout, Cin, kk, Kp, Mp, scale, 1);
   }
   if (wsq) {
@@ -923,7 +870,7 @@ extern "C" int cagc_modconv_fwd(float* out, const float* x, const float* wp, con
     CAGC_REQUIRE(!noise || (noise_w && (noise_batch == 1 || noise_batch == B)), "%s: bad noise arguments", what);
   }
   ConvArgs a;
-  base_args(a, out, x, wp, B, Cin, Cout);
+  base_args(a, out, x, wp, B, Cin, Cout, ksize * ksize);
   a.in_scale = s; a.out_scale = out_scale; a.noise = noise; a.noise_w = noise_w; a.bias = bias;
   a.noise_bstride_on = (noise_batch == B) ? 1 : 0;
   a.epi = epi; a.alpha = alpha; a.act_scale = act_scale;
@@ -943,7 +890,7 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   CAGC_REQUIRE(t && x && wp, "%s: null tensor", what);
   CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
   ConvArgs a;
-  base_args(a, t, x, wp, B, Cin, Cout);
+  base_args(a, t, x, wp, B, Cin, Cout, 9);
   a.in_scale = s;
   a.Hin = H; a.Win = W; a.Wpitch = W;
   a.Hout = H + 1; a.Wout = W + 1; a.Wopitch = cagc_phase_pitch(W); a.NPout = 4;
@@ -966,6 +913,15 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   // Two launches: the main regions keep the small staging footprint (NV = 4 -> 2 waves / SIMD); the thin strips
   // need longer halo tiles.  Split-K launches accumulate with atomics, so t is zeroed once up front.
   hipStream_t st = as_stream(stream);
+  {   // register-direct kernel (conv_rd.hip): all four phases over the FULL (H+1) x (W+1) phase grid in one launch — its tiles
+      // are runs of the linearised pixel space, so the odd grid wastes nothing, there are no edge strips, and the rows /
+      // columns the odd phases do not own come out as the zeros the blur expects (every tap there is out of range)
+    RawItem uni[4];
+    for (int ph = 0; ph < 4; ++ph) uni[ph] = RawItem{items[ph].ntaps, taps[ph], ph, 0, 0, H + 1, W + 1};
+    ConvArgs au = a;
+    const int rd = run_conv_rd(au, uni, 4, st, what);
+    if (rd != CAGC_RD_DECLINED) return rd;
+  }
   bool small = (int64_t)B * H * W <= 32768;   // only small layers are ever split over K
   ConvArgs a2 = a;
   int rc;
@@ -1019,7 +975,7 @@ extern "C" int cagc_modconv_dgrad(float* gx, float* gs, const float* gz, const f
   CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
   CAGC_REQUIRE(ksize == 1 || ksize == 3, "%s: ksize %d unsupported", what, ksize);
   ConvArgs a;
-  base_args(a, gx, gz, wp, B, /*K=*/Cout, /*M=*/Cin);
+  base_args(a, gx, gz, wp, B, /*K=*/Cout, /*M=*/Cin, ksize * ksize);
   a.out_scale = s; a.aux_x = x; a.gs = gs;
   a.Hin = H; a.Win = W; a.Wpitch = W; a.Hout = H; a.Wout = W; a.Wopitch = W;
   // gx[i,y,x] = sum_{o,ky,kx} Wsc[o,i,ky,kx] gz[o, y-(ky-r), x-(kx-r)]
@@ -1039,7 +995,7 @@ extern "C" int cagc_modconv_up_dgrad(float* gx, float* gs, const float* gt, cons
   CAGC_REQUIRE(!gs || x, "%s: gs needs x", what);
   CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
   ConvArgs a;
-  base_args(a, gx, gt, wp, B, /*K=*/Cout, /*M=*/Cin);
+  base_args(a, gx, gt, wp, B, /*K=*/Cout, /*M=*/Cin, 9);
   a.out_scale = s; a.aux_x = x; a.gs = gs;
   a.NPin = 4; a.Hin = H + 1; a.Win = W + 1; a.Wpitch = cagc_phase_pitch(W);
   a.Hout = H; a.Wout = W; a.Wopitch = W;
@@ -1068,7 +1024,7 @@ extern "C" int cagc_conv3x3s2_fwd(float* out, const float* x, const float* wp, i
                "%s: bad shape", what);
   const int Ho = (Hin - 3) / 2 + 1, Wo = (Win - 3) / 2 + 1;
   ConvArgs a;
-  base_args(a, out, x, wp, B, Cin, Cout);
+  base_args(a, out, x, wp, B, Cin, Cout, 9);
   a.isy = 2; a.isx = 2;
   a.Hin = Hin; a.Win = Win; a.Wpitch = in_pitch; a.Hout = Ho; a.Wout = Wo; a.Wopitch = Wo;
   RawTap taps[9];
@@ -1087,7 +1043,7 @@ extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_b
                "%s: bad shape", what);
   const int Ho = (Hin - 3) / 2 + 1, Wo = (Win - 3) / 2 + 1;
   ConvArgs a;
-  base_args(a, gx, g, wp_bwd, B, /*K=*/Cout, /*M=*/Cin);
+  base_args(a, gx, g, wp_bwd, B, /*K=*/Cout, /*M=*/Cin, 9);
   a.Hin = Ho; a.Win = Wo; a.Wpitch = Wo;
   a.Hout = Hin; a.Wout = Win; a.Wopitch = out_pitch; a.osy = 2; a.osx = 2;
   // gx[i, 2m+py, 2n+px] = sum_o sum_{jy,jx} W[o,i,py+2jy,px+2jx] g[o, m-jy, n-jx]
@@ -1105,6 +1061,14 @@ extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_b
       if (px == 0) strip_items[ns++] = RawItem{n, taps[ph], 0, 0, Wo, Ho, 1, py, px};                // col X = 2*Wo
     }
   hipStream_t st = as_stream(stream);
+  {   // register-direct kernel: the four output parities over their exact (Ho+1-py) x (Wo+1-px) grids, one launch, no strips
+    RawItem uni[4];
+    for (int ph = 0; ph < 4; ++ph)
+      uni[ph] = RawItem{main_items[ph].ntaps, taps[ph], 0, 0, 0, Ho + 1 - (ph >> 1), Wo + 1 - (ph & 1), ph >> 1, ph & 1};
+    ConvArgs au = a;
+    const int rd = run_conv_rd(au, uni, 4, st, what);
+    if (rd != CAGC_RD_DECLINED) return rd;
+  }
   ConvArgs a2 = a;
   int rc;
   // low-resolution layers: too few pixel tiles to fill the chip and a 64-chunk K loop per workgroup -> split K

@@ -43,13 +43,13 @@ extern "C" int cagc_modconv_prep_all(float* wp_fwd, float* wp_bwd, float* wsq, f
   CAGC_REQUIRE(ksize == 3 || (!up_fwd && !up_bwd), "cagc_modconv_prep_all: Winograd operands need a 3x3 kernel");
   PrepAllArgs a;
   a.w = weight; a.Cout = Cout; a.Cin = Cin; a.kk = ksize * ksize; a.scale = scale;
-  a.Kp_f = round_up(Cin, 4); a.Mp_f = round_up(Cout, 16);
-  a.Kp_b = round_up(Cout, 4); a.Mp_b = round_up(Cin, 16);
+  a.Kp_f = igemm_kp(Cin); a.Mp_f = round_up(Cout, 16);
+  a.Kp_b = igemm_kp(Cout); a.Mp_b = round_up(Cin, 16);
   a.wKp_f = wino_kp(Cin); a.wMB_f = wino_mb(Cout);
   a.wKp_b = wino_kp(Cout); a.wMB_b = wino_mb(Cin);
   a.out[0] = wp_fwd; a.out[1] = wp_bwd; a.out[2] = wsq; a.out[3] = up_fwd; a.out[4] = up_bwd;
-  a.n[0] = wp_fwd ? (int64_t)a.kk * a.Kp_f * a.Mp_f : 0;
-  a.n[1] = wp_bwd ? (int64_t)a.kk * a.Kp_b * a.Mp_b : 0;
+  a.n[0] = wp_fwd ? igemm_packed_total(a.kk, a.Kp_f, a.Mp_f) : 0;
+  a.n[1] = wp_bwd ? igemm_packed_total(a.kk, a.Kp_b, a.Mp_b) : 0;
   a.n[2] = wsq ? (int64_t)Cout * Cin : 0;
   a.n[3] = up_fwd ? (int64_t)cdiv(Cout, a.wMB_f * 16) * a.wKp_f * 64 : 0;
   a.n[4] = up_bwd ? (int64_t)cdiv(Cin, a.wMB_b * 16) * a.wKp_b * 64 : 0;

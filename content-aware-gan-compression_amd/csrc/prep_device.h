@@ -8,17 +8,56 @@ namespace cagc {
 
 // dest = MFMA A-operand order [t][Kp/4][Mp/16][k % 4][m % 16]: the 64 floats of one (tap, K-step, channel block) are the
 // 64 lanes' operands of one v_mfma_f32_16x16x4_f32 (lane = (k % 4) * 16 + m % 16), contiguous in memory
+// A packed operand holds TWO layouts back to back (cagc_modconv_packed_elems counts both):
+//   [0, kk*Kp*Mp)            the LDS-staged kernel's  [t][Kp/4][Mp/16][k % 4][m % 16]   (conv_igemm.hip)
+//   [kk*Kp*Mp, + rd elems)   the register-direct kernel's  [t][Kp/4][tile][lane = (k % 4, m % 16)][PB blocks]   (conv_rd.hip):
+//                            a lane's operands for all channel blocks of its tile are contiguous, so ONE 16-byte buffer
+//                            load feeds 4 blocks' MFMAs.  Tiles hold RB real blocks padded to PB = 4 or 8 (zeros).
+struct RdTile { int rb, pb; };
+__host__ __device__ inline RdTile rd_tile(int nblk) {
+  if (nblk % 8 == 0) return RdTile{8, 8};
+  if (nblk <= 4) return RdTile{nblk, 4};
+  if (nblk % 5 == 0) return RdTile{5, 8};
+  if (nblk % 4 == 0) return RdTile{4, 4};
+  if (nblk % 3 == 0) return RdTile{3, 4};
+  return RdTile{4, 4};                       // partial last tile: zero blocks
+}
+__host__ __device__ inline int64_t rd_packed_elems(int kk, int Kp, int Mp) {
+  const RdTile t = rd_tile(Mp / 16);
+  const int ntile = (Mp / 16 + t.rb - 1) / t.rb;
+  return (int64_t)kk * (Kp / 4) * ntile * 64 * t.pb;
+}
+__host__ __device__ inline int64_t igemm_packed_total(int kk, int Kp, int Mp) { return (int64_t)kk * Kp * Mp + rd_packed_elems(kk, Kp, Mp); }
+
+// idx over [0, igemm_packed_total): both layouts
 __device__ __forceinline__ void pack_weights_elem(float* __restrict__ wp, const float* __restrict__ w, int64_t idx, int Cout,
                                                   int Cin, int kk, int Kp, int Mp, float scale, int transpose) {
-  const int ln = (int)(idx & 63);
-  int64_t q = idx >> 6;
-  const int mblk = (int)(q % (Mp / 16)); q /= (Mp / 16);
-  const int kq = (int)(q % (Kp / 4));
-  const int t = (int)(q / (Kp / 4));
-  const int k = 4 * kq + (ln >> 4), m = 16 * mblk + (ln & 15);
+  const int64_t n_old = (int64_t)kk * Kp * Mp;
+  int t, k, m;
+  bool real = true;
+  if (idx < n_old) {
+    const int ln = (int)(idx & 63);
+    int64_t q = idx >> 6;
+    const int mblk = (int)(q % (Mp / 16)); q /= (Mp / 16);
+    const int kq = (int)(q % (Kp / 4));
+    t = (int)(q / (Kp / 4));
+    k = 4 * kq + (ln >> 4); m = 16 * mblk + (ln & 15);
+  } else {
+    const RdTile T = rd_tile(Mp / 16);
+    const int ntile = (Mp / 16 + T.rb - 1) / T.rb;
+    int64_t q = idx - n_old;
+    const int comp = (int)(q % T.pb); q /= T.pb;
+    const int ln = (int)(q & 63); q >>= 6;
+    const int tile = (int)(q % ntile); q /= ntile;
+    const int kq = (int)(q % (Kp / 4));
+    t = (int)(q / (Kp / 4));
+    const int blk = tile * T.rb + comp;
+    real = comp < T.rb && blk < Mp / 16;
+    k = 4 * kq + (ln >> 4); m = 16 * blk + (ln & 15);
+  }
   const int o = transpose ? k : m, i = transpose ? m : k;
   float v = 0.f;
-  if (o < Cout && i < Cin) v = w[((int64_t)o * Cin + i) * kk + t] * scale;
+  if (real && o < Cout && i < Cin) v = w[((int64_t)o * Cin + i) * kk + t] * scale;
   wp[idx] = v;
 }
 
@@ -65,6 +104,9 @@ __device__ __forceinline__ void wino_pack_elem(float* __restrict__ up, const flo
     dst[(4 * i + 3) * xs] = u3;
   }
 }
+
+// packed K (reduction channels) of the implicit-GEMM weight packing [t][Kp/4][Mp/16][4][16]: whole chunks of 8, zero rows beyond K
+inline int igemm_kp(int K) { return round_up(K, 8); }
 
 // K (reduction channels) of the Winograd packing: two K-chunks of 8 per main-loop iteration of k_wino, zero-padded
 inline int wino_kp(int K) { return round_up(K, 16); }
