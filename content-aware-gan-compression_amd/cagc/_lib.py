@@ -17,6 +17,7 @@ _PROTOS = {
     "cagc_abi_version": [],
     "cagc_last_error": [],
     "cagc_arch": [],
+    "cagc_set_tuning": [ctypes.c_char_p, _i],
     "cagc_fused_bias_act_fwd": [_p, _p, _p, _i64, _i64, _i64, _f, _f, _p],
     "cagc_fused_bias_act_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _p],
     "cagc_fused_bias_act_bwd2": [_p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _p],

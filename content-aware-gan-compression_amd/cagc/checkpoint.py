@@ -73,7 +73,11 @@ def load_checkpoint(path, size=256, latent=512, n_mlp=8, channel_multiplier=2, d
 
 
 def restore_optimizers(ckpt, g_optim=None, d_optim=None):
-    if g_optim is not None:
+    """g_optim may be a `GraphedKDStep`: its captured Adam graph holds the state tensors by address, so the saved state is
+    copied into them (`load_optim_state`) instead of replacing them."""
+    if g_optim is not None and hasattr(g_optim, "load_optim_state"):
+        g_optim.load_optim_state(ckpt["g_optim"])
+    elif g_optim is not None:
         g_optim.load_state_dict(ckpt["g_optim"])
     if d_optim is not None:
         d_optim.load_state_dict(ckpt["d_optim"])

@@ -118,7 +118,9 @@ class KDStep:
             teacher_list, mask = run_teacher()
         teacher_img = teacher_list[-1]
         if self.kd_mode == "Output_Only":
-            kd_l1 = self.kd_l1_lambda * mc.masked_l1(fake_img, teacher_img, mask)
+            # content-aware KD off (parsing_net None, no mask supplied; reference train.py:155,516-518): plain L1
+            kd_l1 = self.kd_l1_lambda * (mc.masked_l1(fake_img, teacher_img, mask) if mask is not None
+                                         else torch.mean(torch.abs(teacher_img - fake_img)))
         else:
             # 'Intermediate' (train.py:165-169): L1 over EVERY resolution's RGB output.  As in the reference the lists hold
             # the un-masked images — its masked copies only feed the Output_Only and LPIPS terms.
@@ -357,7 +359,29 @@ class GraphedKDStep(KDStep):
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
             self.flat_grad.div_(self.world)
         self.graph_opt.replay()
+        # the replayed Adam rewrites the weights without bumping Tensor._version: frozen uses of this student between
+        # replays (TrainIteration.d_step, an eval after requires_grad_(False)) must not see stale packed weights
+        M.invalidate_caches(self.student)
         return {"g": self.losses[0], "kd_l1_loss": self.losses[1]}
+
+    def load_optim_state(self, state_dict):
+        """Resume: copy a saved Adam state (`optim.state_dict()`, e.g. checkpoint['g_optim']) INTO the tensors the captured
+        optimiser graph holds.  `optim.load_state_dict` after capture would swap those tensors for new ones and the graph
+        would keep updating the old ones — unsupported; use this (or construct after loading and re-capture)."""
+        saved = state_dict["state"]
+        ids = [i for g in state_dict["param_groups"] for i in g["params"]]
+        params = [p for g in self.optim.param_groups for p in g["params"]]
+        assert len(ids) == len(params), "optimizer state does not match this student's parameters"
+        with torch.no_grad():
+            for i, p in zip(ids, params):
+                if i not in saved:
+                    continue
+                live = self.optim.state[p]
+                for k, v in saved[i].items():
+                    if torch.is_tensor(v):
+                        assert k in live and live[k].shape == v.shape, f"optimizer state '{k}' mismatch"
+                        live[k].copy_(v.to(live[k].device, live[k].dtype))
+        M.invalidate_caches(self.student)
 
     def sample_and_step(self, batch=None, mask=None, rng=random, generator=None):
         mix = self.mixing > 0 and rng.random() < self.mixing

@@ -464,6 +464,10 @@ class Generator(nn.Module):
         if not (mc.use_hip(latent) and latent.dtype == torch.float32 and latent.dim() == 3):
             return None
         bank = getattr(self, "_mod_bank", None)
+        # a shallow copy of the module (nn.DataParallel's replicate, copy.copy) inherits the bank through __dict__ while its
+        # modulation layers are other objects, possibly on another device: such a bank is rebuilt for THIS module
+        if bank and (bank.lins[0] is not self.conv1.conv.modulation or bank.lins[0].weight.device != latent.device):
+            bank = None
         if bank is None:
             layers = [(self.conv1.conv.modulation, 0), (self.to_rgb1.conv.modulation, 1)]
             i = 1

@@ -533,7 +533,16 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   CAGC_REQUIRE(nitems <= MAX_ITEMS, "%s: too many work items", what);
   if (!force_mb) {   // launches that fill the chip without a K split: the register-direct kernel (conv_rd.hip)
     const int rd = run_conv_rd(a, raw, nitems, st, what);
-    if (rd != CAGC_RD_DECLINED) return rd;
+    if (rd != CAGC_RD_DECLINED) {
+      if (rd == CAGC_OK && a.ksplit > 1 && a.epi == CAGC_EPI_STYLED) {   // split K: the non-linear epilogue as its own pass
+        const int HW = a.Hout * a.Wout;
+        const int64_t total = (int64_t)a.B * a.Cout * HW;
+        hipLaunchKernelGGL(k_styled_epilogue, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, a.out, a.out_scale, a.noise,
+                           a.noise_bstride_on, a.noise_w, a.bias, a.Cout, HW, total, a.alpha, a.act_scale);
+        return check_launch(what);
+      }
+      return rd;
+    }
   }
   int min_dy = 1 << 20, max_dy = -(1 << 20), min_dx = 1 << 20, max_dx = -(1 << 20);
   for (int p = 0; p < nitems; ++p)

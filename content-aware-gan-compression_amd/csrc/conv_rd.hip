@@ -35,6 +35,7 @@ struct RdItem {
   int tiles_x, tiles_y;
   int ooy, oox;
   int block_end;
+  int ks;                        // K split: ks workgroups per tile take K slices and combine with fp32 atomics (output pre-zeroed)
   int lin;                       // 1: tiles are runs of 256 consecutive pixels of the linearised (image, vy, vx) space (odd regions:
                                  // the (H+1) x (W+1) phase grids of the transposed convs — no edge strips, no wasted tiles)
   RdTap taps[MAX_TAPS];
@@ -52,7 +53,9 @@ struct RdArgs {
   float* gs;                     // [B, Cout-of-this-GEMM], accumulated (one atomic per workgroup and channel)
   int B, Cin, KQ, Cout, MBLK;    // KQ = Kp/4 K-steps (even), MBLK = Mp/16 channel blocks
   int a_tile_bytes, a_kq_bytes, a_tap_bytes;   // strides of the register-direct weight layout [t][KQ][tile][64 lanes][PB]
-  int a_lane_bytes, a_split;     // bytes per lane (PB*4); workgroup tiles per packed tile (2: 4-block workgroups on 8-block tiles)
+  int a_lane_bytes, a_split;     // bytes per lane (PB*4); workgroup tiles per packed tile (8-block tiles run as 2 x 4 / 4 x 2 blocks)
+  int kw;                        // waves of a workgroup that split K among themselves (1, 2, 4): the workgroup covers 256 / kw
+                                 // pixels and its kw partial sums meet in LDS — more workgroups for small layers, no atomics
   int NPin, Hin, Win, Wpitch, isy, isx;
   int NPout, Hout, Wout, Wopitch, osy, osx;
   int nitems, nblocks, mtiles;
@@ -76,7 +79,8 @@ constexpr unsigned RD_OOR = 0x80000000u;
 template <int MB, int NT, bool PAD, bool SCALE>
 __device__ __forceinline__ void rd_main(const RdArgs& A, const RdItem& I, f32x4 (&acc)[MB][NBW], const unsigned (&pbase)[NBW],
                                         const int (&piy)[NBW], const int (&pix)[NBW], const bool (&pok)[NBW],
-                                        const unsigned (&sbase)[NBW], const int b0, const int mtile, const int lane) {
+                                        const unsigned (&sbase)[NBW], const int b0, const int mtile, const int lane,
+                                        const int kq_lo, const int kq_hi) {
   const int cs = A.NPin * A.Hin * A.Wpitch;     // channel stride (floats)
   unsigned voff[NBW][PAD ? NT : 1];
   int soff[NT], aoff[NT];
@@ -99,8 +103,8 @@ __device__ __forceinline__ void rd_main(const RdArgs& A, const RdItem& I, f32x4 
     for (int j = 0; j < NBW; ++j) voff[j][0] = pok[j] ? pbase[j] : RD_OOR;
   }
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.wp), 0, (int)A.wp_bytes, 0x00020000);
-  constexpr int NA = (MB + 3) / 4;        // 16-byte A loads per group: a lane's operands for 4 channel blocks each
-  const unsigned a_lane = (unsigned)(lane * A.a_lane_bytes + (mtile % A.a_split) * 16 * NA);
+  constexpr int NA = (MB + 3) / 4;        // A loads per group: a lane's operands for up to 4 channel blocks each (4 / 8 / 16 bytes)
+  const unsigned a_lane = (unsigned)(lane * A.a_lane_bytes + (mtile % A.a_split) * MB * 4);
   const int64_t img_elems = (int64_t)A.Cin * cs;
   auto in_rsrc = [&](int kq) {   // descriptor of K-step kq: base = channel 4*kq of image b0, ends with the tensor
     const int64_t left = ((int64_t)(A.B - b0) * A.Cin - 4 * kq) * cs * 4;
@@ -122,7 +126,13 @@ __device__ __forceinline__ void rd_main(const RdArgs& A, const RdItem& I, f32x4 
     const int ao = aoff[t] + kq * A.a_kq_bytes;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      if (!RD_ABL(4)) av[slot][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, a_lane + (unsigned)i * 16u, ao, 0));
+      if (!RD_ABL(4)) {
+        if constexpr (MB == 1) av[slot][i].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, a_lane, ao, 0));
+        else if constexpr (MB == 2) {
+          const float2 v2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rw, a_lane, ao, 0));
+          av[slot][i].x = v2.x; av[slot][i].y = v2.y;
+        } else av[slot][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, a_lane + (unsigned)i * 16u, ao, 0));
+      }
   };
   auto issue_scale = [&](const int ks, const int kq) {
     if constexpr (SCALE) {
@@ -131,14 +141,13 @@ __device__ __forceinline__ void rd_main(const RdArgs& A, const RdItem& I, f32x4 
       for (int j = 0; j < NBW; ++j) sv[ks][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, sbase[j], 0, 0));
     }
   };
-  const int KQ = A.KQ;
-  __amdgpu_buffer_rsrc_t r0 = in_rsrc(0);
-  issue(0, r0, 0, 0);
-  issue_scale(0, 0);
+  __amdgpu_buffer_rsrc_t r0 = in_rsrc(kq_lo);
+  issue(0, r0, kq_lo, 0);
+  issue_scale(0, kq_lo);
   __builtin_amdgcn_sched_barrier(0);
-  for (int kq = 0; kq < KQ; kq += 2) {
+  for (int kq = kq_lo; kq < kq_hi; kq += 2) {
     const __amdgpu_buffer_rsrc_t r1 = in_rsrc(kq + 1);
-    const int kqn = (kq + 2 < KQ) ? kq + 2 : kq;           // last iteration: re-read valid operands instead of branching
+    const int kqn = (kq + 2 < kq_hi) ? kq + 2 : kq;        // last iteration: re-read valid operands instead of branching
     const __amdgpu_buffer_rsrc_t r2 = in_rsrc(kqn);
 #pragma unroll
     for (int idx = 0; idx < 2 * NT; ++idx) {
@@ -189,6 +198,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
   while (item < A.nitems - 1 && pix_id >= A.items[item].block_end) ++item;
   const RdItem& I = A.items[item];
   int bid = pix_id - (item ? A.items[item - 1].block_end : 0);
+  const int ks = I.ks;
+  const int ksi = bid % ks;
+  bid /= ks;
+  // K slice of this workgroup: whole pairs of K-steps (the main loop takes two per iteration) ...
+  const int kper = ((A.KQ + ks - 1) / ks + 1) & ~1;
+  const int wg_lo = ksi * kper;
+  const int wg_hi = (wg_lo + kper < A.KQ) ? wg_lo + kper : A.KQ;
+  // ... and of this wave: kw waves share a pixel group and take K sub-slices (reduced through LDS in the epilogue)
+  const int kw = A.kw, pw = 4 / kw;
+  const int pwi = wave % pw, kwi = wave / pw;
+  const int wper = ((wg_hi - wg_lo + kw - 1) / kw + 1) & ~1;
+  const int kq_lo = wg_lo + kwi * wper;
+  const int kq_hi = (kq_lo + wper < wg_hi) ? kq_lo + wper : wg_hi;
+  const int tile_px = CONV_NT / kw;
   const int twl = I.tw_log, thl = I.th_log;
   const int mblk0 = mtile * MB;
   const int m0 = mblk0 * 16;
@@ -198,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
   const int lin = I.lin;
   const int region = I.Hv * I.Wv;
   if (lin) {
-    b0 = (bid * CONV_NT) / region;                       // image of the tile's first pixel (uniform)
+    b0 = (bid * tile_px) / region;                       // image of the tile's first pixel (uniform)
   } else {
     const int tx_i = bid % I.tiles_x;
     bid /= I.tiles_x;
@@ -213,11 +236,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
   bool pok[NBW];
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
-    const int n = (wave * NBW + j) * 16 + lm;
+    const int n = (pwi * NBW + j) * 16 + lm;
     int img, vy, vx;
     bool ok;
     if (lin) {
-      const int p = bid * CONV_NT + n;
+      const int p = bid * tile_px + n;
       const int bb = p / region;
       const int rem = p - bb * region;
       const int ty = rem / I.Wv;
@@ -242,16 +265,39 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
 #pragma unroll
     for (int j = 0; j < NBW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  switch (I.ntaps) {
-    case 1: rd_main<MB, 1, PAD, SCALE>(A, I, acc, pbase, piy, pix, pok, sbase, b0, mtile, lane); break;
-    case 2: rd_main<MB, 2, PAD, SCALE>(A, I, acc, pbase, piy, pix, pok, sbase, b0, mtile, lane); break;
-    case 4: rd_main<MB, 4, PAD, SCALE>(A, I, acc, pbase, piy, pix, pok, sbase, b0, mtile, lane); break;
-    default: rd_main<MB, 9, PAD, SCALE>(A, I, acc, pbase, piy, pix, pok, sbase, b0, mtile, lane); break;
+  if (kq_lo < kq_hi) switch (I.ntaps) {
+    case 1: rd_main<MB, 1, PAD, SCALE>(A, I, acc, pbase, piy, pix, pok, sbase, b0, mtile, lane, kq_lo, kq_hi); break;
+    case 2: rd_main<MB, 2, PAD, SCALE>(A, I, acc, pbase, piy, pix, pok, sbase, b0, mtile, lane, kq_lo, kq_hi); break;
+    case 4: rd_main<MB, 4, PAD, SCALE>(A, I, acc, pbase, piy, pix, pok, sbase, b0, mtile, lane, kq_lo, kq_hi); break;
+    default: rd_main<MB, 9, PAD, SCALE>(A, I, acc, pbase, piy, pix, pok, sbase, b0, mtile, lane, kq_lo, kq_hi); break;
   }
 
+  // ---- K waves: partial sums through LDS; afterwards wave kwi finishes the N-blocks [kwi*NBW/kw, (kwi+1)*NBW/kw) ----
+  extern __shared__ __attribute__((aligned(16))) float rd_smem[];
+  const int j_lo = kwi * (NBW / kw), j_hi = j_lo + NBW / kw;
+  if (kw > 1) {
+    f32x4* red4 = reinterpret_cast<f32x4*>(rd_smem);     // [wave][MB][NBW][64 lanes]
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) red4[((wave * MB + i) * NBW + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NBW; ++j)
+      if (j >= j_lo && j < j_hi) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          f32x4 sum = red4[((pwi * MB + i) * NBW + j) * 64 + lane];
+          for (int kk = 1; kk < kw; ++kk) sum += red4[(((kk * pw + pwi) * MB + i) * NBW + j) * 64 + lane];
+          acc[i][j] = sum;
+        }
+      }
+  }
   // ---- epilogue: lane holds channels m0 + i*16 + 4g + r (r = 0..3) of pixel n (same contract as k_conv_igemm) ----
   const int HWo = A.Hout * A.Wopitch;
-  const bool styled = (A.epi == CAGC_EPI_STYLED);
+  const bool atomic_out = ks > 1;
+  const bool styled = (A.epi == CAGC_EPI_STYLED) && !atomic_out;    // split K: the non-linear epilogue runs as a separate pass
+  const bool scaled = A.out_scale && !(A.epi == CAGC_EPI_STYLED && atomic_out);
   const float nw = (styled && A.noise) ? A.noise_w[0] : 0.f;
   float gpart[GS ? MB : 1][4];
 #pragma unroll
@@ -260,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
     for (int r = 0; r < 4; ++r) gpart[i][r] = 0.f;
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
+    if (j < j_lo || j >= j_hi) continue;      // uniform per wave
     const int vy = pvy[j], vx = pvx[j], b = pb[j];
     const int pix_o = (vy * A.osy + I.ooy) * A.Wopitch + vx * A.osx + I.oox;
     float nz = 0.f;
@@ -275,18 +322,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
           float v = vals[r];
           const int64_t oidx = ((int64_t)(b * A.Cout + m) * A.NPout + I.out_plane) * HWo + pix_o;
           if constexpr (GS) gpart[i][r] += v * A.aux_x[oidx];    // dgrad: sum (unscaled dgrad) * x over pixels -> gs[b, m]
-          if (A.out_scale) v *= A.out_scale[b * A.Cout + m];
+          if (scaled) v *= A.out_scale[b * A.Cout + m];
           if (styled) {
             v += nz + A.bias[m];
             v = (v > 0.f ? v : v * A.alpha) * A.act_scale;
           }
-          if (!RD_ABL(1) || v == 12345.678f) A.out[oidx] = v;
+          if (atomic_out) atomicAdd(A.out + oidx, v);
+          else if (!RD_ABL(1) || v == 12345.678f) A.out[oidx] = v;
         }
       }
     }
   }
   if constexpr (GS) {   // whole tile in one image (host guarantees): lanes -> 16-lane groups -> 4 waves (LDS) -> ONE atomic per (workgroup, channel)
     __shared__ float red[4 * MT];
+    if (kw > 1) __syncthreads();
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -304,7 +353,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
 
 template <int MB, bool PAD, bool SCALE, bool GS>
 static int launch_rd3(const RdArgs& a, dim3 grid, hipStream_t st, const char* what) {
-  hipLaunchKernelGGL((k_conv_rd<MB, PAD, SCALE, GS>), grid, dim3(256), 0, st, a);
+  const size_t smem = a.kw > 1 ? (size_t)4 * MB * NBW * 64 * 16 : 0;
+  if (smem > 32 * 1024) {   // above the default cap (64 KB incl. the gs variant's static buffer): raise it to what this launch needs
+    static size_t granted[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && granted[dev] < smem) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rd<MB, PAD, SCALE, GS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: cannot reserve %zu B of LDS", what, smem);
+        return CAGC_ERR_LAUNCH;
+      }
+      granted[dev] = smem;
+    }
+  }
+  hipLaunchKernelGGL((k_conv_rd<MB, PAD, SCALE, GS>), grid, dim3(256), smem, st, a);
   return check_launch(what);
 }
 template <int MB>
@@ -318,12 +381,24 @@ static int launch_rd(const RdArgs& a, bool pad, dim3 grid, hipStream_t st, const
   return sc ? launch_rd3<MB, false, true, false>(a, grid, st, what) : launch_rd3<MB, false, false, false>(a, grid, st, what);
 }
 
+// Launch-shape tunables of the register-direct kernel: defaults, overridden by the environment (read once) or by
+// cagc_set_tuning() — a test / tuning hook, not part of the data path's contract (process-wide, not synchronised).
+struct RdTuning {
+  int mode, min_wgs, force_mb, force_kw, split_on, atomic_below, split_target;
+};
+static int env_or(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static RdTuning& rd_tuning() {
+  static RdTuning t = {env_or("CAGC_RD", 1), env_or("CAGC_RD_MIN_WGS", 320), env_or("CAGC_RD_MB", 0), env_or("CAGC_RD_KW", 0),
+                       env_or("CAGC_RD_SPLIT", 1), env_or("CAGC_RD_ATOMIC_BELOW", 160), env_or("CAGC_RD_SPLIT_WGS", 320)};
+  return t;
+}
+
 static int ilog2(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
 static int pow2ceil_rd(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, const char* what) {
-  static const int mode = getenv("CAGC_RD") ? atoi(getenv("CAGC_RD")) : 1;   // 0: off
-  if (!mode) return CAGC_RD_DECLINED;
+  const RdTuning& tune = rd_tuning();
+  if (!tune.mode) return CAGC_RD_DECLINED;
   if (nitems > MAX_ITEMS) return CAGC_RD_DECLINED;
   for (int p = 0; p < nitems; ++p) {
     if (raw[p].nph != 1) return CAGC_RD_DECLINED;
@@ -357,56 +432,110 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
   r.a_tap_bytes = (a.Kp / 4) * r.a_kq_bytes;
   r.a_split = 1;
   bool pad = a.gs != nullptr;      // the gs variant is instantiated for the padded form only
-  int blocks = 0;
+  int tiles2d[MAX_ITEMS];
+  bool all_one_image[3] = {true, true, true};   // kw = 1, 2, 4: every tile of every item lies inside one image (gs reduction)
   for (int p = 0; p < nitems; ++p) {
     const RawItem& R = raw[p];
     RdItem& I = r.items[p];
     I.ntaps = R.ntaps; I.out_plane = R.out_plane; I.vy_base = R.vy_base; I.vx_base = R.vx_base; I.Hv = R.Hv; I.Wv = R.Wv;
-    I.ooy = R.ooy; I.oox = R.oox;
+    I.ooy = R.ooy; I.oox = R.oox; I.ks = 1;
     int tw = pow2ceil_rd(R.Wv); if (tw > 32) tw = 32;
     int th = pow2ceil_rd(R.Hv); if (th > CONV_NT / tw) th = CONV_NT / tw;
-    int ipb = CONV_NT / (tw * th);
+    const int ipb = CONV_NT / (tw * th);
     // regions the 2-D tiles do not cover exactly (the odd phase grids of the transposed convs, thin strips, images smaller
-    // than a tile that do not pack evenly): runs of 256 pixels of the linearised (image, y, x) space
+    // than a tile that do not pack evenly): runs of pixels of the linearised (image, y, x) space
     const bool exact = (R.Wv % tw == 0) && (R.Hv % th == 0) && (a.B % ipb == 0);
     I.lin = exact ? 0 : 1;
-    if (a.gs && (I.lin || ipb != 1)) return CAGC_RD_DECLINED;     // the fused gs reduction wants the whole tile in one image
     I.tw_log = ilog2(tw); I.th_log = ilog2(th);
     I.tiles_x = cdiv(R.Wv, tw); I.tiles_y = cdiv(R.Hv, th);
-    const int span = I.lin ? cdiv(CONV_NT, R.Hv * R.Wv) + 1 : ipb;   // images one tile can touch
+    tiles2d[p] = cdiv(a.B, ipb) * I.tiles_x * I.tiles_y;
+    const int region = R.Hv * R.Wv;
+    if (!(exact && ipb == 1)) all_one_image[0] = false;
+    if (region % 128 != 0) all_one_image[1] = false;
+    if (region % 64 != 0) all_one_image[2] = false;
+    const int span = cdiv(CONV_NT, region) + 1;                        // images one tile can touch
     if ((int64_t)span * a.Cin * cs * 4 > 0x7fffffff) return CAGC_RD_DECLINED;
-    if ((int64_t)a.B * R.Hv * R.Wv + CONV_NT >= (1ll << 31)) return CAGC_RD_DECLINED;
+    if ((int64_t)a.B * region + CONV_NT >= (1ll << 31)) return CAGC_RD_DECLINED;
     for (int t = 0; t < R.ntaps; ++t) {
-      const RawTap& T = R.taps[t];
-      I.taps[t].goff = T.plane * a.Hin * a.Wpitch + T.dy * a.Wpitch + T.dx;
-      I.taps[t].widx = T.widx; I.taps[t].dy = T.dy; I.taps[t].dx = T.dx;
+      const RawTap& Tp = R.taps[t];
+      I.taps[t].goff = Tp.plane * a.Hin * a.Wpitch + Tp.dy * a.Wpitch + Tp.dx;
+      I.taps[t].widx = Tp.widx; I.taps[t].dy = Tp.dy; I.taps[t].dx = Tp.dx;
       // does any pixel of the region reach outside the plane with this tap?
-      const int y_lo = R.vy_base * a.isy + T.dy, y_hi = (R.vy_base + R.Hv - 1) * a.isy + T.dy;
-      const int x_lo = R.vx_base * a.isx + T.dx, x_hi = (R.vx_base + R.Wv - 1) * a.isx + T.dx;
+      const int y_lo = R.vy_base * a.isy + Tp.dy, y_hi = (R.vy_base + R.Hv - 1) * a.isy + Tp.dy;
+      const int x_lo = R.vx_base * a.isx + Tp.dx, x_hi = (R.vx_base + R.Wv - 1) * a.isx + Tp.dx;
       if (y_lo < 0 || x_lo < 0 || y_hi >= a.Hin || x_hi >= a.Win || I.taps[t].goff < 0) pad = true;
     }
-    blocks += I.lin ? cdiv((int64_t)a.B * R.Hv * R.Wv, CONV_NT) : cdiv(a.B, ipb) * I.tiles_x * I.tiles_y;
-    I.block_end = blocks;
   }
-  // channel blocks per workgroup: whole tiles only (the A loads of a partial tile would run past the packed row), and
-  // enough workgroups for two per CU where the layer allows it
-  static const int min_wgs = getenv("CAGC_RD_MIN_WGS") ? atoi(getenv("CAGC_RD_MIN_WGS")) : 384;
-  static const int force_mb = getenv("CAGC_RD_MB") ? atoi(getenv("CAGC_RD_MB")) : 0;
-  int mb = T.rb;
-  // 8-block tiles that leave the chip under-filled run as two 4-block workgroups per packed tile
-  if (mb == 8 && (int64_t)blocks * ntile_p < 512 && (int64_t)blocks * ntile_p * 2 >= min_wgs) { mb = 4; r.a_split = 2; }
-  if (force_mb == 4 && T.rb == 8) { mb = 4; r.a_split = 2; }
-  if (mb < 3 && mb < nblk) return CAGC_RD_DECLINED;      // odd channel counts whose only whole tiles are tiny: keep the LDS kernel
+  // ---- shape of the launch: fill the chip without atomics as far as possible --------------------------------------------
+  //   kw  waves of a workgroup that split K (workgroup tile 256 / kw pixels; partial sums meet in LDS)
+  //   mb  channel blocks per workgroup: the packed tile, or a half / quarter of a power-of-two tile
+  //   ks  K split ACROSS workgroups (fp32 atomics on a pre-zeroed output): only when the two above do not suffice
+  const int min_wgs = tune.min_wgs, force_mb = tune.force_mb, force_kw = tune.force_kw, split_on = tune.split_on;
+  auto tiles_for = [&](int kw) {
+    int64_t t = 0;
+    for (int p = 0; p < nitems; ++p)
+      t += (r.items[p].lin || kw > 1) ? cdiv((int64_t)a.B * raw[p].Hv * raw[p].Wv, CONV_NT / kw) : tiles2d[p];
+    return t;
+  };
+  auto kw_ok = [&](int kw) { return !a.gs || all_one_image[kw == 1 ? 0 : (kw == 2 ? 1 : 2)]; };
+  if (!kw_ok(1)) return CAGC_RD_DECLINED;
+  int kw = 1, mb = T.rb;
+  const bool pow2_tile = (T.rb == 8 || T.rb == 4 || T.rb == 2);
+  auto wgs = [&]() { return tiles_for(kw) * ntile_p * (T.rb / mb); };
+  if (mb == 8 && wgs() < 512) mb = 4;
+  while (wgs() < min_wgs) {
+    if (kw < 4 && kw_ok(kw * 2) && mb <= 5) kw *= 2;
+    else if (pow2_tile && mb > 2) mb /= 2;
+    else break;
+  }
+  if (force_mb && pow2_tile && T.rb % force_mb == 0) mb = force_mb;
+  if (force_kw && kw_ok(force_kw) && (mb <= 5 || force_kw == 1)) kw = force_kw;
+  if (mb < 3 && mb < nblk && !pow2_tile) return CAGC_RD_DECLINED;
+  r.kw = kw;
+  r.a_split = T.rb / mb;
   const int mtiles = ntile_p * r.a_split;
-  // launches that cannot fill the chip keep the split-K path of the LDS-staged kernel
-  if ((int64_t)blocks * mtiles < min_wgs) return CAGC_RD_DECLINED;
+  int blocks = 0;
+  for (int p = 0; p < nitems; ++p) {
+    if (kw > 1) r.items[p].lin = 1;
+    r.items[p].block_end = r.items[p].lin ? cdiv((int64_t)a.B * raw[p].Hv * raw[p].Wv, CONV_NT / kw) : tiles2d[p];   // tiles, for now
+    blocks += r.items[p].block_end;
+  }
+  int ks_max = 1;
+  const int atomic_below = tune.atomic_below;
+  if ((int64_t)blocks * mtiles < atomic_below) {
+    if (!split_on) return CAGC_RD_DECLINED;
+    // every workgroup gets about the same number of (K-step, tap) groups: an item's split is proportional to its taps
+    int64_t groups = 0;
+    for (int p = 0; p < nitems; ++p) groups += (int64_t)r.items[p].block_end * raw[p].ntaps * r.KQ;
+    groups *= mtiles;
+    const int target = tune.split_target > 0 ? tune.split_target : 320;
+    int64_t per = groups / target;                        // groups per workgroup
+    if (per < 16 * kw) per = 16 * kw;
+    for (int p = 0; p < nitems; ++p) {
+      int k = (int)(((int64_t)raw[p].ntaps * r.KQ + per / 2) / per);
+      if (k > r.KQ / (2 * kw)) k = r.KQ / (2 * kw);
+      if (k < 1) k = 1;
+      const int kper = (cdiv(r.KQ, k) + 1) & ~1;
+      k = cdiv(r.KQ, kper);                               // no empty slices
+      r.items[p].ks = k;
+      ks_max = k > ks_max ? k : ks_max;
+    }
+  }
+  blocks = 0;
+  for (int p = 0; p < nitems; ++p) { blocks += r.items[p].block_end * r.items[p].ks; r.items[p].block_end = blocks; }
+  a.ksplit = ks_max;
+  if (ks_max > 1) {
+    const size_t bytes = sizeof(float) * (size_t)a.B * a.Cout * a.NPout * a.Hout * a.Wopitch;
+    const int zrc = zero_fill(a.out, bytes, st);
+    if (zrc) return zrc;
+  }
   r.nblocks = blocks; r.mtiles = mtiles;
   if ((int64_t)blocks * mtiles >= (1ll << 31)) return CAGC_RD_DECLINED;
   dim3 grid((unsigned)(blocks * mtiles), 1, 1);
   {
     static const bool dbg = getenv("CAGC_CONV_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[cagc] %s: RD items %d taps %d mb %d pad %d scale %d gs %d lin %d grid %d K %d M %d\n", what, nitems, raw[0].ntaps, mb,
-                     (int)pad, (int)(a.in_scale != nullptr), (int)(a.gs != nullptr), r.items[0].lin, blocks * mtiles, a.Kp, a.Mp);
+    if (dbg) fprintf(stderr, "[cagc] %s: RD items %d taps %d mb %d kw %d ks %d pad %d scale %d gs %d lin %d grid %d K %d M %d\n", what, nitems, raw[0].ntaps, mb,
+                     kw, ks_max, (int)pad, (int)(a.in_scale != nullptr), (int)(a.gs != nullptr), r.items[0].lin, blocks * mtiles, a.Kp, a.Mp);
   }
   switch (mb) {
     case 1: return launch_rd<1>(r, pad, grid, st, what);
@@ -419,3 +548,17 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
 }
 
 }  // namespace cagc
+
+extern "C" int cagc_set_tuning(const char* key, int value) {
+  CAGC_REQUIRE(key, "cagc_set_tuning: null key");
+  cagc::RdTuning& t = cagc::rd_tuning();
+  if (!strcmp(key, "rd")) t.mode = value;
+  else if (!strcmp(key, "rd_min_wgs")) t.min_wgs = value;
+  else if (!strcmp(key, "rd_mb")) t.force_mb = value;
+  else if (!strcmp(key, "rd_kw")) t.force_kw = value;
+  else if (!strcmp(key, "rd_split")) t.split_on = value;
+  else if (!strcmp(key, "rd_atomic_below")) t.atomic_below = value;
+  else if (!strcmp(key, "rd_split_wgs")) t.split_target = value;
+  else { cagc::set_error("cagc_set_tuning: unknown key '%s'", key); return CAGC_ERR_INVALID; }
+  return CAGC_OK;
+}
