@@ -170,7 +170,7 @@ class KernelTimer:
         return agg
 
 
-def cpu_baseline(steps=3, batch=16, budget_s=120.0):
+def cpu_baseline(steps=3, batch=16, budget_s=120.0, threads=None):
     """The oracle (port of the reference CPU path: grouped convs on per-sample modulated weights, composed
     upfirdn2d / leaky_relu) timed on the host cores, SURVEY §8-d: one warm-up step (batch 2: oneDNN primitive creation)
     then up to `steps` timed KD generator steps at batch `batch` of the same 256 px workload; the median is reported.
@@ -180,7 +180,7 @@ def cpu_baseline(steps=3, batch=16, budget_s=120.0):
     from oracle import ref_kd
     # intra-op threads: all cores up to 32 (the grouped-conv CPU kernels stop scaling — and oversubscribe badly —
     # beyond that; measured 5x slower with 256 threads on a 2x64-core host)
-    cores = min(os.cpu_count() or 1, 32)
+    cores = threads if threads else min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     student, teacher, disc = kd.build_synthetic_workload(SIZE, "cpu", seed=0)
     ssd = {k: v.detach() for k, v in student.state_dict().items()}
@@ -255,15 +255,24 @@ def main():
     ap.add_argument("--full-iteration", action="store_true", help="(default at N=1; kept for compatibility)")
     ap.add_argument("--no-full-iteration", action="store_true",
                     help="skip the secondary leg that times 16 whole training iterations (D step, R1, path-length, EMA)")
-    ap.add_argument("--sweep", type=int, default=3, help="time N bs-64 batches of the prune.py saliency sweep (config 5); 0 = skip")
+    ap.add_argument("--sweep", type=int, default=10, help="time N bs-64 batches of the prune.py saliency sweep (config 5); 0 = skip")
+    ap.add_argument("--size", type=int, default=256, choices=(256, 1024),
+                    help="256: BASELINE configs[1] (the headline).  1024: configs[3] — the 1024 px pruned student [..,20,20,10,10] + "
+                         "full 1024 px teacher + Discriminator(1024), global batch 16 over 4 GPUs; at --gpus 1 ONE rank's share "
+                         "(per-GPU batch 4) is timed, the secondary legs are skipped")
+    ap.add_argument("--local-batch", type=int, default=0, help="per-GPU batch override (default: global batch 16 / world size; "
+                                                               "--size 1024 at --gpus 1: 4)")
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong-scaling proxy table (per-GPU batch 8/4/2 on this GPU)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed bs-16 steps of the CPU baseline (SURVEY 8-d: 3)")
     ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline with os.cpu_count() threads (~5 min)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches + DDP instead of HIP-graph replay")
     ap.add_argument("--graph", action="store_true", help="force HIP-graph replay (default: calibrate — a few untimed steps "
                                                          "of each mode on copies of the models, keep the faster)")
     args = ap.parse_args()
 
+    global SIZE
+    SIZE = args.size
     from cagc import _lib, distributed as cd, kd
     rank, world, local = cd.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -277,6 +286,15 @@ def main():
     bs = GLOBAL_BATCH // world
     if os.environ.get("CAGC_BENCH_LOCAL_BS"):   # experiment knob: per-GPU batch of an N-GPU run, on one GPU (value then = bs*K/t)
         bs = int(os.environ["CAGC_BENCH_LOCAL_BS"])
+    share = None
+    if args.local_batch:
+        bs = args.local_batch
+    elif SIZE == 1024 and world == 1:
+        bs = 4                 # configs[3] is a 4-GPU run of global batch 16: one rank's share
+    if bs * world != GLOBAL_BATCH:
+        share = f"one GPU at per-GPU batch {bs} = the share of one rank of a {GLOBAL_BATCH // bs}-GPU run of global batch {GLOBAL_BATCH}"
+    if SIZE != 256:            # the secondary legs belong to the 256 px headline configuration
+        args.no_full_iteration, args.no_proxy, args.sweep, args.no_cpu_baseline = True, True, 0, True
 
     student, teacher, disc = kd.build_synthetic_workload(SIZE, dev, seed=0)
     n_params = sum(p.numel() for p in student.parameters())
@@ -353,7 +371,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     ms = dt / args.steps * 1e3
-    value = GLOBAL_BATCH * args.steps / dt
+    value = bs * world * args.steps / dt
 
     roof = None
     if not args.no_roofline:
@@ -429,9 +447,22 @@ def main():
             it.iteration(i, real, mask, rng, None)
         torch.cuda.synchronize()
         dtf = time.perf_counter() - t1
+        # the eight phases of the reference's profiler (Miscellaneous/train_time_profiler.py:186-314), on a second,
+        # untimed-for-`value` period of 16 iterations with HIP events at the same boundaries; one stream (the teacher's
+        # side stream off) so that a phase's time is its own kernels'
+        overlap_saved, kd.OVERLAP_TEACHER = kd.OVERLAP_TEACHER, False
+        it.phase_timer = kd.PhaseTimer()
+        for i in range(16):
+            it.iteration(i, real, mask, rng, None)
+        phases = it.phase_timer.summary()
+        it.phase_timer = None
+        kd.OVERLAP_TEACHER = overlap_saved
         full = {"value": round(16 * bs / dtf, 2), "unit": "images/s", "ms_per_iteration": round(dtf / 16 * 1e3, 2),
                 "what": "D step + G/KD step + R1/16 + path-length/4 + EMA, bs16, eager launches (train.py:371-398 equivalent); "
-                        "every convolution incl. the second-order passes and D's weight gradients on libcagc (no MIOpen)"}
+                        "every convolution incl. the second-order passes and D's weight gradients on libcagc (no MIOpen)",
+                "phases": phases,
+                "phases_note": "GPU ms per call over 16 iterations (R1 runs in 1, the path-length regulariser in 4 of them); "
+                               "train_G_d_forward = frozen-D forward + teacher forward + KD loss, as the reference brackets it"}
         del it, g_ema
         torch.cuda.empty_cache()
     proxy = None
@@ -480,16 +511,34 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_steps, args.cpu_batch)
+        allc = os.cpu_count() or 1
+        if allc > cpu["cores"]:
+            # SURVEY 8-d names torch.set_num_threads(os.cpu_count()).  Measured once on the GPU box (gpurun_out/bench_r3_d.json,
+            # 2x EPYC 9575F = 256 hardware threads): ONE bs-4 step took 297.7 s = 0.0134 img/s — the grouped-conv CPU kernels
+            # oversubscribe badly beyond ~32 threads — so the default line quotes that measurement and re-times it only on request
+            if args.cpu_all_cores:
+                try:
+                    ac = cpu_baseline(1, 4, 60.0, threads=allc)
+                    cpu["all_cores"] = {"value": ac["value"], "unit": "images/s", "cores": allc, "sample": ac["sample"]}
+                except Exception as e:  # noqa: BLE001
+                    cpu["all_cores"] = {"error": f"{type(e).__name__}: {e}", "cores": allc}
+            else:
+                cpu["all_cores"] = {"value": 0.0134, "unit": "images/s", "cores": 256, "measured": "round 3, gpurun_out/bench_r3_d.json",
+                                    "sample": "1 timed KD generator step at batch 4 after a batch-2 warm-up: 297.7 s (256 threads "
+                                              "oversubscribe the grouped-conv CPU kernels); re-time with --cpu-all-cores (+5 min)"}
 
     if rank == 0:
-        out = {"metric": "KD-retrain images/sec, 256px StyleGAN2 70%-pruned bs16", "value": round(value, 3),
+        shape_txt = "[154x10,77,77,39,39]" if SIZE == 256 else "[154x10,77,77,39,39,20,20,10,10]"
+        cfg_txt = "configs[1]" if SIZE == 256 else "configs[3]"
+        out = {"metric": f"KD-retrain images/sec, {SIZE}px StyleGAN2 70%-pruned bs16", "value": round(value, 3),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 3), "median_ms_per_step": None if median_ms is None else round(median_ms, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "256px StyleGAN2 70%-pruned student [154x10,77,77,39,39] + full teacher KD generator step, "
-                                      "global bs16 (configs[1]); frozen D fwd+dgrad, masked-L1 KD, Adam; LPIPS/BiSeNet off",
-                          "global_batch": GLOBAL_BATCH, "per_gpu_batch": bs, "parallelism": f"dp{world}", "launch_mode": mode, "launch_mode_calibration_ms": calib,
+               "config": {"workload": f"{SIZE}px StyleGAN2 70%-pruned student {shape_txt} + full teacher KD generator step, "
+                                      f"global bs16 ({cfg_txt}); frozen D fwd+dgrad, masked-L1 KD, Adam; LPIPS/BiSeNet off"
+                                      + (f"; {share}" if share else ""),
+                          "global_batch": bs * world, "per_gpu_batch": bs, "parallelism": f"dp{world}", "launch_mode": mode, "launch_mode_calibration_ms": calib,
                           "student_params": n_params},
                "roofline": roof, "cpu_baseline": cpu, "full_iteration": full, "saliency_sweep": sweep,
                "strong_scaling_proxy_1gpu": proxy}

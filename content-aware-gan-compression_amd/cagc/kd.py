@@ -81,6 +81,11 @@ class KDStep:
             kw["fused"] = True
         self.optim = torch.optim.Adam(params, lr=lr * c, betas=(0.0 ** c, 0.99 ** c), **kw)
         self.n_latent = (student.module if hasattr(student, "module") else student).n_latent
+        self.phase_timer = None
+
+    def _mark(self, phase=None):
+        if self.phase_timer is not None:
+            self.phase_timer.mark(phase)
 
     def g_losses(self, zs, inject_index, mask, student_noise=None, teacher_noise=None):
         # The frozen teacher's forward is independent of the student / discriminator chain until the distillation loss:
@@ -105,8 +110,10 @@ class KDStep:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 teacher_list, mask = run_teacher()
+        self._mark()
         fake_list = self.student(zs, return_rgb_list=True, inject_index=inject_index, noise=student_noise)
         fake_img = fake_list[-1]
+        self._mark("train_G_g_forward")
         g_loss = g_nonsaturating_loss(self.disc_frozen(fake_img))
         if overlap:
             main.wait_stream(side)
@@ -143,9 +150,11 @@ class KDStep:
         requires_grad(self.disc, False)
         g_loss, kd_l1, _ = self.g_losses(zs, inject_index, mask, student_noise, teacher_noise)
         total = g_loss + kd_l1
+        self._mark("train_G_d_forward")      # as in the reference's profiler: D forward + teacher forward + the KD loss
         self.optim.zero_grad(set_to_none=True)
         total.backward()
         self.optim.step()
+        self._mark("train_G_g_backward")
         if self.percept_loss is not None:
             lp = self.last_kd_lpips.detach()
             return {"g": g_loss.detach(), "kd_l1_loss": kd_l1.detach() - lp, "kd_lpips_loss": lp}
@@ -178,6 +187,30 @@ def accumulate(model_ema, model, decay=0.999):
     M.invalidate_caches(model_ema)
 
 
+class PhaseTimer:
+    """GPU time of the eight phases the reference's profiler reports (Miscellaneous/train_time_profiler.py:186-314):
+    train_D_{g_forward, d_forward, d_backward}, reg_D, train_G_{g_forward, d_forward, g_backward}, reg_G — HIP events on the
+    launch stream at the same boundaries (the reference brackets them with host clocks and no device sync).  Attach to a
+    KDStep / TrainIteration as `.phase_timer`; `summary()` synchronises once."""
+
+    def __init__(self):
+        self.events = []        # (phase that ENDS here | None for a start mark, event)
+
+    def mark(self, phase=None):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.events.append((phase, ev))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        tot, cnt = {}, {}
+        for (_, e0), (ph, e1) in zip(self.events[:-1], self.events[1:]):
+            if ph is not None:
+                tot[ph] = tot.get(ph, 0.0) + e0.elapsed_time(e1)
+                cnt[ph] = cnt.get(ph, 0) + 1
+        return {k: {"calls": cnt[k], "ms_per_call": round(tot[k] / cnt[k], 3), "ms_total": round(tot[k], 2)} for k in tot}
+
+
 class TrainIteration(KDStep):
     """The rest of one reference training iteration around the KD generator step (reference train.py:371-398):
     D step (:241-262), lazy R1 every `d_reg_every` (:264-278), G+KD step (KDStep.g_step), lazy path-length
@@ -201,19 +234,24 @@ class TrainIteration(KDStep):
     def d_step(self, real_img, zs, inject_index=None, noise=None):
         requires_grad(self.student, False)
         requires_grad(self.disc, True)
+        self._mark()
         with torch.no_grad():      # G is frozen here: nothing of its graph is needed (same values as the reference's :251)
             fake_img = (self.student.module if hasattr(self.student, "module") else self.student)(
                 zs, inject_index=inject_index, noise=noise)
+        self._mark("train_D_g_forward")
         fake_pred = self.disc(fake_img)
         real_pred = self.disc(real_img)
         d_loss = d_logistic_loss(real_pred, fake_pred)
+        self._mark("train_D_d_forward")
         self.d_optim.zero_grad(set_to_none=True)
         d_loss.backward()
         self.d_optim.step()
+        self._mark("train_D_d_backward")
         return {"d": d_loss.detach(), "real_score": real_pred.mean().detach(), "fake_score": fake_pred.mean().detach()}
 
     def d_reg(self, real_img):
         requires_grad(self.disc, True)
+        self._mark()
         real_img = real_img.detach().requires_grad_(True)
         # double backward through D: its fused ops build a differentiable backward under create_graph=True (closed conv
         # family of op/conv_closure.py + the twice-differentiable upfirdn2d / fused-act ops) — all on libcagc
@@ -222,10 +260,12 @@ class TrainIteration(KDStep):
         self.d_optim.zero_grad(set_to_none=True)
         (self.r1 / 2 * r1_loss * self.d_reg_every + 0 * real_pred[0]).backward()
         self.d_optim.step()
+        self._mark("reg_D")
         return r1_loss.detach()
 
     def g_reg(self, zs, inject_index=None, noise=None):
         requires_grad(self.student, True)
+        self._mark()
         fake_img, path_lengths = self.student(zs, PPL_regularize=True, inject_index=inject_index, noise=noise)
         path_mean = self.mean_path_length + 0.01 * (path_lengths.mean() - self.mean_path_length)
         path_loss = (path_lengths - path_mean).pow(2).mean()
@@ -236,6 +276,7 @@ class TrainIteration(KDStep):
             weighted = weighted + 0 * fake_img[0, 0, 0, 0]
         weighted.backward()
         self.optim.step()
+        self._mark("reg_G")
         return path_loss.detach(), path_lengths.detach()
 
     def ema(self):

@@ -105,6 +105,8 @@ class EqualConv2d(nn.Module):
             if cc.supported(input, self.weight, self.stride, self.padding):
                 out = cc.conv2d(input, self.weight, self.scale, self.stride, self.padding)
                 return out if self.bias is None else out + self.bias.view(1, -1, 1, 1)
+            mc.warn_stock_conv_once(f"EqualConv2d(k={self.weight.shape[-1]}, stride={self.stride}, padding={self.padding}, "
+                                    f"dtype={input.dtype})")
         return F.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
 
     def __repr__(self):

@@ -71,6 +71,22 @@ def use_hip(t):
     return t.is_cuda and not composed_active()
 
 
+_stock_conv_warned = set()
+
+
+def warn_stock_conv_once(what):
+    """A GPU tensor is about to take a stock PyTorch convolution (MIOpen) because no hand-written kernel covers the layer
+    pattern / dtype (non-fp32 modulated convs, EqualConv2d shapes outside conv_closure.supported).  Never on the KD step or
+    the training iteration (tests patch F.conv2d to raise there); said out loud ONCE per pattern so that "the HIP path
+    ran" is never silently false.  CAGC_STRICT_HIP=1 turns it into an error."""
+    if os.environ.get("CAGC_STRICT_HIP", "0") == "1":
+        raise RuntimeError(f"cagc: {what} has no HIP kernel and CAGC_STRICT_HIP=1 forbids the stock convolution")
+    if what not in _stock_conv_warned:
+        _stock_conv_warned.add(what)
+        import warnings
+        warnings.warn(f"cagc: {what} runs on the stock PyTorch convolution (MIOpen), not on libcagc_hip", RuntimeWarning, stacklevel=3)
+
+
 # ---------------------------------------------------------------------------------------------------
 # weight packing
 # ---------------------------------------------------------------------------------------------------
@@ -273,19 +289,25 @@ def modconv_composed(x, weight, s, demodulate, upsample, downsample, blur_kernel
             y = upfirdn2d(cc.conv_transpose2d_s2(xs, weight[0].transpose(0, 1), scale), blur_kernel, pad=blur_pad)
         elif downsample and k == 3:
             xb = upfirdn2d(xs, blur_kernel, pad=blur_pad)
-            y = cc.conv2d(xb, weight[0], scale, stride=2, padding=0) if cc.supported(xb, weight[0], 2, 0) \
-                else F.conv2d(xb, w, stride=2, padding=0)
+            if cc.supported(xb, weight[0], 2, 0):
+                y = cc.conv2d(xb, weight[0], scale, stride=2, padding=0)
+            else:          # even blurred size: not the reference's geometry (2*Ho+1)
+                warn_stock_conv_once(f"ModulatedConv2d(downsample) on an even {tuple(xb.shape[2:])} blurred input")
+                y = F.conv2d(xb, w, stride=2, padding=0)
         elif not upsample and not downsample:
             y = cc.conv2d(xs, weight[0], scale, stride=1, padding=k // 2)
         else:
             raise RuntimeError("modulated conv: up/down-sampling needs a 3x3 kernel")
-    elif upsample:
-        y = F.conv_transpose2d(xs, w.transpose(0, 1), stride=2, padding=0)
-        y = upfirdn2d(y, blur_kernel, pad=blur_pad)
-    elif downsample:
-        y = F.conv2d(upfirdn2d(xs, blur_kernel, pad=blur_pad), w, stride=2, padding=0)
     else:
-        y = F.conv2d(xs, w, padding=k // 2)
+        if x.is_cuda:      # GPU tensor outside the kernels' coverage (non-fp32 dtype, k not in {1, 3}): said once, or refused
+            warn_stock_conv_once(f"ModulatedConv2d(k={k}, dtype={x.dtype}, upsample={bool(upsample)}, downsample={bool(downsample)})")
+        if upsample:
+            y = F.conv_transpose2d(xs, w.transpose(0, 1), stride=2, padding=0)
+            y = upfirdn2d(y, blur_kernel, pad=blur_pad)
+        elif downsample:
+            y = F.conv2d(upfirdn2d(xs, blur_kernel, pad=blur_pad), w, stride=2, padding=0)
+        else:
+            y = F.conv2d(xs, w, padding=k // 2)
     if demodulate:
         wsq = w.pow(2).sum([2, 3])
         d = torch.rsqrt((s * s) @ wsq.t() + 1e-8)

@@ -54,6 +54,7 @@ struct RdArgs {
   int B, Cin, KQ, Cout, MBLK;    // KQ = Kp/4 K-steps (even), MBLK = Mp/16 channel blocks
   int a_tile_bytes, a_kq_bytes, a_tap_bytes;   // strides of the register-direct weight layout [t][KQ][tile][64 lanes][PB]
   int a_lane_bytes, a_split;     // bytes per lane (PB*4); workgroup tiles per packed tile (8-block tiles run as 2 x 4 / 4 x 2 blocks)
+  int gs_block;                  // gs reduction per N-block (16-pixel images: every N-block lies in one image) instead of per workgroup
   int kw;                        // waves of a workgroup that split K among themselves (1, 2, 4): the workgroup covers 256 / kw
                                  // pixels and its kw partial sums meet in LDS — more workgroups for small layers, no atomics
   int NPin, Hin, Win, Wpitch, isy, isx;
@@ -333,6 +334,31 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
       }
     }
   }
+  if constexpr (GS) if (A.gs_block) {   // 4x4 images: an N-block is one image; its 16 lanes reduce and add per (image, channel)
+    // (gpart was summed over this wave's N-blocks, which belong to different images: redo it per block)
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      if (j < j_lo || j >= j_hi) continue;
+      const int b = pb[j];
+      const int pix_o = (pvy[j] * A.osy + I.ooy) * A.Wopitch + pvx[j] * A.osx + I.oox;
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const f32x4 a4 = acc[i][j];
+        const float vals[4] = {a4[0], a4[1], a4[2], a4[3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + i * 16 + 4 * g + r;
+          float pr = 0.f;
+          if (pok[j] && m < A.Cout) pr = vals[r] * A.aux_x[((int64_t)(b * A.Cout + m) * A.NPout + I.out_plane) * HWo + pix_o];
+          pr = group16_sum(pr);
+          const int bl = __shfl(b, lane & 48, 64);
+          const bool okl = __shfl(pok[j] ? 1 : 0, lane & 48, 64) != 0;
+          if (lm == 0 && okl && m < A.Cout) atomicAdd(A.gs + (int64_t)bl * A.Cout + m, pr);
+        }
+      }
+    }
+    return;
+  }
   if constexpr (GS) {   // whole tile in one image (host guarantees): lanes -> 16-lane groups -> 4 waves (LDS) -> ONE atomic per (workgroup, channel)
     __shared__ float red[4 * MT];
     if (kw > 1) __syncthreads();
@@ -477,12 +503,16 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
       t += (r.items[p].lin || kw > 1) ? cdiv((int64_t)a.B * raw[p].Hv * raw[p].Wv, CONV_NT / kw) : tiles2d[p];
     return t;
   };
-  auto kw_ok = [&](int kw) { return !a.gs || all_one_image[kw == 1 ? 0 : (kw == 2 ? 1 : 2)]; };
-  if (!kw_ok(1)) return CAGC_RD_DECLINED;
-  int kw = 1, mb = T.rb;
+  bool gs_block = a.gs != nullptr;     // every region is a 16-pixel image: N-blocks never straddle images
+  for (int p = 0; p < nitems; ++p) if (raw[p].Hv * raw[p].Wv != 16) gs_block = false;
+  r.gs_block = gs_block ? 1 : 0;
+  auto kw_ok = [&](int kw) { return !a.gs || gs_block || all_one_image[kw == 1 ? 0 : (kw == 2 ? 1 : 2)]; };
+  int kw = kw_ok(1) ? 1 : (kw_ok(2) ? 2 : (kw_ok(4) ? 4 : 0));   // gs launches: the smallest pixel tile that stays inside one image
+  if (!kw) return CAGC_RD_DECLINED;
+  int mb = T.rb;
   const bool pow2_tile = (T.rb == 8 || T.rb == 4 || T.rb == 2);
   auto wgs = [&]() { return tiles_for(kw) * ntile_p * (T.rb / mb); };
-  if (mb == 8 && wgs() < 512) mb = 4;
+  if (mb == 8 && (wgs() < 512 || kw > 1)) mb = 4;
   while (wgs() < min_wgs) {
     if (kw < 4 && kw_ok(kw * 2) && mb <= 5) kw *= 2;
     else if (pow2_tile && mb > 2) mb /= 2;

@@ -923,3 +923,87 @@ def test_winograd_both_workgroup_shapes_vs_float64(nh, tmp_path):
     env = dict(os.environ, CAGC_WINO_NH="2", CAGC_WINO_WIDE="2") if nh == "wide" else dict(os.environ, CAGC_WINO_NH=nh, CAGC_WINO_WIDE="0")
     r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "WINO_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("shape", [(16, 512), (3, 24), (64, 512), (1, 7)])
+def test_pixelnorm_forward_and_backward_vs_float64(shape):
+    """PixelNorm (reference model.py:14-24) on its own: cagc_pixelnorm_fwd / cagc_pixelnorm_bwd (one wavefront per row,
+    shuffle reduction over the channels) against x * rsqrt(mean_c(x^2) + 1e-8) and its autograd gradient in float64."""
+    torch.manual_seed(21)
+    x = torch.randn(*shape)
+    go = torch.randn(*shape)
+    xr = x.double().requires_grad_(True)
+    yr = xr * torch.rsqrt(torch.mean(xr * xr, dim=1, keepdim=True) + 1e-8)
+    (gr,) = torch.autograd.grad(yr, xr, go.double())
+    xg = cu(x).requires_grad_(True)
+    yg = M.PixelNorm()(xg)
+    assert yg.grad_fn is not None and "PixelNorm" in type(yg.grad_fn).__name__      # the HIP node, not the composed formula
+    (gg,) = torch.autograd.grad(yg, xg, cu(go))
+    assert_close(yg, yr, 2e-6, "pixelnorm out")
+    assert_close(gg, gr, 5e-6, "pixelnorm grad")
+    # degenerate row: all zeros -> 0 * rsqrt(1e-8) = 0, gradient = g * 1e4 (finite)
+    z = torch.zeros(2, shape[1], device=DEV, requires_grad=True)
+    yz = M.PixelNorm()(z)
+    (gz,) = torch.autograd.grad(yz, z, torch.ones_like(yz))
+    assert float(yz.abs().max()) == 0.0 and torch.isfinite(gz).all()
+    assert_close(gz, torch.full_like(gz, 1e4).cpu(), 1e-5, "pixelnorm grad at 0")
+
+
+def test_graphed_kd_step_resumes_from_saved_optimizer_state_and_invalidates_frozen_caches():
+    """Advisor round 2: (1) a GraphedKDStep resumed from a checkpoint's Adam state (checkpoint.restore_optimizers ->
+    load_optim_state copies INTO the tensors the captured graph holds) continues exactly like the uninterrupted run;
+    (2) a frozen (no-grad) use of the student between replays sees the replayed weights, not stale packed ones."""
+    from cagc import checkpoint as ck
+    g = load_npz("kd_step_tiny")
+    meta = load_json("kd_step_tiny_meta")
+
+    def build():
+        student = M.Generator(32, 24, 2, generator_net_shape=meta["student_shape"])
+        student.load_state_dict(sub(g, "student_sd/"), strict=True)
+        teacher = M.Generator(32, 24, 2, generator_net_shape=meta["teacher_shape"])
+        teacher.load_state_dict(sub(g, "teacher_sd/"), strict=True)
+        disc = M.Discriminator(32)
+        disc.load_state_dict(ref_model.regenerate_state_dict(load_json("discriminator32_keys"), g["d_seed"]), strict=True)
+        return student.to(DEV), teacher.to(DEV), disc.to(DEV)
+
+    B = g["mask"].shape[0]
+    steps = meta["steps"]
+
+    def inputs(st, student):
+        p = f"step{st['step']}/"
+        n = student.num_layers
+        return ([cu(g[p + f"z{i}"]) for i in range(st["n_z"])], st["inject_index"], cu(g["mask"]),
+                [cu(g[p + f"student_noise{i}"]) for i in range(n)], [cu(g[p + f"teacher_noise{i}"]) for i in range(n)])
+
+    # uninterrupted: two replays
+    s0, t0, d0 = build()
+    run0 = kd.GraphedKDStep(s0, t0, d0, B, cu(g["mask"]), random_noise=False, latent=24)
+    run0.g_step(*inputs(steps[0], s0))
+    saved = {"g": {k: v.detach().clone() for k, v in s0.state_dict().items()},
+             "g_optim": {"state": {i: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                                   for i, st in run0.optim.state_dict()["state"].items()},
+                         "param_groups": run0.optim.state_dict()["param_groups"]}}
+    # frozen use between replays: eval forward must use the UPDATED weights (caches keyed on _version would be stale)
+    z = cu(g["step0/z0"])
+    with torch.no_grad():
+        kd.requires_grad(s0, False)
+        img_frozen = s0([z], randomize_noise=False)
+        kd.requires_grad(s0, True)
+        img_live = s0([z], randomize_noise=False)
+    assert_close(img_frozen, img_live, 1e-6, "frozen forward after a graph replay")
+    run0.g_step(*inputs(steps[1], s0))
+    # resumed: fresh objects, weights + Adam state restored, one replay
+    s1, t1, d1 = build()
+    s1.load_state_dict(saved["g"])
+    run1 = kd.GraphedKDStep(s1, t1, d1, B, cu(g["mask"]), random_noise=False, latent=24)
+    ck.restore_optimizers(saved, run1)
+    run1.g_step(*inputs(steps[1], s1))
+    torch.cuda.synchronize()
+    p0, p1 = dict(s0.named_parameters()), dict(s1.named_parameters())
+    for k in p0:
+        assert_close(p1[k].detach(), p0[k].detach(), 2e-4, "resumed graph replay param " + k)   # atomics order differs run to run
+    st0 = run0.optim.state_dict()["state"]
+    st1 = run1.optim.state_dict()["state"]
+    for i in st0:
+        assert_close(st1[i]["exp_avg_sq"], st0[i]["exp_avg_sq"], 2e-3, f"resumed Adam second moment {i}")
+        assert float(st1[i]["step"]) == float(st0[i]["step"]) == 2.0

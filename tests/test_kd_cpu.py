@@ -180,3 +180,26 @@ def test_ddp_two_ranks_equal_one_rank_on_concatenated_batch(tmp_path):
     for k, p in student.named_parameters():
         assert_close(got["grads"][k], p.grad, 2e-4 if p.numel() > 1 else 3e-3, "ddp grad " + k)
         assert_close(got["params"][k], p.detach(), 1e-4, "ddp param " + k)
+
+
+def test_kd_step_without_content_mask_is_plain_l1():
+    """Content-aware KD off (reference train.py:155, 516-518: parsing_net None): KD_loss is an un-masked L1 between the
+    teacher's and the student's image.  KDStep(parsing_net=None) with mask=None must compute exactly that (advisor r2)."""
+    g = load_npz("kd_step_tiny")
+    meta = load_json("kd_step_tiny_meta")
+    student, teacher, disc = _kd_objects(g, meta)
+    step = kd.KDStep(student, teacher, disc, latent=24)
+    st = meta["steps"][0]
+    nl = student.num_layers
+    zs = [g[f"step0/z{i}"] for i in range(st["n_z"])]
+    sn = [g[f"step0/student_noise{i}"] for i in range(nl)]
+    tn = [g[f"step0/teacher_noise{i}"] for i in range(nl)]
+    g_loss, kd_l1, fake = step.g_losses(zs, st["inject_index"], None, sn, tn)
+    with torch.no_grad():
+        t_img = teacher(zs, inject_index=st["inject_index"], noise=tn)
+    assert abs(kd_l1.item() - 3 * torch.mean(torch.abs(t_img - fake)).item()) < 1e-6
+    ones = torch.ones(fake.shape[0], 1, fake.shape[2], fake.shape[3])
+    _, kd_ones, _ = step.g_losses(zs, st["inject_index"], ones, sn, tn)
+    assert abs(kd_l1.item() - kd_ones.item()) < 1e-6          # an all-ones mask is the same loss
+    losses = step.g_step(zs, st["inject_index"], None, sn, tn)  # and the whole step runs (backward + Adam)
+    assert torch.isfinite(losses["kd_l1_loss"]) and all(p.grad is not None for p in student.parameters() if p.requires_grad)
