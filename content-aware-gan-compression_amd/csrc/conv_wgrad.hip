@@ -10,6 +10,7 @@
 // end and write one partial slab; k_wgrad_reduce sums the slabs (deterministic, no atomics), applies
 // `scale` and writes the [Cout,Cin,k,k] layout.
 #include "common.h"
+#include "conv_wgrad_rd.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -813,6 +814,10 @@ extern "C" int64_t cagc_modconv_wgrad_workspace(int B, int Cin, int Cout, int H,
     const int64_t n2 = (int64_t)b.nsplit * b.ntaps * b.Mp * b.Np;
     if (n2 > n) n = n2;
   }
+  for (int mod = 0; mod < 2; ++mod) {   // register-direct kernel: its split count depends on whether the launch is modulated
+    WgrPlan P;
+    if (wgrad_rd_plan(P, B, Cin, Cout, H, W, ksize, up, mod != 0) && P.workspace > n) n = P.workspace;
+  }
   return n;
 }
 
@@ -831,6 +836,18 @@ extern "C" int cagc_modconv_wgrad_demod(float* gweight, float* workspace, const 
   CAGC_REQUIRE(gweight && workspace && g && x, "%s: null tensor", what);
   CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad shape", what);
   CAGC_REQUIRE(ksize == 3 || (ksize == 1 && !up), "%s: unsupported ksize/up", what);
+  {   // register-direct kernel (conv_wgrad_rd.hip): operands global/L2 -> VGPR in MFMA order, no LDS, no VALU in the K loop
+    WgrPlan P;
+    if ((((uintptr_t)g | (uintptr_t)x) % 16 == 0) && wgrad_rd_plan(P, B, Cin, Cout, H, W, ksize, up, s != nullptr)) {
+      hipStream_t st3 = as_stream(stream);
+      const int rc3 = run_wgrad_rd(P, workspace, g, x, s, B, Cin, Cout, H, W, up, st3);
+      if (rc3) return rc3;
+      const int64_t n3 = (int64_t)Cout * Cin * P.ntaps;
+      hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(n3, 256)), dim3(256), 0, st3, gweight, workspace, Cout, Cin, P.ntaps, P.Mp, P.Np,
+                         P.nsplit, scale, gwsq, weight, dscale);
+      return check_launch("cagc_modconv_wgrad(reduce)");
+    }
+  }
   if (wgrad_use_v2(W, ksize, g, x)) {
     hipStream_t st2 = as_stream(stream);
     const Wg2Plan pl = wg2_plan(Cout, Cin, up);

@@ -49,7 +49,8 @@ int cagc_abi_version(void);
 const char* cagc_last_error(void);
 /* Test / tuning hook: override a launch-shape heuristic of the convolution kernels (process-wide, not synchronised; results
  * never depend on it beyond fp32 summation order).  Keys: "rd" (0 = LDS-staged kernel only), "rd_min_wgs", "rd_mb", "rd_kw",
- * "rd_split", "rd_atomic_below", "rd_split_wgs" — see csrc/conv_rd.hip.  The same knobs are read from CAGC_RD* at first use. */
+ * "rd_split", "rd_atomic_below", "rd_split_wgs" — see csrc/conv_rd.hip; "wgrad_rd" (0 = LDS-staged weight-gradient kernels
+ * only), "wgrad_rd_wgs" — csrc/conv_wgrad_rd.hip.  The same knobs are read from CAGC_RD* at first use. */
 int cagc_set_tuning(const char* key, int value);
 /* "gfx950" — the only architecture the library is built for. */
 const char* cagc_arch(void);

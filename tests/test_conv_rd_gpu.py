@@ -161,3 +161,77 @@ def test_set_tuning_rejects_unknown_keys():
     lib = _lib.load()
     assert lib.cagc_set_tuning(b"no_such_knob", 1) != 0
     assert b"unknown key" in lib.cagc_last_error()
+
+
+# ---------------------------------------------------------------------------------------------------
+# register-direct weight gradient (csrc/conv_wgrad_rd.hip)
+# ---------------------------------------------------------------------------------------------------
+WG_CONFIGS = {"default": {}, "lds_kernels": {"wgrad_rd": 0}, "few_splits": {"wgrad_rd_wgs": 8}, "many_splits": {"wgrad_rd_wgs": 100000}}
+WG_DEFAULTS = {"wgrad_rd": 1, "wgrad_rd_wgs": 768}
+
+
+@pytest.fixture(params=list(WG_CONFIGS))
+def wg_tuning(request):
+    lib = _lib.load()
+    for k, v in {**WG_DEFAULTS, **WG_CONFIGS[request.param]}.items():
+        assert lib.cagc_set_tuning(k.encode(), v) == 0
+    yield request.param
+    for k, v in WG_DEFAULTS.items():
+        lib.cagc_set_tuning(k.encode(), v)
+
+
+# (B, cin, cout, H, W, up, modulated)
+WGRAD_SHAPES = [(3, 20, 36, 16, 16, 0, True), (2, 77, 39, 32, 32, 0, True), (4, 154, 154, 16, 32, 0, True), (2, 128, 64, 64, 64, 0, False),
+                (1, 512, 512, 32, 32, 0, False), (3, 20, 36, 16, 16, 1, True), (2, 154, 77, 32, 32, 1, True), (2, 77, 39, 64, 64, 1, True),
+                (2, 128, 256, 32, 32, 1, False), (5, 39, 39, 48, 48, 0, True)]
+# 1x1 convolutions (ResBlock skip, from-RGB; reference model.py:726-728, 758): (B, cin, cout, H, W, modulated)
+WGRAD_1X1_SHAPES = [(2, 128, 256, 32, 32, False), (3, 3, 128, 64, 64, False), (2, 77, 39, 16, 48, True), (1, 512, 512, 16, 16, False),
+                    (4, 20, 36, 32, 16, False)]
+
+
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+def test_weight_gradient_plain_and_transposed(shape, wg_tuning):
+    """gW = scale * sum_b s[b,i] sum_p g[b,o,p(+k)] x[b,i,p(+k)]  (cagc_modconv_wgrad; plain and transposed-conv geometry, the
+    latter from the phase-planar gradient) against autograd of the float64 convolution."""
+    B, cin, cout, H, W, up, mod = shape
+    torch.manual_seed(14)
+    scale = 1.0 / math.sqrt(cin * 9)
+    x = torch.randn(B, cin, H, W)
+    s = (torch.rand(B, cin) + 0.5) if mod else None
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    xs = x.double() * (s.double()[:, :, None, None] if mod else 1.0)
+    if up:
+        gfull = torch.randn(B, cout, 2 * H + 1, 2 * W + 1)
+        y = F.conv_transpose2d(xs, (w * scale).transpose(0, 1), stride=2)
+        (gref,) = torch.autograd.grad(y, w, gfull.double())
+        gdev = phase_planar(gfull, H, W).to(DEV)
+    else:
+        gz = torch.randn(B, cout, H, W)
+        y = F.conv2d(xs, w * scale, padding=1)
+        (gref,) = torch.autograd.grad(y, w, gz.double())
+        gdev = gz.to(DEV)
+    xg = x.to(DEV)
+    sg = s.to(DEV) if mod else None
+    n_ws = _lib.query("cagc_modconv_wgrad_workspace", B, cin, cout, H, W, 3, up)
+    ws = torch.empty(n_ws, device=DEV)
+    gw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+    _lib.call("cagc_modconv_wgrad", _lib.ptr(gw), _lib.ptr(ws), _lib.ptr(gdev), _lib.ptr(xg), _lib.ptr(sg), B, cin, cout, H, W, 3, up,
+              float(scale))
+    assert rel(gw, gref) <= 2e-5, ("wgrad", wg_tuning, shape, rel(gw, gref))     # sums over B*H*W pixels of random products
+
+
+@pytest.mark.parametrize("shape", WGRAD_1X1_SHAPES)
+def test_weight_gradient_1x1(shape, wg_tuning):
+    B, cin, cout, H, W, mod = shape
+    torch.manual_seed(15)
+    scale = 1.0 / math.sqrt(cin)
+    x, gz = torch.randn(B, cin, H, W), torch.randn(B, cout, H, W)
+    s = (torch.rand(B, cin) + 0.5) if mod else None
+    xs = x.double() * (s.double()[:, :, None, None] if mod else 1.0)
+    gref = scale * torch.einsum("bohw,bihw->oi", gz.double(), xs)[:, :, None, None]
+    xg, gg = x.to(DEV), gz.to(DEV)
+    sg = s.to(DEV) if mod else None
+    ws = torch.empty(_lib.query("cagc_modconv_wgrad_workspace", B, cin, cout, H, W, 1, 0), device=DEV)
+    gw = torch.full((cout, cin, 1, 1), float("nan"), device=DEV)
+    _lib.call("cagc_modconv_wgrad", _lib.ptr(gw), _lib.ptr(ws), _lib.ptr(gg), _lib.ptr(xg), _lib.ptr(sg), B, cin, cout, H, W, 1, 0, float(scale))
+    assert rel(gw, gref) <= 2e-5, ("wgrad 1x1", wg_tuning, shape, rel(gw, gref))
