@@ -415,7 +415,7 @@ struct RdTuning {
 };
 static int env_or(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static RdTuning& rd_tuning() {
-  static RdTuning t = {env_or("CAGC_RD", 1), env_or("CAGC_RD_MIN_WGS", 320), env_or("CAGC_RD_MB", 0), env_or("CAGC_RD_KW", 0),
+  static RdTuning t = {env_or("CAGC_RD", 1), env_or("CAGC_RD_MIN_WGS", 512), env_or("CAGC_RD_MB", 0), env_or("CAGC_RD_KW", 0),
                        env_or("CAGC_RD_SPLIT", 1), env_or("CAGC_RD_ATOMIC_BELOW", 160), env_or("CAGC_RD_SPLIT_WGS", 320)};
   return t;
 }

@@ -30,7 +30,7 @@ CONFIGS = {
     "kw1_atomics": {"rd_min_wgs": 1, "rd_kw": 1, "rd_atomic_below": 1 << 20, "rd_split_wgs": 512},
     "mb4": {"rd_min_wgs": 1, "rd_mb": 4, "rd_atomic_below": 0},
 }
-DEFAULTS = {"rd": 1, "rd_min_wgs": 320, "rd_mb": 0, "rd_kw": 0, "rd_split": 1, "rd_atomic_below": 160, "rd_split_wgs": 320}
+DEFAULTS = {"rd": 1, "rd_min_wgs": 512, "rd_mb": 0, "rd_kw": 0, "rd_split": 1, "rd_atomic_below": 160, "rd_split_wgs": 320}
 
 
 @pytest.fixture(params=list(CONFIGS))
