@@ -71,6 +71,31 @@ def use_hip(t):
     return t.is_cuda and not composed_active()
 
 
+class _nullctx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+# CAGC_SIDE_WGRAD: elements of the layer's larger activation below which the student's weight gradient runs on a side stream
+# (0 = never).  Default 2^24 elements (measured, graph replay: batch 16 35.39 -> 35.11 ms, per-GPU batch 2 7.98 -> 7.83 ms).
+_SIDE_LIMIT = int(os.environ.get("CAGC_SIDE_WGRAD", str(1 << 24)))
+_side_streams = {}
+
+
+def _side_stream_small(numel):
+    return _SIDE_LIMIT > 0 and numel <= _SIDE_LIMIT
+
+
+def _side_stream(dev):
+    st = _side_streams.get(dev)
+    if st is None:
+        st = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 _stock_conv_warned = set()
 
 
@@ -235,7 +260,28 @@ class _ModConv(Function):
                 _lib.call("cagc_blur_up_bwd", _lib.ptr(g), _lib.ptr(gz), _lib.ptr(fir), B, cout, H, W)
             else:
                 g = gz
-            gx = gweight = None
+            gx = gweight = gwsq = None
+            if need_d:   # demodulation branch: gs += 2 s sum_o t wsq, gwsq = sum_b t s^2   (t = -gd d^3 / 2)
+                gwsq = torch.empty_like(wsq) if need_w else None
+                _lib.call("cagc_demod_bwd", _lib.ptr(gs), _lib.ptr(gwsq), _lib.ptr(gd), _lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq),
+                          B, cin, cout)
+            # Small launches (low resolutions, small per-GPU batches) leave most of the 256 CUs idle: the weight gradient — which
+            # nothing else in this node depends on — then runs on a side stream next to the data gradient (fork / join become
+            # graph dependencies under HIP-graph capture; at batch 16 the big layers fill the chip on their own and it is off)
+            side = None
+            if need_w and (need_x or need_s) and _side_stream_small(B * max(cin, cout) * Ho * Wo):
+                main = torch.cuda.current_stream()
+                side = _side_stream(dev)
+                side.wait_stream(main)
+            if need_w:
+                with (torch.cuda.stream(side) if side is not None else _nullctx()):
+                    up = 1 if upsample else 0
+                    n_ws = _lib.query("cagc_modconv_wgrad_workspace", B, cin, cout, H, W, k, up)
+                    ws = torch.empty(n_ws, dtype=x.dtype, device=dev)
+                    gweight = torch.empty(1, cout, cin, k, k, dtype=x.dtype, device=dev)
+                    wc = weight.detach().contiguous() if gwsq is not None else None
+                    _lib.call("cagc_modconv_wgrad_demod", _lib.ptr(gweight), _lib.ptr(ws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(s),
+                              _lib.ptr(gwsq), _lib.ptr(wc), B, cin, cout, H, W, k, up, 1.0 / math.sqrt(cin * k * k))
             if need_x or need_s:
                 gx = torch.empty_like(x)
                 if upsample:
@@ -250,19 +296,12 @@ class _ModConv(Function):
                 else:
                     _lib.call("cagc_modconv_dgrad", _lib.ptr(gx), _lib.ptr(gs), _lib.ptr(g), _lib.ptr(wp_bwd), _lib.ptr(s),
                               _lib.ptr(x), B, cin, cout, H, W, k)
-            gwsq = None
-            if need_d:   # demodulation branch: gs += 2 s sum_o t wsq, gwsq = sum_b t s^2   (t = -gd d^3 / 2)
-                gwsq = torch.empty_like(wsq) if need_w else None
-                _lib.call("cagc_demod_bwd", _lib.ptr(gs), _lib.ptr(gwsq), _lib.ptr(gd), _lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq),
-                          B, cin, cout)
-            if need_w:
-                up = 1 if upsample else 0
-                n_ws = _lib.query("cagc_modconv_wgrad_workspace", B, cin, cout, H, W, k, up)
-                ws = torch.empty(n_ws, dtype=x.dtype, device=dev)
-                gweight = torch.empty(1, cout, cin, k, k, dtype=x.dtype, device=dev)
-                wc = weight.detach().contiguous() if gwsq is not None else None
-                _lib.call("cagc_modconv_wgrad_demod", _lib.ptr(gweight), _lib.ptr(ws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(s),
-                          _lib.ptr(gwsq), _lib.ptr(wc), B, cin, cout, H, W, k, up, 1.0 / math.sqrt(cin * k * k))
+            if side is not None:
+                main.wait_stream(side)
+                gweight.record_stream(main)                     # allocated on the side stream, consumed on the main one
+                for t_ in (wc, gwsq, g, x, s):                  # allocated on the main stream, read on the side stream
+                    if t_ is not None:
+                        t_.record_stream(side)
         g_noise = None
         if styled and noise is not None and ctx.needs_input_grad[4]:
             # d out / d noise = noise_weight * gpre, summed over channels (and over the batch for a shared [1,1,H,W] map);

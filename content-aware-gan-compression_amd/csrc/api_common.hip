@@ -1,5 +1,6 @@
 // ABI-level helpers: version, arch, thread-local error string.
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace cagc {
@@ -35,4 +36,14 @@ int zero_fill(void* ptr, size_t bytes, hipStream_t st) {
 
 extern "C" int cagc_abi_version(void) { return CAGC_ABI_VERSION; }
 extern "C" const char* cagc_last_error(void) { return cagc::g_err; }
+
+namespace cagc {
+// CAGC_DETERMINISTIC=1 / cagc_set_tuning("deterministic", 1): no K split through fp32 atomics in the convolution kernels
+// (small launches then split K across the waves of a workgroup / stay un-split): every FORWARD pass is bit-reproducible, so
+// the LeakyReLU gate pattern — and with it every gradient up to summation-order rounding (1e-6) — is the same run to run.
+int& deterministic_mode() {
+  static int v = getenv("CAGC_DETERMINISTIC") ? atoi(getenv("CAGC_DETERMINISTIC")) : 0;
+  return v;
+}
+}  // namespace cagc
 extern "C" const char* cagc_arch(void) { return "gfx950"; }

@@ -30,6 +30,9 @@ inline int check_launch(const char* what) {
 // zero-fill as a plain kernel launch (graph-capture friendly; used instead of hipMemsetAsync)
 int zero_fill(void* ptr, size_t bytes, hipStream_t st);
 
+// see api_common.hip
+int& deterministic_mode();
+
 inline hipStream_t as_stream(cagc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

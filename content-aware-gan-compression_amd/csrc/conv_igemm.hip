@@ -639,7 +639,7 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
     int ks = 1;
     // target ~256 workgroups: every extra split adds a pass of fp32 atomics over the tile, which costs more than the
     // shorter (latency-bound, ~2 us per chunk) K loop saves beyond that (sweep: 512 -> 256 saves 0.75 ms per step)
-    if (allow_split && tiles_all * mt < 512 && nchunks >= 4) {
+    if (allow_split && !deterministic_mode() && tiles_all * mt < 512 && nchunks >= 4) {
       ks = (tiles_all * mt < 256) ? cdiv(256, tiles_all * mt) : 2;   // half a round of workgroups: split once
       if (ks > nchunks / 2) ks = nchunks / 2;
       if (ks < 1) ks = 1;

@@ -532,7 +532,7 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
     blocks += r.items[p].block_end;
   }
   int ks_max = 1;
-  const int atomic_below = tune.atomic_below;
+  const int atomic_below = deterministic_mode() ? 0 : tune.atomic_below;
   if ((int64_t)blocks * mtiles < atomic_below) {
     if (!split_on) return CAGC_RD_DECLINED;
     // every workgroup gets about the same number of (K-step, tap) groups: an item's split is proportional to its taps
@@ -590,6 +590,7 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "rd_split")) t.split_on = value;
   else if (!strcmp(key, "rd_atomic_below")) t.atomic_below = value;
   else if (!strcmp(key, "rd_split_wgs")) t.split_target = value;
+  else if (!strcmp(key, "deterministic")) cagc::deterministic_mode() = value;
   else if (!strcmp(key, "wgrad_rd")) cagc::wgrad_rd_set_tuning(value, 0);
   else if (!strcmp(key, "wgrad_rd_wgs")) cagc::wgrad_rd_set_tuning(-1, value);
   else { cagc::set_error("cagc_set_tuning: unknown key '%s'", key); return CAGC_ERR_INVALID; }

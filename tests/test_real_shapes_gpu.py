@@ -111,21 +111,31 @@ def test_kd_step_256_batch16_properties():
         gs = torch.autograd.grad(wg * g_loss + wk * kd_l1, params, allow_unused=True)
         return g_loss.detach(), kd_l1.detach(), img.detach(), gs
 
-    gl, kl, img, g_all = grads(1.0, 1.0)
-    assert torch.isfinite(gl) and torch.isfinite(kl) and kl.item() > 0
-    _, _, img2, g_again = grads(1.0, 1.0)
-    assert_close(img2, img, 1e-6, "forward run to run")
-    worst = 0.0
-    for n, a, b in zip(names, g_all, g_again):
-        if a is not None:
-            assert torch.isfinite(a).all(), n
-            worst = max(worst, _rel(a, b))
-    assert worst <= 1e-3, f"run-to-run gradient deviation {worst:.2e}"
-    _, _, _, g_g = grads(1.0, 0.0)
-    _, _, _, g_k = grads(0.0, 1.0)
-    for n, a, b, c in zip(names, g_all, g_g, g_k):
-        if a is not None:
-            assert_close(a, b + c, 1e-3 if a.numel() > 1 else 1e-2, "additivity " + n)
+    from cagc import _lib
+    lib = _lib.load()
+    # Deterministic mode (CAGC_DETERMINISTIC=1 / cagc_set_tuning): no fp32-atomic K split in the convolution kernels, so every
+    # forward pass is bit-reproducible.  The LeakyReLU gates of the 10^8 activations of student and discriminator are then the
+    # same in every run, and gradients repeat to summation-order rounding instead of to the effect of flipped gates (default
+    # mode, measured on this step: 2.3e-3 of a tensor's scale)
+    assert lib.cagc_set_tuning(b"deterministic", 1) == 0
+    try:
+        gl, kl, img, g_all = grads(1.0, 1.0)
+        assert torch.isfinite(gl) and torch.isfinite(kl) and kl.item() > 0
+        gl2, kl2, img2, g_again = grads(1.0, 1.0)
+        assert torch.equal(img2, img), "deterministic mode: the forward pass is bit-reproducible"
+        worst = 0.0
+        for n, a, b in zip(names, g_all, g_again):
+            if a is not None:
+                assert torch.isfinite(a).all(), n
+                worst = max(worst, _rel(a, b))
+        assert worst <= 2e-5, f"run-to-run gradient deviation {worst:.2e}"
+        _, _, _, g_g = grads(1.0, 0.0)
+        _, _, _, g_k = grads(0.0, 1.0)
+        for n, a, b, c in zip(names, g_all, g_g, g_k):
+            if a is not None:
+                assert_close(a, b + c, 2e-5 if a.numel() > 1 else 1e-3, "additivity " + n)
+    finally:
+        lib.cagc_set_tuning(b"deterministic", 0)
     with torch.no_grad():
         one = student([z[3:4] for z in zs], inject_index=5, noise=[n[3:4] for n in sn])
         assert_close(one, img[3:4], 1e-5, "student batch independence")
