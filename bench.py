@@ -33,6 +33,15 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 3
 PEAK_HBM_GBS = 8000.0
 
 
+def wino_f4(k_ch, m_ch):
+    """csrc/prep_device.h wino_use_f4: the layer runs on the F(4x4,3x3) kernel (conv_wino4.hip)."""
+    return os.environ.get("CAGC_WINO_F4", "1") != "0" and m_ch % 128 == 0 and k_ch >= 128
+
+
+def wino_macs(k_ch, m_ch):
+    return 2.25 if wino_f4(k_ch, m_ch) else 4.0
+
+
 def conv_flops(name, a):
     """Algorithmic FLOPs (2 * MACs, the repo's own MAC convention of Util/Calculators.py) of one MFMA launch."""
     if name == "cagc_modconv_fwd":       # (out,x,wp,s,B,Cin,Cout,H,W,k,...)
@@ -53,12 +62,12 @@ def conv_flops(name, a):
     if name == "cagc_modconv_wgrad_demod":   # (gw,ws,g,x,s,gwsq,weight,B,Cin,Cout,H,W,k,up,scale)
         B, cin, cout, H, W, k = a[7:13]
         return 2.0 * B * cin * cout * k * k * H * W
-    if name == "cagc_wino_conv3x3":      # (out,x,up,s,B,Cin,Cout,H,W,...): Winograd F(2x2,3x3) — count the flops the
-        B, cin, cout, H, W = a[4:9]      # MFMA pipe EXECUTES (16 GEMMs over H/2*W/2 tiles = 4 MACs per output pixel
-        return 2.0 * B * cin * cout * 4 * H * W   # and channel pair), not the 9 of the direct conv it replaces
+    if name == "cagc_wino_conv3x3":      # (out,x,up,s,B,Cin,Cout,H,W,...): Winograd — count the flops the MFMA pipe EXECUTES
+        B, cin, cout, H, W = a[4:9]      # (F(2x2,3x3): 16 GEMMs over H/2*W/2 tiles = 4 MACs per output pixel and channel pair;
+        return 2.0 * B * cin * cout * wino_macs(cin, cout) * H * W   # F(4x4,3x3): 36 over H/4*W/4 = 2.25), not the direct conv's 9
     if name == "cagc_wino_conv3x3_act_dgrad":   # (gx,gout,act_out,up,residual,B,Cin,Cout,H,W,...)
         B, cin, cout, H, W = a[5:10]
-        return 2.0 * B * cin * cout * 4 * H * W
+        return 2.0 * B * cin * cout * wino_macs(cout, cin) * H * W     # data gradient: GEMM K = Cout, M = Cin
     if name in ("cagc_conv3x3s2_fwd", "cagc_conv3x3s2_dgrad"):   # (out,x,wp,B,Cin,Cout,Hin,Win,pitch)
         B, cin, cout, hin, win = a[3:8]
         return 2.0 * B * cin * cout * 9 * ((hin - 3) // 2 + 1) * ((win - 3) // 2 + 1)
@@ -94,11 +103,13 @@ KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false, false", "c
              "cagc_wino_conv3x3[k_wino<4, false, NH2>]": "k_wino<4, false, false, 2>", "cagc_wino_conv3x3[k_wino<4, false, NH1>]": "k_wino<4, false, false, 1>",
              "cagc_wino_conv3x3[k_wino<3, false, NH1>]": "k_wino<3, false, false, 1>", "cagc_wino_conv3x3[k_wino<3, false, NH2>]": "k_wino<3, false, false, 2>",
              "cagc_wino_conv3x3_act_dgrad[k_wino<4, true, NH2>]": "k_wino<4, true, false, 2>", "cagc_wino_conv3x3_act_dgrad[k_wino<4, true, NH1>]": "k_wino<4, true, false, 1>",
-             "cagc_modconv_fwd": "k_conv_igemm<8, 4, true, false, 1>",
-             "cagc_modconv_up_fwd": "k_conv_igemm<8, 4, true, false, 1>",
-             "cagc_modconv_dgrad": "k_conv_igemm<8, 12, true, false, 1>",
-             "cagc_modconv_up_dgrad": "k_conv_igemm<8, 12, true, false, 1>", "cagc_modconv_wgrad": "k_wgrad2<5, 2>",
-             "cagc_modconv_wgrad_demod": "k_wgrad2<5, 2>"}
+             "cagc_wino_conv3x3[k_wino4<false>]": "k_wino4<false>", "cagc_wino_conv3x3_act_dgrad[k_wino4<true>]": "k_wino4<true>",
+             "cagc_modconv_fwd": "k_conv_rd<4, true, true, false>",
+             "cagc_modconv_up_fwd": "k_conv_rd<8, true, true, false>",
+             "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_dgrad": "k_conv_rd<8, true, false, false>",
+             "cagc_modconv_dgrad": "k_conv_rd<5, true, false, true>",
+             "cagc_modconv_up_dgrad": "k_conv_rd<5, true, false, true>", "cagc_modconv_wgrad": "k_wgrad_rd<4, 1, false, 9>",
+             "cagc_modconv_wgrad_demod": "k_wgrad_rd<3, 1, false, 9>"}
 
 
 def pmc_traffic(symbol):
@@ -142,7 +153,9 @@ class KernelTimer:
             self.orig(name, *args)
             e.record(st)
             key = name
-            if name in ("cagc_wino_conv3x3", "cagc_wino_conv3x3_act_dgrad"):   # one record family per device kernel, so the
+            if name in ("cagc_wino_conv3x3", "cagc_wino_conv3x3_act_dgrad") and wino_f4(args[7] if name.endswith("act_dgrad") else args[5], args[6]):
+                key = f"{name}[k_wino4<{'true' if name.endswith('act_dgrad') else 'false'}>]"       # F(4x4,3x3): conv_wino4.hip
+            elif name in ("cagc_wino_conv3x3", "cagc_wino_conv3x3_act_dgrad"):   # one record family per device kernel, so the
                 gated = name.endswith("act_dgrad")                              # average launch duration is comparable with the
                 nblk = -(-(args[6]) // 16)                                      # rocprofv3 per-symbol summary (conv_wino.hip wino_mb)
                 mb = nblk if nblk <= 3 else (3 if (nblk % 4 != 0 and nblk % 3 == 0) else 4)
@@ -408,9 +421,11 @@ def main():
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "launches_per_step": cnt // 3, "avg_launch_ms": round(tot_ms / cnt, 4),
                     "flops_per_launch_avg": flops / cnt,
-                    "achieved_direct_conv_equivalent": round(ach * (2.25 if name.startswith("cagc_wino_conv3x3") else 1.0), 2),
-                    "flops_note": "MFMA flops executed (Winograd: 4 MACs/output/channel-pair; its direct-conv equivalent "
-                                  "rate is 2.25x 'achieved')" if name.startswith("cagc_wino_conv3x3") else "2*MACs of the conv",
+                    "achieved_direct_conv_equivalent": round(ach * (4.0 if "k_wino4" in name else (2.25 if name.startswith("cagc_wino_conv3x3") else 1.0)), 2),
+                    "flops_note": ("MFMA flops executed (Winograd F(4x4,3x3): 2.25 MACs/output/channel-pair; its direct-conv equivalent "
+                                   "rate is 4x 'achieved')" if "k_wino4" in name else
+                                   "MFMA flops executed (Winograd F(2x2,3x3): 4 MACs/output/channel-pair; its direct-conv equivalent "
+                                   "rate is 2.25x 'achieved')" if name.startswith("cagc_wino_conv3x3") else "2*MACs of the conv"),
                     "all_mfma_entry_points": {k: {"ms_per_step": round(v[1] / 3, 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
                                               for k, v in sorted(mfma.items(), key=lambda kv: -kv[1][1])},
                     "cagc_kernel_ms_per_step": {k: round(v[1] / 3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}

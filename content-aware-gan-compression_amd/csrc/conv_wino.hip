@@ -28,6 +28,7 @@
 // packed with flipped taps and swapped channel roles (cagc_wino_prep(..., dgrad = 1)).
 #include "common.h"
 #include "prep_device.h"
+#include "conv_wino.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -50,25 +51,6 @@ constexpr int wino_th(int NH) { return 4 * wino_geo(NH); }                  // t
 constexpr int wino_ih(int NH) { return 4 * wino_geo(NH) + 2; }              // raw tile rows
 constexpr int wino_vs(int NH) { return wino_geo(NH) == 2 ? 80 : 48; }       // V row stride: 32 * geo tiles, == 16 (mod 32)
 
-struct WinoArgs {
-  const float* in;
-  float* out;
-  const float* up;         // [mtiles][16][Kp/4][64][4]  (k_wino_pack)
-  const float* in_scale;   // [B,Cin] or null
-  const float* gate;       // [B,Cin,H,W] or null: the staged input is multiplied by lrelu'(gate) = (gate > 0 ? 1 : gate_alpha) * gate_scale
-  const float* residual;   // [B,Cout,H,W] or null: added to the (linear-epilogue) output — gradient accumulation in the store
-  float gate_alpha, gate_scale;
-  const float* out_scale;  // [B,Cout] or null
-  const float* noise;
-  const float* noise_w;
-  const float* bias;
-  int B, Cin, Kp, Cout, Mp, H, W;
-  int tiles_x, tiles_y, nblocks, mtiles;
-  int pmb;                 // channel blocks per PACKED tile of `up` (wino_mb of the layer); a SUB launch runs fewer per workgroup
-  int epi, noise_bstride_on;
-  int wg_map;              // workgroup -> tile mapping, see k_wino
-  float alpha, act_scale;
-};
 
 // Timing of one workgroup (debug builds only: -DCAGC_WINO_TRACE, scripts/trace_wino.py): per wave, shader cycles per chunk
 // in [2] the K-steps in front of the barrier, [4] barrier + last K-step's issue; [5] prologue, [6] epilogue of the workgroup.
@@ -569,6 +551,7 @@ extern "C" int cagc_wino_eligible(int H, int W) { return (H % 8 == 0 && W % WTW 
 
 extern "C" int64_t cagc_wino_packed_elems(int K, int M) {
   if (K <= 0 || M <= 0) return 0;
+  if (wino_use_f4(K, M)) return wino4_packed_elems(K, M);
   const int mb = wino_mb(M);
   return (int64_t)cdiv(M, mb * 16) * 16 * wino_kp(K) * 64;
 }
@@ -577,6 +560,7 @@ extern "C" int cagc_wino_prep(float* up, const float* weight, int Cout, int Cin,
                               cagc_stream_t stream) {
   CAGC_REQUIRE(up && weight && Cout > 0 && Cin > 0, "cagc_wino_prep: bad argument");
   const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
+  if (wino_use_f4(K, M)) return wino4_prep(up, weight, Cout, Cin, scale, dgrad, as_stream(stream));
   const int Kp = wino_kp(K), mb = wino_mb(M), mtiles = cdiv(M, mb * 16);
   hipLaunchKernelGGL(k_wino_pack, dim3(cdiv((int64_t)mtiles * Kp * 64, 256)), dim3(256), 0, as_stream(stream), up, weight,
                      Cout, Cin, Kp, mtiles, mb, scale, dgrad);
@@ -603,6 +587,10 @@ extern "C" int cagc_wino_conv3x3(float* out, const float* x, const float* up, co
   a.in = x; a.out = out; a.up = up; a.in_scale = s; a.out_scale = out_scale; a.noise = noise; a.noise_w = noise_w; a.bias = bias;
   a.B = B; a.Cin = Cin; a.Kp = wino_kp(Cin); a.Cout = Cout; a.Mp = round_up(Cout, 16); a.H = H; a.W = W;
   a.epi = epi; a.noise_bstride_on = (noise_batch == B) ? 1 : 0; a.alpha = alpha; a.act_scale = act_scale;
+  if (wino_use_f4(Cin, Cout)) {   // F(4x4,3x3): 2.25 multiplies per output (conv_wino4.hip); `up` was packed for it by the same predicate
+    CAGC_REQUIRE(((uintptr_t)out % 16) == 0 && (!noise || ((uintptr_t)noise % 16) == 0), "%s: unaligned tensor", what);
+    return run_wino4(a, false, as_stream(stream), what);
+  }
   return wino_dispatch<false>(a, Cout, as_stream(stream), what);
 }
 
@@ -626,5 +614,9 @@ extern "C" int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const f
   a.in = gout; a.gate = act_out; a.gate_alpha = alpha; a.gate_scale = act_scale; a.out = gx; a.up = up; a.residual = residual;
   a.B = B; a.Cin = Cout; a.Kp = wino_kp(Cout); a.Cout = Cin; a.Mp = round_up(Cin, 16); a.H = H; a.W = W;
   a.epi = CAGC_EPI_LINEAR; a.alpha = alpha; a.act_scale = 1.f;
+  if (wino_use_f4(Cout, Cin)) {
+    CAGC_REQUIRE(((uintptr_t)gx % 16) == 0 && (!residual || ((uintptr_t)residual % 16) == 0), "%s: unaligned tensor", what);
+    return run_wino4(a, true, as_stream(stream), what);
+  }
   return wino_dispatch<true>(a, Cin, as_stream(stream), what);
 }

@@ -1,0 +1,409 @@
+// Winograd F(4x4, 3x3) convolution on the fp32 matrix cores of gfx950 — stride-1 "same" 3x3 convs whose GEMM M (output
+// channels) is a multiple of 128: the teacher's and the discriminator's layers, forward and data gradient.
+//
+//   Y = A^T [ sum_c (G g G^T)[o,c] (.) (B^T d B)[c] ] A        per 6x6 input patch d -> 4x4 outputs
+//
+// 36 independent GEMMs  M[pos][o][tile] = sum_c U[pos][o][c] * V[pos][c][tile]: 36 multiplies per 16 outputs = 2.25 per output
+// against F(2x2)'s 4 (conv_wino.hip) and the direct convolution's 9.  fp32 throughout (exact-fp32 MFMA); the transforms use
+// the interpolation points 0, +-1, +-2, inf — their larger constants cost ~1.5 decimal digits against F(2x2) (measured ~1e-5
+// of the output scale; the parity bar is 1e-3).
+//
+// Workgroup = 4 waves, ONE wave per SIMD (up to 512 registers), tile = 128 output channels x (8 x 32 output pixels = 2 x 8
+// Winograd tiles = one MFMA N-block).  Wave (I, J) owns the 3x3 block of positions i in 3I..3I+2, j in 3J..3J+2 for all 8
+// channel blocks: 72 accumulator tiles.  K runs in chunks of 8 input channels:
+//   A operand: transformed weights U pre-packed in MFMA register order [mtile][pos][K/4][lane][8 blocks], global / L2 -> VGPR
+//     (two 16-byte loads per (position, K-step) feed 8 MFMAs), a ring of half a chunk refilled in place;
+//   B operand: raw halo tile [8][10][40] --(registers)--> LDS (2 buffers) --B^T d B, half a patch (3 of the 6 transformed rows)
+//     per thread--> V[36][8][16] in LDS (2 buffers), one ds_read_b32 per 8 MFMAs.
+// On gfx950 VALU instructions do not overlap the fp32 MFMA: per chunk a wave issues 144 MFMAs next to ~45
+// packed transform operations, the commit of the prefetched raw tile and 36 + 18 LDS accesses; one barrier per chunk.
+// Output transform: every wave reduces ITS 3x3 block of positions to a partial 4x4 output tile with the separable A^T . A
+// (the rows / columns of A^T restricted to the block need 3-5 operations), the four partials meet in LDS per channel block,
+// and wave a finishes output row a of the tile: demodulation / noise / bias / LeakyReLU / residual, 16-byte stores.
+#include "common.h"
+#include "prep_device.h"
+#include "conv_wino.h"
+#include <string.h>
+#include <stdlib.h>
+
+namespace cagc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int W4_CK = 8;                 // input channels per chunk
+constexpr int W4_IH = 10, W4_IWP = 40;   // raw tile: rows y0-1 .. y0+8, LDS col 0 <-> global col x0-4
+constexpr int W4_RPS = W4_IH * W4_IWP;   // raw channel-plane stride (floats)
+constexpr int W4_RSZ = W4_CK * W4_RPS;   // one raw buffer
+constexpr int W4_VSZ = 36 * W4_CK * 16;  // one V buffer: [pos][k][tile]
+constexpr int W4_NU = (W4_CK * W4_IH * 10 + 255) / 256;   // float4 units of the raw tile per thread (800 / 256 -> 4)
+
+// 1-D input transform B^T (6 -> 6), rows 0..2 (H = 0) or 3..5 (H = 1)
+template <int H>
+__device__ __forceinline__ void w4_bt3(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
+                                       float& o0, float& o1, float& o2) {
+  if (H == 0) {
+    o0 = 4.f * d0 - 5.f * d2 + d4;
+    o1 = (d3 + d4) - 4.f * (d1 + d2);
+    o2 = 4.f * (d1 - d2) - (d3 - d4);
+  } else {
+    const float a = d4 - d2, b = d3 - d1;
+    o0 = a + 2.f * b;
+    o1 = a - 2.f * b;
+    o2 = 4.f * d1 - 5.f * d3 + d5;
+  }
+}
+__device__ __forceinline__ void w4_bt6(const float (&t)[6], float (&o)[6]) {
+  w4_bt3<0>(t[0], t[1], t[2], t[3], t[4], t[5], o[0], o[1], o[2]);
+  w4_bt3<1>(t[0], t[1], t[2], t[3], t[4], t[5], o[3], o[4], o[5]);
+}
+// 1-D output transform A^T restricted to the three positions 3*H .. 3*H+2: 3 -> 4
+template <int H>
+__device__ __forceinline__ void w4_at3(const float m0, const float m1, const float m2, float (&z)[4]) {
+  if (H == 0) {            // columns 0,1,2 of A^T: (1,1,1), (0,1,-1), (0,1,1), (0,1,-1)
+    const float s = m1 + m2, d = m1 - m2;
+    z[0] = m0 + s; z[1] = d; z[2] = s; z[3] = d;
+  } else {                 // columns 3,4,5: (1,1,0), (2,-2,0), (4,4,0), (8,-8,1)
+    const float s = m0 + m1, d = m0 - m1;
+    z[0] = s; z[1] = 2.f * d; z[2] = 4.f * s; z[3] = 8.f * d + m2;
+  }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// packed-fp32 helpers with half selection (VOP3P op_sel): the row stage of the input transform works on values paired along the
+// axis it mixes, so sums / differences of neighbouring elements take their operands from different register halves
+__device__ __forceinline__ f32x2 pk_hi_pm_lo(const f32x2 a, const f32x2 b) {     // (a.hi + b.lo, a.hi - b.lo)
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_fma_negc_hi(const f32x2 a, const f32x2 b, const f32x2 c) {   // (a.lo*b.lo + c.lo, a.hi*b.hi - c.hi)
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_fma_ahi_clo(const f32x2 a, const f32x2 b, const f32x2 c) {    // (a.hi*b.lo + c.lo, a.hi*b.hi + c.lo)
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// Workgroup = 8 waves (2 per SIMD): wave = (channel half hb, I, J) owns the 3x3 block of positions (3I.., 3J..) for 4 channel
+// blocks: 36 accumulator tiles.  The two waves of a SIMD are (hb = 0, I, J) and (hb = 1, I, J) (waves w and w + 4 share a SIMD):
+// they take turns transforming (even / odd chunks), so every SIMD carries the same VALU work in every chunk.
+template <bool GATED, bool SCALE>
+__global__ __launch_bounds__(512, 1) void k_wino4(const WinoArgs A) {
+  constexpr int CK = W4_CK;
+  constexpr int NU = (CK * W4_IH * 10 + 511) / 512;     // raw-tile float4 units per thread (800 / 512 -> 2)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* v_lds = smem;                    // [2][36*CK][16]
+  float* raw = v_lds + 2 * W4_VSZ;        // [2][CK][RPS]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hb = wave >> 2, WI = (wave >> 1) & 1, WJ = wave & 1;
+  const int lm = lane & 15, g = lane >> 4;
+
+  int pix_id, mtile;
+  {
+    const int w = blockIdx.x, nx = A.nblocks, mt = A.mtiles;
+    const int total = nx * mt, per = total / 8;
+    const int s = w >> 3, xcd = w & 7;
+    const int idx = (w < per * 8) ? xcd * per + s : w;
+    mtile = idx / nx; pix_id = idx - mtile * nx;
+  }
+  const int tx_i = pix_id % A.tiles_x;
+  const int ty_i = (pix_id / A.tiles_x) % A.tiles_y;
+  const int b = pix_id / (A.tiles_x * A.tiles_y);
+  const int x0 = tx_i * 32, y0 = ty_i * 8;
+  const int m0 = mtile * 128;
+  const int HW = A.H * A.W;
+  const int nch = A.Kp / CK;
+  const int KQ = A.Kp / 4;
+
+  // ---- raw-tile staging: CK x 10 rows x 10 float4 = 800 units over 512 threads ---------------------------------------------
+  constexpr unsigned OOR = 0x80000000u;
+  unsigned e_boff[NU], e_soff[NU];
+  int e_loff[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    int e = tid + 512 * i;
+    if (e >= CK * W4_IH * 10) e -= CK * W4_IH * 10;       // spare lanes of the last round repeat a unit (same value, same address)
+    const int r = e / 10, q = e - r * 10;
+    const int c = r / W4_IH, iy = r - c * W4_IH;
+    const int gy = y0 - 1 + iy, gx = x0 - 4 + 4 * q;
+    const bool ok = (gy >= 0) && (gy < A.H) && (gx >= 0) && (gx + 4 <= A.W);
+    e_boff[i] = ok ? 4u * (unsigned)(c * HW + gy * A.W + gx) : OOR;
+    e_soff[i] = 4u * (unsigned)c;
+    e_loff[i] = c * W4_RPS + iy * W4_IWP + 4 * q;
+  }
+  float4 rin[NU];
+  float4 rgt[GATED ? NU : 1];
+  float rsc[NU];
+  constexpr bool has_scale = SCALE;      // compile-time: no select / multiply in the commit of unmodulated layers
+  const int nfull = A.Cin / CK;
+  auto prefetch = [&](int j) {   // global -> registers, chunk j (channels past Cin / chunks past the end: zeros)
+    const int nreal = j < nfull ? CK : (j == nfull ? A.Cin - nfull * CK : 0);
+    const int64_t cbase = ((int64_t)b * A.Cin + (int64_t)j * CK) * HW;
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.in + cbase), 0, nreal * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_scale ? A.in_scale + (int64_t)b * A.Cin + j * CK : A.in), 0, has_scale ? nreal * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      rin[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ri, e_boff[i], 0, 0));
+      if (GATED) {
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.gate + cbase), 0, nreal * HW * 4, 0x00020000);
+        rgt[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rg, e_boff[i], 0, 0));
+      }
+      if (has_scale) rsc[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, e_soff[i], 0, 0));
+    }
+  };
+  auto commit = [&](float* rbuf) {   // registers -> raw tile in LDS (modulation s[b,c] and the fused LeakyReLU backward applied here)
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      float4 v = rin[i];
+      if (GATED) {
+        const float4 gt = rgt[i];
+        const float hi = A.gate_scale, lo = A.gate_alpha * A.gate_scale;
+        v.x *= gt.x > 0.f ? hi : lo; v.y *= gt.y > 0.f ? hi : lo; v.z *= gt.z > 0.f ? hi : lo; v.w *= gt.w > 0.f ? hi : lo;
+      }
+      if (has_scale) { const float s = rsc[i]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+      *reinterpret_cast<float4*>(rbuf + e_loff[i]) = v;
+    }
+  };
+
+  // ---- input transform: work item = (half h of the transformed rows, channel c, tile); 256 items per chunk -----------------
+  // done by the 256 threads of channel half hb == (chunk & 1): both waves of a SIMD alternate
+  const int wt = tid & 255;
+  const int t_h = wt >> 7, t_c = (wt >> 4) & 7, t_t = wt & 15;
+  const int t_src = t_c * W4_RPS + (4 * (t_t >> 3)) * W4_IWP + 3 + 4 * (t_t & 7);   // patch origin: row y0-1+4ty, col x0-1+4tx
+  const int t_dst = (t_h * 18 * CK + t_c) * 16 + t_t;                                 // V[(3h + i)*6 + j][c][tile]
+  const f32x2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f}, cm44 = {-4.f, 4.f}, c2m2 = {2.f, -2.f}, c22 = {2.f, 2.f};
+  auto transform = [&](const float* rbuf, float* vbuf) {
+    // column stage (mixes rows: separate registers): rows 3h..3h+2 of B^T d, two columns per packed operation; the patch is
+    // read one column pair at a time (12 LDS reads) so that only 6 packed inputs are live next to the 9 packed results
+    const float* p = rbuf + t_src;
+    f32x2 t3[3][3];
+#pragma unroll
+    for (int qp = 0; qp < 3; ++qp) {
+      f32x2 d[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) d[r] = (f32x2){p[r * W4_IWP + 2 * qp], p[r * W4_IWP + 2 * qp + 1]};
+      if (t_h == 0) {
+        t3[0][qp] = c4 * d[0] + cm5 * d[2] + d[4];
+        t3[1][qp] = (d[3] + d[4]) - c4 * (d[1] + d[2]);
+        t3[2][qp] = c4 * (d[1] - d[2]) - (d[3] - d[4]);
+      } else {
+        const f32x2 a = d[4] - d[2], bb = d[3] - d[1];
+        t3[0][qp] = a + c22 * bb;
+        t3[1][qp] = a - c22 * bb;
+        t3[2][qp] = c4 * d[1] + cm5 * d[3] + d[5];
+      }
+    }
+    // row stage (mixes columns, which are paired): Q0 = (t0,t1), Q1 = (t2,t3), Q2 = (t4,t5) -> V[i][0..5]
+    float* vp = vbuf + t_dst;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const f32x2 Q0 = t3[i][0], Q1 = t3[i][1], Q2 = t3[i][2];
+      const f32x2 o05 = c4 * Q0 + cm5 * Q1 + Q2;                 // (4t0 - 5t2 + t4, 4t1 - 5t3 + t5)
+      const f32x2 S12 = pk_hi_pm_lo(Q0, Q1);                      // (t1 + t2, t1 - t2)
+      const f32x2 S34 = pk_hi_pm_lo(Q1, Q2);                      // (t3 + t4, t3 - t4)
+      const f32x2 o12 = pk_fma_negc_hi(S12, cm44, S34);           // (-4(t1+t2) + (t3+t4), 4(t1-t2) - (t3-t4))
+      const f32x2 D1 = Q2 - Q1, D0 = Q1 - Q0;                     // D1.lo = t4 - t2, D0.hi = t3 - t1
+      const f32x2 o34 = pk_fma_ahi_clo(D0, c2m2, D1);             // ((t4-t2) + 2(t3-t1), (t4-t2) - 2(t3-t1))
+      vp[((i * 6 + 0) * CK) * 16] = o05.x;
+      vp[((i * 6 + 1) * CK) * 16] = o12.x;
+      vp[((i * 6 + 2) * CK) * 16] = o12.y;
+      vp[((i * 6 + 3) * CK) * 16] = o34.x;
+      vp[((i * 6 + 4) * CK) * 16] = o34.y;
+      vp[((i * 6 + 5) * CK) * 16] = o05.y;
+    }
+  };
+
+  // ---- A operand ring: half a chunk = 9 (position, K-step) groups of ONE float4 (this wave's 4 channel blocks) ----------------
+  const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(A.up) + (int64_t)mtile * 36 * KQ * 512, 0, 0x7fffffff, 0x00020000);
+  const unsigned ua_lane = (unsigned)lane * 32u + (unsigned)hb * 16u;
+  auto a_soff = [&](int gi, int chunk) {
+    const int p = gi >> 1, s = gi & 1;
+    const int pos = (3 * WI + p / 3) * 6 + 3 * WJ + p % 3;
+    return ((pos * KQ + 2 * chunk + s) * 512) * 4;
+  };
+  float4 ring[6];      // a third of a chunk ahead (6 groups = 24 MFMAs of this wave, twice that in wall time next to its partner)
+  auto load_a = [&](int slot, int gi, int chunk) {
+    ring[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, ua_lane, a_soff(gi, chunk), 0));
+  };
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int p = 0; p < 9; ++p)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[p][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- pipeline --------------------------------------------------------------------------------------------------------------
+  prefetch(0);
+  commit(raw);
+  prefetch(1);
+  __syncthreads();
+  if (hb == 0) transform(raw, v_lds);
+  commit(raw + W4_RSZ);
+  prefetch(2);
+#pragma unroll
+  for (int gi = 0; gi < 6; ++gi) load_a(gi, gi, 0);
+  __syncthreads();
+
+  // B operand of this wave: V[pos][4s + g][lm]; read one group ahead
+  // position = (3WI + li)*6 + 3WJ + lj = (18WI + 3WJ) + (6li + lj): the wave's part goes into the base address, the rest is
+  // an immediate offset of the ds_read (no address arithmetic in the loop)
+  const int vb_wave = ((18 * WI + 3 * WJ) * CK + g) * 16 + lm;
+  auto b_off = [&](int gi) {
+    const int p = gi >> 1, s = gi & 1;
+    return ((6 * (p / 3) + p % 3) * CK + 4 * s) * 16;
+  };
+  float bv_next = (v_lds + vb_wave)[b_off(0)];
+  // one chunk with the LDS buffer parity `cur` a compile-time constant: every LDS address in it is (one per-thread base
+  // register) + (an immediate) — no address arithmetic next to the MFMAs; the K loop below runs two chunks per iteration
+  auto chunk = [&](const int j, const int cur) {
+    const float* vb = v_lds + cur * W4_VSZ + vb_wave;
+    const float* vbn = v_lds + (cur ^ 1) * W4_VSZ + vb_wave;
+    float* vnext = v_lds + (cur ^ 1) * W4_VSZ;
+    const float* rnext = raw + (cur ^ 1) * W4_RSZ;      // chunk j+1, transformed during this chunk by the waves of half (j+1)&1
+    const bool xf = (hb == (cur ^ 1));                  // uniform per wave: (j + 1) & 1 == cur ^ 1
+    const int jn = (j + 1 < nch) ? j + 1 : j;           // last chunk: re-read valid weights instead of branching
+#pragma unroll
+    for (int gi = 0; gi < 18; ++gi) {
+      const int p = gi >> 1, slot = gi % 6;
+      const float bv = bv_next;
+      if (gi < 17) bv_next = vb[b_off(gi + 1)];
+      const float4 a0 = ring[slot];
+      acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv, acc[p][0], 0, 0, 0);
+      acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv, acc[p][1], 0, 0, 0);
+      acc[p][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv, acc[p][2], 0, 0, 0);
+      acc[p][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv, acc[p][3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gi + 6 < 18) load_a(slot, gi + 6, j);
+      else load_a(slot, gi + 6 - 18, jn);
+      if (xf && gi == 8) transform(rnext, vnext);   // chunk j+1's input transform; the partner wave's MFMAs cover its LDS latency
+      if (gi == 12) {                              // raw[cur] (chunk j) was transformed during chunk j-1: refill it with chunk j+2
+        commit(raw + cur * W4_RSZ);
+        prefetch(j + 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    bv_next = vbn[b_off(0)];
+  };
+  for (int j = 0; j < nch; j += 2) {     // Kp is a multiple of 16: an even number of chunks
+    chunk(j, 0);
+    chunk(j + 1, 1);
+  }
+
+  // ---- output transform + epilogue, one channel block (of each half) at a time ----------------------------------------------
+  f32x4* ex = reinterpret_cast<f32x4*>(smem);        // [wave 8][a 4][r 4][lane 64] of float4 (b = 0..3)
+  const int w4 = wave & 3;                           // this wave finishes output row a = w4 of every tile, for its half's blocks
+  const bool styled = (A.epi == CAGC_EPI_STYLED);
+  const float nw = (styled && A.noise) ? A.noise_w[0] : 0.f;
+  const int oy = y0 + 4 * (lm >> 3) + w4, ox = x0 + 4 * (lm & 7);
+  float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (styled && A.noise) {
+    const float4 n4 = *reinterpret_cast<const float4*>(A.noise + (A.noise_bstride_on ? (int64_t)b * HW : 0) + (int64_t)oy * A.W + ox);
+    nz = make_float4(nw * n4.x, nw * n4.y, nw * n4.z, nw * n4.w);
+  }
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    if (blk) __syncthreads();                        // the exchange buffer is reused
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float z[3][4];
+#pragma unroll
+      for (int li = 0; li < 3; ++li) {
+        if (WJ == 0) w4_at3<0>(acc[li * 3 + 0][blk][r], acc[li * 3 + 1][blk][r], acc[li * 3 + 2][blk][r], z[li]);
+        else w4_at3<1>(acc[li * 3 + 0][blk][r], acc[li * 3 + 1][blk][r], acc[li * 3 + 2][blk][r], z[li]);
+      }
+      float y[4][4];   // [b][a]
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        if (WI == 0) w4_at3<0>(z[0][bb], z[1][bb], z[2][bb], y[bb]);
+        else w4_at3<1>(z[0][bb], z[1][bb], z[2][bb], y[bb]);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        ex[((wave * 4 + a) * 4 + r) * 64 + lane] = (f32x4){y[0][a], y[1][a], y[2][a], y[3][a]};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + (hb * 4 + blk) * 16 + 4 * g + r;
+      f32x4 v = ex[(((hb * 4 + 0) * 4 + w4) * 4 + r) * 64 + lane];
+      v += ex[(((hb * 4 + 1) * 4 + w4) * 4 + r) * 64 + lane];
+      v += ex[(((hb * 4 + 2) * 4 + w4) * 4 + r) * 64 + lane];
+      v += ex[(((hb * 4 + 3) * 4 + w4) * 4 + r) * 64 + lane];
+      if (m < A.Cout) {
+        const float osc = A.out_scale ? A.out_scale[b * A.Cout + m] : 1.f;
+        float4 o = make_float4(v[0] * osc, v[1] * osc, v[2] * osc, v[3] * osc);
+        float* op = A.out + ((int64_t)(b * A.Cout + m)) * HW + (int64_t)oy * A.W + ox;
+        if (GATED && A.residual) {
+          const float4 rr = *reinterpret_cast<const float4*>(A.residual + ((int64_t)(b * A.Cout + m)) * HW + (int64_t)oy * A.W + ox);
+          o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
+        if (styled) {
+          const float bs = A.bias[m];
+          o.x += nz.x + bs; o.y += nz.y + bs; o.z += nz.z + bs; o.w += nz.w + bs;
+          o.x = (o.x > 0.f ? o.x : o.x * A.alpha) * A.act_scale; o.y = (o.y > 0.f ? o.y : o.y * A.alpha) * A.act_scale;
+          o.z = (o.z > 0.f ? o.z : o.z * A.alpha) * A.act_scale; o.w = (o.w > 0.f ? o.w : o.w * A.alpha) * A.act_scale;
+        }
+        *reinterpret_cast<float4*>(op) = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wino4_pack(float* __restrict__ up, const float* __restrict__ w, int Cout, int Cin, int Kp,
+                                                    int64_t n, float scale, int dgrad) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  wino4_pack_elem(up, w, idx, Cout, Cin, Kp, scale, dgrad);
+}
+
+int wino4_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad, hipStream_t st) {
+  const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
+  const int Kp = round_up(K, 16);
+  const int64_t n = (int64_t)(M / 128) * Kp * 128;
+  hipLaunchKernelGGL(k_wino4_pack, dim3(cdiv(n, 256)), dim3(256), 0, st, up, weight, Cout, Cin, Kp, n, scale, dgrad);
+  return check_launch("cagc_wino_prep(F4)");
+}
+
+int run_wino4(WinoArgs& a, bool gated, hipStream_t st, const char* what) {
+  CAGC_REQUIRE(a.Cout % 128 == 0 && a.H % 8 == 0 && a.W % 32 == 0, "%s: F(4x4) needs Cout %% 128 == 0, H %% 8 == 0, W %% 32 == 0", what);
+  a.Kp = round_up(a.Cin, 16);
+  a.tiles_x = a.W / 32; a.tiles_y = a.H / 8; a.nblocks = a.B * a.tiles_x * a.tiles_y;
+  a.mtiles = a.Cout / 128;
+  CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
+  CAGC_REQUIRE((int64_t)36 * a.Kp * 128 * 4 < (1ll << 31), "%s: weight tile too large for 32-bit offsets", what);
+  size_t smem = sizeof(float) * (size_t)(2 * W4_VSZ + 2 * W4_RSZ);
+  const size_t exch = sizeof(float) * 8 * 4 * 4 * 4 * 64;     // [wave 8][a][r][lane] float4
+  if (smem < exch) smem = exch;
+  const bool sc = a.in_scale != nullptr;
+  const void* fn = gated ? (sc ? reinterpret_cast<const void*>(&k_wino4<true, true>) : reinterpret_cast<const void*>(&k_wino4<true, false>))
+                         : (sc ? reinterpret_cast<const void*>(&k_wino4<false, true>) : reinterpret_cast<const void*>(&k_wino4<false, false>));
+  static bool attr[4][64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int vi = (gated ? 2 : 0) + (sc ? 1 : 0);
+  if (dev >= 0 && dev < 64 && !attr[vi][dev]) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipGetLastError();
+    attr[vi][dev] = true;
+  }
+  dim3 grid((unsigned)(a.nblocks * a.mtiles));
+  if (gated) {
+    if (sc) hipLaunchKernelGGL((k_wino4<true, true>), grid, dim3(512), smem, st, a);
+    else hipLaunchKernelGGL((k_wino4<true, false>), grid, dim3(512), smem, st, a);
+  } else {
+    if (sc) hipLaunchKernelGGL((k_wino4<false, true>), grid, dim3(512), smem, st, a);
+    else hipLaunchKernelGGL((k_wino4<false, false>), grid, dim3(512), smem, st, a);
+  }
+  return check_launch(what);
+}
+
+}  // namespace cagc

@@ -15,6 +15,7 @@ struct PrepAllArgs {
   int Cout, Cin, kk;
   int Kp_f, Mp_f, Kp_b, Mp_b;           // packed dims fwd / bwd
   int wKp_f, wMB_f, wKp_b, wMB_b;       // Winograd packing dims
+  int f4_f, f4_b;                       // F(4x4) packing instead of F(2x2) (wino_use_f4)
   float scale;
 };
 
@@ -28,8 +29,14 @@ __global__ __launch_bounds__(256) void k_prep_all(const PrepAllArgs A) {
     case 0: pack_weights_elem(A.out[0], A.w, idx, A.Cout, A.Cin, A.kk, A.Kp_f, A.Mp_f, A.scale, 0); break;
     case 1: pack_weights_elem(A.out[1], A.w, idx, A.Cout, A.Cin, A.kk, A.Kp_b, A.Mp_b, A.scale, 1); break;
     case 2: wsq_elem(A.out[2], A.w, idx, A.kk, A.scale * A.scale); break;
-    case 3: wino_pack_elem(A.out[3], A.w, idx, A.Cout, A.Cin, A.wKp_f, A.wMB_f, A.scale, 0); break;
-    default: wino_pack_elem(A.out[4], A.w, idx, A.Cout, A.Cin, A.wKp_b, A.wMB_b, A.scale, 1); break;
+    case 3:
+      if (A.f4_f) wino4_pack_elem(A.out[3], A.w, idx, A.Cout, A.Cin, A.wKp_f, A.scale, 0);
+      else wino_pack_elem(A.out[3], A.w, idx, A.Cout, A.Cin, A.wKp_f, A.wMB_f, A.scale, 0);
+      break;
+    default:
+      if (A.f4_b) wino4_pack_elem(A.out[4], A.w, idx, A.Cout, A.Cin, A.wKp_b, A.scale, 1);
+      else wino_pack_elem(A.out[4], A.w, idx, A.Cout, A.Cin, A.wKp_b, A.wMB_b, A.scale, 1);
+      break;
   }
 }
 
@@ -51,8 +58,12 @@ extern "C" int cagc_modconv_prep_all(float* wp_fwd, float* wp_bwd, float* wsq, f
   a.n[0] = wp_fwd ? igemm_packed_total(a.kk, a.Kp_f, a.Mp_f) : 0;
   a.n[1] = wp_bwd ? igemm_packed_total(a.kk, a.Kp_b, a.Mp_b) : 0;
   a.n[2] = wsq ? (int64_t)Cout * Cin : 0;
-  a.n[3] = up_fwd ? (int64_t)cdiv(Cout, a.wMB_f * 16) * a.wKp_f * 64 : 0;
-  a.n[4] = up_bwd ? (int64_t)cdiv(Cin, a.wMB_b * 16) * a.wKp_b * 64 : 0;
+  a.f4_f = wino_use_f4(Cin, Cout) ? 1 : 0; a.f4_b = wino_use_f4(Cout, Cin) ? 1 : 0;
+  if (a.f4_f) a.wKp_f = wino4_kp(Cin);
+  if (a.f4_b) a.wKp_b = wino4_kp(Cout);
+  // elements = threads: one per (tile, K/4 group, lane, block) — each writes its 16 / 36 positions
+  a.n[3] = up_fwd ? (a.f4_f ? (int64_t)(Cout / 128) * a.wKp_f * 128 : (int64_t)cdiv(Cout, a.wMB_f * 16) * a.wKp_f * 64) : 0;
+  a.n[4] = up_bwd ? (a.f4_b ? (int64_t)(Cin / 128) * a.wKp_b * 128 : (int64_t)cdiv(Cin, a.wMB_b * 16) * a.wKp_b * 64) : 0;
   int64_t blocks = 0;
   for (int j = 0; j < 5; ++j) {
     blocks += (a.n[j] + 255) / 256;

