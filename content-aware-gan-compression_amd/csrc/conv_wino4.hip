@@ -11,7 +11,7 @@
 // Workgroup = 4 waves, ONE wave per SIMD (up to 512 registers), tile = 128 output channels x (8 x 32 output pixels = 2 x 8
 // Winograd tiles = one MFMA N-block).  Wave (I, J) owns the 3x3 block of positions i in 3I..3I+2, j in 3J..3J+2 for all 8
 // channel blocks: 72 accumulator tiles.  K runs in chunks of 8 input channels:
-//   A operand: transformed weights U pre-packed in MFMA register order [mtile][pos][K/4][lane][8 blocks], global / L2 -> VGPR
+//   A operand: transformed weights U pre-packed in MFMA register order [mtile][pos][K/4][channel half][lane][4 blocks], global / L2 -> VGPR
 //     (two 16-byte loads per (position, K-step) feed 8 MFMAs), a ring of half a chunk refilled in place;
 //   B operand: raw halo tile [8][10][40] --(registers)--> LDS (2 buffers) --B^T d B, half a patch (3 of the 6 transformed rows)
 //     per thread--> V[36][8][16] in LDS (2 buffers), one ds_read_b32 per 8 MFMAs.
@@ -69,6 +69,14 @@ __device__ __forceinline__ void w4_at3(const float m0, const float m1, const flo
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// debug builds only (-DCAGC_W4_ABL=bits, wrong results, timing only): 1 no input transform, 2 no commit / prefetch, 4 no A loads,
+// 8 no B reads, 16 no chunk barrier
+#ifdef CAGC_W4_ABL
+#define W4_ABL(bit) ((CAGC_W4_ABL & (bit)) != 0)
+#else
+#define W4_ABL(bit) false
+#endif
 
 // packed-fp32 helpers with half selection (VOP3P op_sel): the row stage of the input transform works on values paired along the
 // axis it mixes, so sums / differences of neighbouring elements take their operands from different register halves
@@ -223,13 +231,18 @@ __global__ __launch_bounds__(512, 1) void k_wino4(const WinoArgs A) {
   // ---- A operand ring: half a chunk = 9 (position, K-step) groups of ONE float4 (this wave's 4 channel blocks) ----------------
   const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(A.up) + (int64_t)mtile * 36 * KQ * 512, 0, 0x7fffffff, 0x00020000);
-  const unsigned ua_lane = (unsigned)lane * 32u + (unsigned)hb * 16u;
+  const unsigned ua_lane = (unsigned)lane * 16u + (unsigned)hb * 1024u;   // [half][lane][4 blocks]: one contiguous KB per wave and load
   auto a_soff = [&](int gi, int chunk) {
     const int p = gi >> 1, s = gi & 1;
     const int pos = (3 * WI + p / 3) * 6 + 3 * WJ + p % 3;
     return ((pos * KQ + 2 * chunk + s) * 512) * 4;
   };
-  float4 ring[6];      // a third of a chunk ahead (6 groups = 24 MFMAs of this wave, twice that in wall time next to its partner)
+#ifndef CAGC_W4_RING
+#define CAGC_W4_RING 6
+#endif
+  constexpr int RING = CAGC_W4_RING;   // groups the A operand is fetched ahead (6 = a third of a chunk: 24 MFMAs of this wave, twice that in
+                                       // wall time next to its partner; 9 measured no better: 0.86 vs 0.79 ms on 512->512 @64^2)
+  float4 ring[RING];
   auto load_a = [&](int slot, int gi, int chunk) {
     ring[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, ua_lane, a_soff(gi, chunk), 0));
   };
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(512, 1) void k_wino4(const WinoArgs A) {
   commit(raw + W4_RSZ);
   prefetch(2);
 #pragma unroll
-  for (int gi = 0; gi < 6; ++gi) load_a(gi, gi, 0);
+  for (int gi = 0; gi < RING; ++gi) load_a(gi, gi, 0);
   __syncthreads();
 
   // B operand of this wave: V[pos][4s + g][lm]; read one group ahead
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void k_wino4(const WinoArgs A) {
     const int p = gi >> 1, s = gi & 1;
     return ((6 * (p / 3) + p % 3) * CK + 4 * s) * 16;
   };
-  float bv_next = (v_lds + vb_wave)[b_off(0)];
+  float bv_cur = (v_lds + vb_wave)[b_off(0)], bv_nxt = (v_lds + vb_wave)[b_off(1)];
   // one chunk with the LDS buffer parity `cur` a compile-time constant: every LDS address in it is (one per-thread base
   // register) + (an immediate) — no address arithmetic next to the MFMAs; the K loop below runs two chunks per iteration
   auto chunk = [&](const int j, const int cur) {
@@ -272,26 +285,30 @@ __global__ __launch_bounds__(512, 1) void k_wino4(const WinoArgs A) {
     const int jn = (j + 1 < nch) ? j + 1 : j;           // last chunk: re-read valid weights instead of branching
 #pragma unroll
     for (int gi = 0; gi < 18; ++gi) {
-      const int p = gi >> 1, slot = gi % 6;
-      const float bv = bv_next;
-      if (gi < 17) bv_next = vb[b_off(gi + 1)];
+      const int p = gi >> 1, slot = gi % RING;
+      const float bv = bv_cur;
+      bv_cur = bv_nxt;
+      if (gi < 16 && !W4_ABL(8)) bv_nxt = vb[b_off(gi + 2)];      // B operand two groups ahead
       const float4 a0 = ring[slot];
       acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv, acc[p][0], 0, 0, 0);
       acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv, acc[p][1], 0, 0, 0);
       acc[p][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv, acc[p][2], 0, 0, 0);
       acc[p][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv, acc[p][3], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (gi + 6 < 18) load_a(slot, gi + 6, j);
-      else load_a(slot, gi + 6 - 18, jn);
-      if (xf && gi == 8) transform(rnext, vnext);   // chunk j+1's input transform; the partner wave's MFMAs cover its LDS latency
-      if (gi == 12) {                              // raw[cur] (chunk j) was transformed during chunk j-1: refill it with chunk j+2
+      if (!W4_ABL(4)) {
+        if (gi + RING < 18) load_a(slot, gi + RING, j);
+        else load_a(slot, gi + RING - 18, jn);
+      }
+      if (xf && gi == 8 && !W4_ABL(1)) transform(rnext, vnext);   // chunk j+1's input transform; the partner wave's MFMAs cover its LDS latency
+      if (gi == 12 && !W4_ABL(2)) {                // raw[cur] (chunk j) was transformed during chunk j-1: refill it with chunk j+2
         commit(raw + cur * W4_RSZ);
         prefetch(j + 3);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
-    bv_next = vbn[b_off(0)];
+    if (!W4_ABL(16)) __syncthreads();
+    bv_cur = vbn[b_off(0)];
+    bv_nxt = vbn[b_off(1)];
   };
   for (int j = 0; j < nch; j += 2) {     // Kp is a multiple of 16: an even number of chunks
     chunk(j, 0);

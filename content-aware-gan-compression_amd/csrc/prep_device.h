@@ -126,10 +126,13 @@ inline int wino4_kp(int K) { return round_up(K, 16); }     // two chunks of 8 pe
 inline int64_t wino4_packed_elems(int K, int M) { return (int64_t)(M / 128) * 36 * wino4_kp(K) * 128; }
 
 // U[pos=(i,j)][k][m] = scale * (G g G^T)[i][j], G the 6x3 matrix of F(4,3) (interpolation points 0, +-1, +-2, inf); stored in
-// MFMA A-operand order  up[mtile(128)][pos 36][K/4][lane = (k%4, m%16)][8 channel blocks];  idx over [mtiles][Kp/4][64][8]
+// MFMA A-operand order  up[mtile(128)][pos 36][K/4][channel half][lane = (k%4, m%16)][4 channel blocks];  idx over [mtiles][Kp/4][2][64][4]
 __device__ __forceinline__ void wino4_pack_elem(float* __restrict__ up, const float* __restrict__ w, int64_t idx, int Cout, int Cin,
                                                 int Kp, float scale, int dgrad) {
-  const int blk = (int)(idx & 7), ln = (int)((idx >> 3) & 63);
+  // per (mtile, pos, K/4 group): [channel half 2][lane 64][4 blocks] — the 4 blocks of a lane that ONE wave feeds to the MFMAs
+  // are 16 contiguous bytes and a wave's 64 lanes read one contiguous KB
+  const int b4 = (int)(idx & 3), ln = (int)((idx >> 2) & 63), half = (int)((idx >> 8) & 1);
+  const int blk = half * 4 + b4;
   const int kq = (int)((idx >> 9) % (Kp / 4)), mt = (int)((idx >> 9) / (Kp / 4));
   const int k = 4 * kq + (ln >> 4), m = mt * 128 + blk * 16 + (ln & 15);
   const int o = dgrad ? k : m, c = dgrad ? m : k;
@@ -150,7 +153,7 @@ __device__ __forceinline__ void wino4_pack_elem(float* __restrict__ up, const fl
 #pragma unroll
     for (int bb = 0; bb < 3; ++bb) t[i][bb] = G[i][0] * gk[0][bb] + G[i][1] * gk[1][bb] + G[i][2] * gk[2][bb];
   const int64_t ps = (int64_t)(Kp / 4) * 512;                                   // stride between positions
-  float* dst = up + ((int64_t)mt * 36 * (Kp / 4) + kq) * 512 + ln * 8 + blk;
+  float* dst = up + ((int64_t)mt * 36 * (Kp / 4) + kq) * 512 + half * 256 + ln * 4 + b4;
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
