@@ -928,7 +928,8 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
     RawItem uni[4];
     for (int ph = 0; ph < 4; ++ph) uni[ph] = RawItem{items[ph].ntaps, taps[ph], ph, 0, 0, H + 1, W + 1};
     ConvArgs au = a;
-    const int rd = run_conv_rd(au, uni, 4, st, what);
+    static const char* only = getenv("CAGC_UP_PHASE");      // timing aid (scripts/time_upfwd.py): one parity alone
+    const int rd = only ? run_conv_rd(au, uni + (atoi(only) & 3), 1, st, what) : run_conv_rd(au, uni, 4, st, what);
     if (rd != CAGC_RD_DECLINED) return rd;
   }
   bool small = (int64_t)B * H * W <= 32768;   // only small layers are ever split over K
