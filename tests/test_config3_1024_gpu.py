@@ -136,6 +136,20 @@ def test_kd_step_1024_properties():
         # (one flipped gate moves a 3x3 patch of a gradient by O(1e-3) of its scale).  Observed over repeated runs
         # of this test: 1e-5 .. 9e-4; the bound is the parity bar's order, not a rounding bound.
         assert_close(a, b + c, 3e-3 if a.numel() > 1 else 2e-2, "additivity " + p[0])   # single-element sums of 10^7 atomically accumulated terms
+    # the same property in deterministic mode (no fp32-atomic K split: the three forward passes are bit-identical, so are
+    # their gates): additivity to summation-order rounding of the backward reductions — the 3e-3 above is gate flips only
+    from cagc import _lib
+    _lib.call("cagc_set_tuning", b"deterministic", 1)
+    try:
+        _, _, img_d, d_all = grads(1.0, 1.0)
+        _, _, img_d2, d_g = grads(1.0, 0.0)
+        _, _, _, d_k = grads(0.0, 1.0)
+    finally:
+        _lib.call("cagc_set_tuning", b"deterministic", 0)
+    assert torch.equal(img_d, img_d2), "deterministic mode: forward not bit-reproducible"
+    for p, a, b, c in zip(student.named_parameters(), d_all, d_g, d_k):
+        if a is not None:
+            assert_close(a, b + c, 1e-4 if a.numel() > 1 else 2e-3, "additivity (deterministic mode) " + p[0])
     with torch.no_grad():
         one = student([z[1:2] for z in zs], inject_index=7, noise=[n[1:2] for n in sn])
         assert_close(one, img[1:2], 1e-5, "student batch independence")

@@ -425,10 +425,22 @@ def test_pruned_1024_generator_vs_oracle_image_and_grads():
         return img.detach(), torch.autograd.grad((img * proj.to(dtype)).mean(), [leaves[k] for k in names], allow_unused=True)
 
     img32, g32 = ref(torch.float32)
-    img64, g64 = ref(torch.float64)
+    with ref_ops.gates() as rec:
+        img64, g64 = ref(torch.float64)
     assert tuple(img64.shape) == (1, 3, 1024, 1024)
     netg = net.to(DEV)
+    # the HIP run's LeakyReLU gates in the oracle's call order: mapping network of z0, of z1 (the product maps the stacked
+    # latents in one pass: rows 0 / 1 of each layer's output), then the 17 styled convs
+    acts_map, acts_conv, hooks = [], [], []
+    for m in netg.style:
+        if isinstance(m, M.EqualLinear):
+            hooks.append(m.register_forward_hook(lambda mod, inp, out: acts_map.append(out.detach())))
+    for m in [netg.conv1] + list(netg.convs):
+        hooks.append(m.register_forward_hook(lambda mod, inp, out: acts_conv.append((out[0] if isinstance(out, tuple) else out).detach())))
     img_g = netg([cu(z[0]), cu(z[1])], inject_index=7, randomize_noise=False)
+    for h in hooks:
+        h.remove()
+    gates_g = [(a[:1] > 0).cpu() for a in acts_map] + [(a[1:] > 0).cpu() for a in acts_map] + [(a > 0).cpu() for a in acts_conv]
     rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-300))
     assert rel(img_g.detach(), img64) <= TOL, "image 1024"
     (img_g * cu(proj)).mean().backward()
@@ -441,6 +453,20 @@ def test_pruned_1024_generator_vs_oracle_image_and_grads():
         e_gpu, e_cpu = rel(a, b64), rel(b32, b64)
         bar = max(5e-3, 3 * e_cpu) if b64.numel() > 1 else max(5e-2, 5 * e_cpu)   # noise.weight: one cancelling sum over up to 10^6 pixels
         assert e_gpu <= bar, f"grad {k}: HIP vs float64 {e_gpu:.2e}, fp32 CPU reference vs float64 {e_cpu:.2e}"
+    # ... and the north-star bar proper, on the common gate pattern: every gate where the HIP run and float64
+    # disagree sits at rounding level of its layer; float64 evaluated on the HIP run's pattern then agrees with every
+    # gradient to 5e-5 (observed 6.5e-6; single-element cancelling sums 1e-3) — what the 5e-3 above leaves room for is gate flips only
+    n_dis = ref_ops.gate_disagreements(rec, gates_g, rounding=1e-5, max_fraction=1e-5)
+    with ref_ops.gates(force=gates_g):
+        _, g64f = ref(torch.float64)
+    worst = 0.0
+    for k, b in zip(names, g64f):
+        if b is None:
+            continue
+        e = rel(params[k].grad, b)
+        worst = max(worst, e if b.numel() > 1 else 0.0)
+        assert e <= (5e-5 if b.numel() > 1 else 1e-3), f"grad {k} on the common gate pattern ({n_dis} disagreements): {e:.2e}"
+    print(f"1024 px student: {n_dis} gate disagreements with float64, worst tensor gradient error on the common pattern {worst:.2e}")
 
 
 @pytest.mark.parametrize("cfg", [(154, 154, 4, True, 16), (154, 154, 8, False, 1), (154, 154, 16, True, 1),
