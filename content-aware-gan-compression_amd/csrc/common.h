@@ -33,6 +33,33 @@ int zero_fill(void* ptr, size_t bytes, hipStream_t st);
 // see api_common.hip
 int& deterministic_mode();
 
+// ---- order-independent accumulation for the backward reductions (deterministic mode) -----------------------------------
+// The reductions that many workgroups add into one float (grad-bias sums, the styled epilogue's [3,B,C] sums, the style
+// gradient `gs`, ToRGB's weight sums, the L1 loss) use fp32 atomics: fast, but the order of the additions — and so the last
+// bits of the result — changes run to run.  In deterministic mode they go through a DetSink instead: each contribution is
+// split EXACTLY into two fixed-point parts (v = hi * 2^-20 + lo * 2^-59, hi / lo integers) that are added with 64-bit integer
+// atomics — integer addition is associative, so the sum does not depend on the order — and a finishing kernel adds the
+// exact total to the destination.  Exact for |v| < 2^32 down to 2^-59; sums must stay below 2^43 (anything else, inf and
+// nan included, falls back to the fp32 atomic so that it still propagates).
+struct DetSink {
+  long long* acc;        // [n][2] zeroed scratch, nullptr = plain fp32 atomics
+  const float* base;     // destination element 0
+};
+__device__ __forceinline__ void sink_add(const DetSink& k, float* dst, float v) {
+  if (!k.acc || !(fabsf(v) < 4.0e9f)) { atomicAdd(dst, v); return; }
+  const int64_t i = dst - k.base;
+  const double d = (double)v;
+  const long long hi = __double2ll_rn(d * 1048576.0);                       // 2^20
+  const double rest = d - (double)hi * (1.0 / 1048576.0);                   // exact; |rest| <= 2^-21
+  const long long lo = __double2ll_rn(rest * 576460752303423488.0);         // 2^59: |lo| <= 2^38
+  if (hi) atomicAdd(reinterpret_cast<unsigned long long*>(k.acc + 2 * i), (unsigned long long)hi);
+  if (lo) atomicAdd(reinterpret_cast<unsigned long long*>(k.acc + 2 * i + 1), (unsigned long long)lo);
+}
+// host side (api_common.hip): det_begin hands out the stream's zeroed scratch for a destination of n floats (sink.acc stays
+// nullptr when deterministic mode is off); det_end adds the exact sums to base[0..n) in a fixed order
+int det_begin(DetSink& k, const float* base, int64_t n, hipStream_t st, const char* what);
+int det_end(const DetSink& k, float* base, int64_t n, hipStream_t st, const char* what);
+
 inline hipStream_t as_stream(cagc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

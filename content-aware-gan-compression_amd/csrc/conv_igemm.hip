@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
             gpart[i][r] += ok ? v * xv : 0.f;
           } else {
             const float part = group16_sum(ok ? v * xv : 0.f);
-            if (lm == 0 && m < A.Cout && bl < A.B && part != 0.f) atomicAdd(A.gs + (int64_t)bl * A.Cout + m, part);
+            if (lm == 0 && m < A.Cout && bl < A.B && part != 0.f) sink_add(A.det_gs, A.gs + (int64_t)bl * A.Cout + m, part);
           }
         }
         if (ok) {
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, (((NV <= 4 || (NV <= 12 && MB <= 4)) && !(GS &
     __syncthreads();
     if (tid < MT && m0 + tid < A.Cout && b0 < A.B) {
       const float p = red[tid] + red[MT + tid] + red[2 * MT + tid] + red[3 * MT + tid];
-      atomicAdd(A.gs + (int64_t)b0 * A.Cout + m0 + tid, p);
+      sink_add(A.det_gs, A.gs + (int64_t)b0 * A.Cout + m0 + tid, p);
     }
   }
 }
@@ -995,7 +995,10 @@ extern "C" int cagc_modconv_dgrad(float* gx, float* gs, const float* gz, const f
   for (int ky = 0; ky < ksize; ++ky)
     for (int kx = 0; kx < ksize; ++kx) taps[n++] = RawTap{0, r - ky, r - kx, ky * ksize + kx};
   RawItem it{n, taps, 0, 0, 0, H, W};
-  return run_conv(a, &it, 1, as_stream(stream), what);
+  { const int drc = det_begin(a.det_gs, gs, (int64_t)B * Cin, as_stream(stream), what); if (drc) return drc; }
+  const DetSink det = a.det_gs;
+  { const int rc = run_conv(a, &it, 1, as_stream(stream), what); if (rc) return rc; }
+  return det_end(det, gs, (int64_t)B * Cin, as_stream(stream), what);
 }
 
 extern "C" int cagc_modconv_up_dgrad(float* gx, float* gs, const float* gt, const float* wp, const float* s,
@@ -1015,7 +1018,10 @@ extern "C" int cagc_modconv_up_dgrad(float* gx, float* gs, const float* gt, cons
   for (int ky = 0; ky < 3; ++ky)
     for (int kx = 0; kx < 3; ++kx) taps[n++] = RawTap{(ky & 1) * 2 + (kx & 1), ky / 2, kx / 2, ky * 3 + kx};
   RawItem it{n, taps, 0, 0, 0, H, W};
-  return run_conv(a, &it, 1, as_stream(stream), what);
+  { const int drc = det_begin(a.det_gs, gs, (int64_t)B * Cin, as_stream(stream), what); if (drc) return drc; }
+  const DetSink det = a.det_gs;
+  { const int rc = run_conv(a, &it, 1, as_stream(stream), what); if (rc) return rc; }
+  return det_end(det, gs, (int64_t)B * Cin, as_stream(stream), what);
 }
 
 

@@ -41,6 +41,7 @@ struct ConvArgs {
   const float* bias;
   const float* aux_x;  // dgrad: x at the output positions, for the gs reduction
   float* gs;           // [B,Cout-of-this-GEMM], accumulated
+  DetSink det_gs;      // deterministic mode: gs goes through the order-independent sink (common.h)
   int B, Cin, Kp, Cout, Mp;
   int kk;                      // taps of the packed weights (1 or 9): locates the register-direct layout behind the first one
   int NPin, Hin, Win, Wpitch;  // input planes per channel, valid plane dims, row pitch (floats)

@@ -52,6 +52,7 @@ struct RdArgs {
   const float* bias;
   const float* aux_x;            // dgrad: x at the output positions, for the gs reduction
   float* gs;                     // [B, Cout-of-this-GEMM], accumulated (one atomic per workgroup and channel)
+  DetSink det_gs;                // deterministic mode: through the order-independent sink (common.h)
   int B, Cin, KQ, Cout, MBLK;    // KQ = Kp/4 K-steps (even), MBLK = Mp/16 channel blocks
   int a_tile_bytes, a_kq_bytes, a_tap_bytes;   // strides of the register-direct weight layout [t][KQ][tile][64 lanes][PB]
   int a_lane_bytes, a_split;     // bytes per lane (PB*4); workgroup tiles per packed tile (8-block tiles run as 2 x 4 / 4 x 2 blocks)
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
           pr = group16_sum(pr);
           const int bl = __shfl(b, lane & 48, 64);
           const bool okl = __shfl(pok[j] ? 1 : 0, lane & 48, 64) != 0;
-          if (lm == 0 && okl && m < A.Cout) atomicAdd(A.gs + (int64_t)bl * A.Cout + m, pr);
+          if (lm == 0 && okl && m < A.Cout) sink_add(A.det_gs, A.gs + (int64_t)bl * A.Cout + m, pr);
         }
       }
     }
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
     __syncthreads();
     if (tid < MT && m0 + tid < A.Cout && b0 < A.B) {
       const float p = red[tid] + red[MT + tid] + red[2 * MT + tid] + red[3 * MT + tid];
-      atomicAdd(A.gs + (int64_t)b0 * A.Cout + m0 + tid, p);
+      sink_add(A.det_gs, A.gs + (int64_t)b0 * A.Cout + m0 + tid, p);
     }
   }
 }
@@ -440,7 +441,7 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
   RdArgs r;
   memset(&r, 0, sizeof(r));
   r.in = a.in; r.out = a.out; r.wp = a.wp; r.in_scale = a.in_scale; r.out_scale = a.out_scale;
-  r.noise = a.noise; r.noise_w = a.noise_w; r.bias = a.bias; r.aux_x = a.aux_x; r.gs = a.gs;
+  r.noise = a.noise; r.noise_w = a.noise_w; r.bias = a.bias; r.aux_x = a.aux_x; r.gs = a.gs; r.det_gs = a.det_gs;
   r.B = a.B; r.Cin = a.Cin; r.KQ = a.Kp / 4; r.Cout = a.Cout; r.MBLK = nblk;
   r.NPin = a.NPin; r.Hin = a.Hin; r.Win = a.Win; r.Wpitch = a.Wpitch; r.isy = a.isy; r.isx = a.isx;
   r.NPout = a.NPout; r.Hout = a.Hout; r.Wout = a.Wout; r.Wopitch = a.Wopitch; r.osy = a.osy; r.osx = a.osx;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_bias_act_plane(float* __restrict
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ ref, float* __restrict__ gsum,
                                                                int C, int64_t inner, int nchunk, float alpha,
-                                                               float scale) {
+                                                               float scale, const DetSink det) {
   __shared__ float sm[4];
   const int plane = blockIdx.x / nchunk;
   const int chunk = blockIdx.x - plane * nchunk;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_bias_act_plane(float* __restrict
   }
   if (MODE == 1 && gsum) {
     const float s = block_sum(acc, sm);
-    if (threadIdx.x == 0) atomicAdd(gsum + c, s);
+    if (threadIdx.x == 0) sink_add(det, gsum + c, s);
   }
 }
 
@@ -141,12 +141,16 @@ static int launch_bias_act(float* out, const float* a, const float* bias, const 
     const int64_t nb = outer * C * nchunk;
     CAGC_REQUIRE(nb < (1ll << 31), "%s: too large", what);
     const bool vec = (inner % 4 == 0) && (((uintptr_t)out | (uintptr_t)a | (uintptr_t)ref) % 16 == 0);
+    DetSink det;
+    { const int drc = det_begin(det, MODE == 1 ? gsum : nullptr, C, st, what); if (drc) return drc; }
     if (vec)
       hipLaunchKernelGGL((k_bias_act_plane<MODE, true>), dim3((unsigned)nb), dim3(EW_THREADS), 0, st, out, a, bias, ref,
-                         gsum, (int)C, inner, nchunk, alpha, scale);
+                         gsum, (int)C, inner, nchunk, alpha, scale, det);
     else
       hipLaunchKernelGGL((k_bias_act_plane<MODE, false>), dim3((unsigned)nb), dim3(EW_THREADS), 0, st, out, a, bias, ref,
-                         gsum, (int)C, inner, nchunk, alpha, scale);
+                         gsum, (int)C, inner, nchunk, alpha, scale, det);
+    { const int drc = check_launch(what); if (drc) return drc; }
+    return det_end(det, gsum, C, st, what);
   }
   return check_launch(what);
 }
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_styled_act_bwd(float* __restrict
                                                                const float* __restrict__ d,
                                                                const float* __restrict__ noise, int noise_bstride_on,
                                                                int B, int C, int64_t HW, int nchunk, float alpha,
-                                                               float act_scale) {
+                                                               float act_scale, const DetSink det) {
   __shared__ float sm[4];
   const int plane = blockIdx.x / nchunk;  // b*C + c
   const int chunk = blockIdx.x - plane * nchunk;
@@ -205,9 +209,9 @@ __global__ __launch_bounds__(EW_THREADS) void k_styled_act_bwd(float* __restrict
   const float s2 = block_sum(r2, sm);
   if (threadIdx.x == 0) {
     const int64_t BC = (int64_t)B * C;
-    atomicAdd(red + plane, s0);
-    atomicAdd(red + BC + plane, s1);
-    atomicAdd(red + 2 * BC + plane, s2);
+    sink_add(det, red + plane, s0);
+    sink_add(det, red + BC + plane, s1);
+    sink_add(det, red + 2 * BC + plane, s2);
   }
 }
 
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(256) void k_demod_bwd_w(float* __restrict__ gwsq, c
 __global__ __launch_bounds__(EW_THREADS) void k_masked_l1(float* __restrict__ loss_sum, float* __restrict__ gs,
                                                           const float* __restrict__ t, const float* __restrict__ s,
                                                           const float* __restrict__ mask, int C, int64_t HW, int nchunk,
-                                                          float coef) {
+                                                          float coef, const DetSink det) {
   __shared__ float sm[4];
   const int plane = blockIdx.x / nchunk;  // b*C + c
   const int chunk = blockIdx.x - plane * nchunk;
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_masked_l1(float* __restrict__ lo
     }
   }
   const float tot = block_sum(acc, sm);
-  if (threadIdx.x == 0) atomicAdd(loss_sum, tot);
+  if (threadIdx.x == 0) sink_add(det, loss_sum, tot);
 }
 
 }  // namespace cagc
@@ -372,13 +376,16 @@ extern "C" int cagc_styled_act_bwd(float* gz, float* red, const float* gout, con
   const int64_t nb = (int64_t)B * C * nchunk;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_styled_act_bwd: too large");
   const bool vec = (HW % 4 == 0) && (((uintptr_t)gz | (uintptr_t)gout | (uintptr_t)out | (uintptr_t)noise) % 16 == 0);
+  DetSink det;
+  { const int drc = det_begin(det, red, 3 * (int64_t)B * C, st, "cagc_styled_act_bwd"); if (drc) return drc; }
   if (vec)
     hipLaunchKernelGGL((k_styled_act_bwd<true>), dim3((unsigned)nb), dim3(EW_THREADS), 0, st, gz, red, gout, out, d,
-                       noise, noise_batch == B ? 1 : 0, B, C, HW, nchunk, alpha, act_scale);
+                       noise, noise_batch == B ? 1 : 0, B, C, HW, nchunk, alpha, act_scale, det);
   else
     hipLaunchKernelGGL((k_styled_act_bwd<false>), dim3((unsigned)nb), dim3(EW_THREADS), 0, st, gz, red, gout, out, d,
-                       noise, noise_batch == B ? 1 : 0, B, C, HW, nchunk, alpha, act_scale);
-  return check_launch("cagc_styled_act_bwd");
+                       noise, noise_batch == B ? 1 : 0, B, C, HW, nchunk, alpha, act_scale, det);
+  { const int drc = check_launch("cagc_styled_act_bwd"); if (drc) return drc; }
+  return det_end(det, red, 3 * (int64_t)B * C, st, "cagc_styled_act_bwd");
 }
 
 extern "C" int cagc_pixelnorm_fwd(float* y, const float* x, int64_t rows, int dim, cagc_stream_t stream) {
@@ -416,7 +423,7 @@ extern "C" int cagc_demod_bwd(float* gs, float* gwsq, const float* gd, const flo
 // workgroup.
 __global__ __launch_bounds__(EW_THREADS) void k_scale_reduce(float* __restrict__ gx, const float* __restrict__ x,
                                                              const float* __restrict__ s, float* __restrict__ gs,
-                                                             int64_t HW, int nchunk) {
+                                                             int64_t HW, int nchunk, const DetSink det) {
   __shared__ float sm[4];
   const int plane = blockIdx.x / nchunk;
   const int chunk = blockIdx.x - plane * nchunk;
@@ -443,7 +450,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_scale_reduce(float* __restrict__
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0 && gs) atomicAdd(gs + plane, (sm[0] + sm[1]) + (sm[2] + sm[3]));
+  if (threadIdx.x == 0 && gs) sink_add(det, gs + plane, (sm[0] + sm[1]) + (sm[2] + sm[3]));
 }
 extern "C" int cagc_scale_reduce(float* gx, const float* x, const float* s, float* gs, int B, int C, int64_t HW,
                                  cagc_stream_t stream) {
@@ -453,8 +460,11 @@ extern "C" int cagc_scale_reduce(float* gx, const float* x, const float* s, floa
   const int nchunk = (int)cdiv(HW, (int64_t)EW_CHUNK);
   const int64_t nb = (int64_t)B * C * nchunk;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_scale_reduce: too large");
-  hipLaunchKernelGGL(k_scale_reduce, dim3((unsigned)nb), dim3(EW_THREADS), 0, as_stream(stream), gx, x, s, gs, HW, nchunk);
-  return check_launch("cagc_scale_reduce");
+  DetSink det;
+  { const int drc = det_begin(det, gs, (int64_t)B * C, as_stream(stream), "cagc_scale_reduce"); if (drc) return drc; }
+  hipLaunchKernelGGL(k_scale_reduce, dim3((unsigned)nb), dim3(EW_THREADS), 0, as_stream(stream), gx, x, s, gs, HW, nchunk, det);
+  { const int drc = check_launch("cagc_scale_reduce"); if (drc) return drc; }
+  return det_end(det, gs, (int64_t)B * C, as_stream(stream), "cagc_scale_reduce");
 }
 
 // out = (a + b) * scale — the residual merge of the discriminator's ResBlock ((conv path + skip) / sqrt(2), reference
@@ -486,9 +496,12 @@ extern "C" int cagc_masked_l1(float* loss_sum, float* gs, const float* t, const 
   const int nchunk = cdiv(HW, EW_CHUNK);
   const int64_t nb = (int64_t)B * C * nchunk;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_masked_l1: too large");
+  DetSink det;
+  { const int drc = det_begin(det, loss_sum, 1, as_stream(stream), "cagc_masked_l1"); if (drc) return drc; }
   hipLaunchKernelGGL(k_masked_l1, dim3((unsigned)nb), dim3(EW_THREADS), 0, as_stream(stream), loss_sum, gs, t, s, mask, C,
-                     HW, nchunk, coef);
-  return check_launch("cagc_masked_l1");
+                     HW, nchunk, coef, det);
+  { const int drc = check_launch("cagc_masked_l1"); if (drc) return drc; }
+  return det_end(det, loss_sum, 1, as_stream(stream), "cagc_masked_l1");
 }
 
 // Phase-planar re-layout of an odd-sized plane stack: x [planes, 2H+1, 2W+1] (row pitch in_pitch) ->

@@ -187,7 +187,7 @@ constexpr int RGB_CCH = 8;  // channels per workgroup in the backward
 __global__ __launch_bounds__(256) void k_torgb_bwd(float* __restrict__ gx, float* __restrict__ gws,
                                                    const float* __restrict__ g, const float* __restrict__ x,
                                                    const float* __restrict__ w, const float* __restrict__ s, int C,
-                                                   int64_t HW, int nchunk, int nsplit, float scale) {
+                                                   int64_t HW, int nchunk, int nsplit, float scale, const DetSink det) {
   __shared__ float red[4][3 * RGB_CCH];
   int bid = blockIdx.x;
   const int sp = bid % nsplit; bid /= nsplit;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_torgb_bwd(float* __restrict__ gx, float
     const int c = c0 + k;
     if (c < C) {
       const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-      atomicAdd(gws + ((int64_t)b * 3 + o) * C + c, v);
+      sink_add(det, gws + ((int64_t)b * 3 + o) * C + c, v);
     }
   }
 }
@@ -283,9 +283,12 @@ extern "C" int cagc_torgb_bwd(float* gx, float* gws, const float* g, const float
   const int maxsplit = cdiv(HW, 1024);
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
+  DetSink det;
+  { const int drc = det_begin(det, gws, (int64_t)B * 3 * C, st, what); if (drc) return drc; }
   hipLaunchKernelGGL(k_torgb_bwd, dim3((unsigned)(B * nchunk * nsplit)), dim3(256), 0, st, gx, gws, g, x, w, s, C, HW,
-                     nchunk, nsplit, scale);
-  return check_launch(what);
+                     nchunk, nsplit, scale, det);
+  { const int drc = check_launch(what); if (drc) return drc; }
+  return det_end(det, gws, (int64_t)B * 3 * C, st, what);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
