@@ -51,7 +51,9 @@ const char* cagc_last_error(void);
  * never depend on it beyond fp32 summation order).  Keys: "rd" (0 = LDS-staged kernel only), "rd_min_wgs", "rd_mb", "rd_kw",
  * "rd_split", "rd_atomic_below", "rd_split_wgs" — see csrc/conv_rd.hip; "wgrad_rd" (0 = LDS-staged weight-gradient kernels
  * only), "wgrad_rd_wgs" — csrc/conv_wgrad_rd.hip; "deterministic" (also CAGC_DETERMINISTIC=1): no fp32-atomic K split in the
- * convolution kernels — forward passes become bit-reproducible run to run (slower at small per-GPU batch).  The same knobs are read from CAGC_RD* at first use. */
+ * convolution kernels, and the backward reductions (grad-bias / styled-epilogue / style / ToRGB weight sums, L1 loss) through an
+ * order-independent fixed-point sink on a library-owned per-stream scratch — forward passes AND gradients become
+ * bit-reproducible run to run (slower at small per-GPU batch).  The same knobs are read from CAGC_RD* at first use. */
 int cagc_set_tuning(const char* key, int value);
 /* "gfx950" — the only architecture the library is built for. */
 const char* cagc_arch(void);
