@@ -80,8 +80,9 @@ class _nullctx:
 
 
 # CAGC_SIDE_WGRAD: elements of the layer's larger activation below which the student's weight gradient runs on a side stream
-# (0 = never).  Default 2^24 elements (measured, graph replay: batch 16 35.39 -> 35.11 ms, per-GPU batch 2 7.98 -> 7.83 ms).
-_SIDE_LIMIT = int(os.environ.get("CAGC_SIDE_WGRAD", str(1 << 24)))
+# (0 = never).  Default: every layer (measured, graph replay, batch 16: never 32.90, <= 2^24 elements 32.70, all layers 32.48 ms —
+# the weight gradient's workgroups fill the tail of the data-gradient launch it runs beside; per-GPU batch 2: 7.98 -> 7.83 ms).
+_SIDE_LIMIT = int(os.environ.get("CAGC_SIDE_WGRAD", str(1 << 40)))
 _side_streams = {}
 
 
@@ -267,7 +268,7 @@ class _ModConv(Function):
                           B, cin, cout)
             # Small launches (low resolutions, small per-GPU batches) leave most of the 256 CUs idle: the weight gradient — which
             # nothing else in this node depends on — then runs on a side stream next to the data gradient (fork / join become
-            # graph dependencies under HIP-graph capture; at batch 16 the big layers fill the chip on their own and it is off)
+            # graph dependencies under HIP-graph capture)
             side = None
             if need_w and (need_x or need_s) and _side_stream_small(B * max(cin, cout) * Ho * Wo):
                 main = torch.cuda.current_stream()
@@ -706,6 +707,16 @@ class _ResBlockFrozen(Function):
         dev = g.device
         scale = 1.0 / SQRT2
         with _lib.on_device(g):
+            # skip branch, first half: the 1x1 data gradient W_skip^T @ g[b] (library SGEMM) depends on g alone — it runs on the
+            # side stream next to the conv branch (its workgroups fill the tails of that chain's launches) and joins in front
+            # of the adjoint FIR that adds it onto gx
+            side = None
+            if _SIDE_LIMIT > 0:
+                main = torch.cuda.current_stream()
+                side = _side_stream(dev)
+                side.wait_stream(main)
+            with (torch.cuda.stream(side) if side is not None else _nullctx()):
+                gy = torch.matmul(wpsk_bwd, g.view(B, cout, ho * wo)).view(B, C, ho, wo)
             # conv branch: activation backward carrying the 1/sqrt2, stride-2 data gradient, adjoint blur
             gz2 = torch.empty_like(g)
             _lib.call("cagc_fused_bias_act_bwd", _lib.ptr(gz2), None, _lib.ptr(g), _lib.ptr(y2a), B, cout, ho * wo, 0.2, SQRT2 * scale)
@@ -721,10 +732,14 @@ class _ResBlockFrozen(Function):
             _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(g1), _lib.ptr(y1), _lib.ptr(up1_bwd), None,
                       B, C, C, H, W, 0.2, SQRT2)
             del g1
-            # skip branch: 1x1 data gradient, then the adjoint of the decimating FIR (the merge's 1/sqrt2 in its taps) added
-            # onto gx in the same streaming pass.  (Adding it inside the Winograd kernel's store instead was measured: +0.4 ms
-            # on that MFMA-bound kernel's un-overlapped epilogue for the 0.36 ms pass it saved — bench_r2_i.)
-            gy = torch.matmul(wpsk_bwd, g.view(B, cout, ho * wo)).view(B, C, ho, wo)      # W_skip^T @ g[b]: library SGEMM
+            # skip branch, second half: the adjoint of the decimating FIR (the merge's 1/sqrt2 in its taps) added onto gx in
+            # the same streaming pass.  (Adding it inside the Winograd kernel's store instead was measured: +0.4 ms on that
+            # MFMA-bound kernel's un-overlapped epilogue for the 0.36 ms pass it saved — bench_r2_i.)
+            if side is not None:
+                main.wait_stream(side)
+                gy.record_stream(main)       # allocated on the side stream, consumed on the main one
+                g.record_stream(side)
+                wpsk_bwd.record_stream(side)
             gp = (4 - padsk[0] - 1, W - 2 * wo + padsk[0], 4 - padsk[0] - 1, H - 2 * ho + padsk[0])
             if gp == (2, 1, 2, 1) and W % 4 == 0:
                 _lib.call("cagc_fir4x4_up2_acc", _lib.ptr(gx), _lib.ptr(gy), _lib.ptr(_flipped_scaled(firsk, scale)), _lib.ptr(gx),
