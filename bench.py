@@ -103,7 +103,7 @@ KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false, false", "c
              "cagc_wino_conv3x3[k_wino<4, false, NH2>]": "k_wino<4, false, false, 2>", "cagc_wino_conv3x3[k_wino<4, false, NH1>]": "k_wino<4, false, false, 1>",
              "cagc_wino_conv3x3[k_wino<3, false, NH1>]": "k_wino<3, false, false, 1>", "cagc_wino_conv3x3[k_wino<3, false, NH2>]": "k_wino<3, false, false, 2>",
              "cagc_wino_conv3x3_act_dgrad[k_wino<4, true, NH2>]": "k_wino<4, true, false, 2>", "cagc_wino_conv3x3_act_dgrad[k_wino<4, true, NH1>]": "k_wino<4, true, false, 1>",
-             "cagc_wino_conv3x3[k_wino4<false>]": "k_wino4<false>", "cagc_wino_conv3x3_act_dgrad[k_wino4<true>]": "k_wino4<true>",
+             "cagc_wino_conv3x3[k_wino4<false>]": "k_wino4<false,", "cagc_wino_conv3x3_act_dgrad[k_wino4<true>]": "k_wino4<true,",   # both SCALE variants
              "cagc_modconv_fwd": "k_conv_rd<4, true, true, false>",
              "cagc_modconv_up_fwd": "k_conv_rd<8, true, true, false>",
              "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_dgrad": "k_conv_rd<8, true, false, false>",
@@ -113,13 +113,15 @@ KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false, false", "c
 
 
 def pmc_traffic(symbol):
-    """HBM-side bytes per launch of `symbol` from the committed rocprofv3 PMC passes (profiles/r01_pmc_*.md; separate
+    """HBM-side bytes per launch of `symbol` from the committed rocprofv3 PMC passes (profiles/r0N_pmc_*.md, newest round; separate
     --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same bench, counters in KB).  gfx950 correction
     (MI355X_MICROARCH.md §HBM, re-calibrated here on the bias+act stream kernel whose byte count is known exactly:
     FETCH_SIZE reads 0.50x, WRITE_SIZE 1.00x of the true bytes): bytes = 2*FETCH + WRITE."""
+    if SIZE != 256:
+        return None, "the committed PMC passes profile the 256 px workload"
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_{c}.md") for r in ("r02", "r01")) if os.path.exists(q)), None)
+        path = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_{c}.md") for r in ("r03", "r02", "r01")) if os.path.exists(q)), None)
         if path is None:
             return None, "no committed PMC summary"
         for line in open(path):
