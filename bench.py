@@ -33,13 +33,15 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 3
 PEAK_HBM_GBS = 8000.0
 
 
-def wino_f4(k_ch, m_ch):
-    """csrc/prep_device.h wino_use_f4: the layer runs on the F(4x4,3x3) kernel (conv_wino4.hip)."""
-    return os.environ.get("CAGC_WINO_F4", "1") != "0" and m_ch % 128 == 0 and k_ch >= 128
+def wino_f4(k_ch, m_ch, B, H, W):
+    """csrc/prep_device.h wino4_for_launch: this launch runs on the F(4x4,3x3) kernel (conv_wino4.hip) — eligible layer
+    (K, M >= 128) whose grid of 64-channel x 8x32-pixel workgroups fills the chip; otherwise F(2x2,3x3)."""
+    return (os.environ.get("CAGC_WINO_F4", "1") != "0" and m_ch >= 128 and k_ch >= 128
+            and B * (H // 8) * (W // 32) * (-(-m_ch // 64)) >= int(os.environ.get("CAGC_WINO4_MIN_WGS", "256")))
 
 
-def wino_macs(k_ch, m_ch):
-    return 2.25 if wino_f4(k_ch, m_ch) else 4.0
+def wino_macs(k_ch, m_ch, B, H, W):
+    return 2.25 if wino_f4(k_ch, m_ch, B, H, W) else 4.0
 
 
 def conv_flops(name, a):
@@ -64,10 +66,10 @@ def conv_flops(name, a):
         return 2.0 * B * cin * cout * k * k * H * W
     if name == "cagc_wino_conv3x3":      # (out,x,up,s,B,Cin,Cout,H,W,...): Winograd — count the flops the MFMA pipe EXECUTES
         B, cin, cout, H, W = a[4:9]      # (F(2x2,3x3): 16 GEMMs over H/2*W/2 tiles = 4 MACs per output pixel and channel pair;
-        return 2.0 * B * cin * cout * wino_macs(cin, cout) * H * W   # F(4x4,3x3): 36 over H/4*W/4 = 2.25), not the direct conv's 9
+        return 2.0 * B * cin * cout * wino_macs(cin, cout, B, H, W) * H * W   # F(4x4,3x3): 36 over H/4*W/4 = 2.25), not the direct conv's 9
     if name == "cagc_wino_conv3x3_act_dgrad":   # (gx,gout,act_out,up,residual,B,Cin,Cout,H,W,...)
         B, cin, cout, H, W = a[5:10]
-        return 2.0 * B * cin * cout * wino_macs(cout, cin) * H * W     # data gradient: GEMM K = Cout, M = Cin
+        return 2.0 * B * cin * cout * wino_macs(cout, cin, B, H, W) * H * W     # data gradient: GEMM K = Cout, M = Cin
     if name in ("cagc_conv3x3s2_fwd", "cagc_conv3x3s2_dgrad"):   # (out,x,wp,B,Cin,Cout,Hin,Win,pitch)
         B, cin, cout, hin, win = a[3:8]
         return 2.0 * B * cin * cout * 9 * ((hin - 3) // 2 + 1) * ((win - 3) // 2 + 1)
@@ -155,7 +157,8 @@ class KernelTimer:
             self.orig(name, *args)
             e.record(st)
             key = name
-            if name in ("cagc_wino_conv3x3", "cagc_wino_conv3x3_act_dgrad") and wino_f4(args[7] if name.endswith("act_dgrad") else args[5], args[6]):
+            if name in ("cagc_wino_conv3x3", "cagc_wino_conv3x3_act_dgrad") and (
+                    wino_f4(args[7], args[6], args[5], args[8], args[9]) if name.endswith("act_dgrad") else wino_f4(args[5], args[6], args[4], args[7], args[8])):
                 key = f"{name}[k_wino4<{'true' if name.endswith('act_dgrad') else 'false'}>]"       # F(4x4,3x3): conv_wino4.hip
             elif name in ("cagc_wino_conv3x3", "cagc_wino_conv3x3_act_dgrad"):   # one record family per device kernel, so the
                 gated = name.endswith("act_dgrad")                              # average launch duration is comparable with the
@@ -392,7 +395,9 @@ def main():
     if not args.no_roofline:
         # per-kernel HIP-event timing needs individual launches: same models, eager launches (no graph), no DDP
         prof_step = step if mode == "eager" else kd.KDStep(student, teacher, disc)
+        from cagc.op import modconv as _mc
         overlap_saved, kd.OVERLAP_TEACHER = kd.OVERLAP_TEACHER, False   # one stream: kernels are timed in isolation
+        side_saved, _mc._SIDE_LIMIT = _mc._SIDE_LIMIT, 0                # (also the weight gradients / skip GEMMs of the side stream)
         for _ in range(2):
             prof_step.sample_and_step(bs, mask, rng, None)
         with KernelTimer(_lib) as kt:
@@ -400,6 +405,7 @@ def main():
                 prof_step.sample_and_step(bs, mask, rng, None)
         agg = kt.summary()
         kd.OVERLAP_TEACHER = overlap_saved
+        _mc._SIDE_LIMIT = side_saved
         if rank == 0:
             mfma = {k: v for k, v in agg.items() if v[2] > 0}
             # the Winograd kernel runs as 4-wave (NH1) or 8-wave (NH2) workgroups of the SAME source kernel, chosen per launch
@@ -467,13 +473,16 @@ def main():
         # the eight phases of the reference's profiler (Miscellaneous/train_time_profiler.py:186-314), on a second,
         # untimed-for-`value` period of 16 iterations with HIP events at the same boundaries; one stream (the teacher's
         # side stream off) so that a phase's time is its own kernels'
+        from cagc.op import modconv as _mc
         overlap_saved, kd.OVERLAP_TEACHER = kd.OVERLAP_TEACHER, False
+        side_saved, _mc._SIDE_LIMIT = _mc._SIDE_LIMIT, 0
         it.phase_timer = kd.PhaseTimer()
         for i in range(16):
             it.iteration(i, real, mask, rng, None)
         phases = it.phase_timer.summary()
         it.phase_timer = None
         kd.OVERLAP_TEACHER = overlap_saved
+        _mc._SIDE_LIMIT = side_saved
         full = {"value": round(16 * bs / dtf, 2), "unit": "images/s", "ms_per_iteration": round(dtf / 16 * 1e3, 2),
                 "what": "D step + G/KD step + R1/16 + path-length/4 + EMA, bs16, eager launches (train.py:371-398 equivalent); "
                         "every convolution incl. the second-order passes and D's weight gradients on libcagc (no MIOpen)",

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "prep_device.h"
 #include "conv_plan.h"
+#include "conv_wino.h"
 #include "conv_wgrad_rd.h"
 #include <stdlib.h>
 #include <string.h>
@@ -594,6 +595,8 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "deterministic")) cagc::deterministic_mode() = value;
   else if (!strcmp(key, "wgrad_rd")) cagc::wgrad_rd_set_tuning(value, 0);
   else if (!strcmp(key, "wgrad_rd_wgs")) cagc::wgrad_rd_set_tuning(-1, value);
+  else if (!strcmp(key, "wino4_hv")) cagc::wino4_hv_tuning() = value;
+  else if (!strcmp(key, "wino4_min_wgs")) cagc::wino4_min_wgs() = value;
   else { cagc::set_error("cagc_set_tuning: unknown key '%s'", key); return CAGC_ERR_INVALID; }
   return CAGC_OK;
 }

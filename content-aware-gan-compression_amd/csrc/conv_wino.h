@@ -24,7 +24,8 @@ struct WinoArgs {
   float alpha, act_scale;
 };
 
-// F(4x4,3x3) kernel (conv_wino4.hip): M % 128 == 0, H % 8 == 0, W % 32 == 0; `up` packed by wino4_pack_elem
+// F(4x4,3x3) kernel (conv_wino4.hip): H % 8 == 0, W % 32 == 0; `up` packed by wino4_pack_elem (64-channel tiles)
+int& wino4_hv_tuning();
 int run_wino4(WinoArgs& a, bool gated, hipStream_t st, const char* what);
 int wino4_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad, hipStream_t st);
 

@@ -551,16 +551,18 @@ extern "C" int cagc_wino_eligible(int H, int W) { return (H % 8 == 0 && W % WTW 
 
 extern "C" int64_t cagc_wino_packed_elems(int K, int M) {
   if (K <= 0 || M <= 0) return 0;
-  if (wino_use_f4(K, M)) return wino4_packed_elems(K, M);
-  const int mb = wino_mb(M);
-  return (int64_t)cdiv(M, mb * 16) * 16 * wino_kp(K) * 64;
+  return wino_packed_total(K, M);
 }
 
 extern "C" int cagc_wino_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad,
                               cagc_stream_t stream) {
   CAGC_REQUIRE(up && weight && Cout > 0 && Cin > 0, "cagc_wino_prep: bad argument");
   const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
-  if (wino_use_f4(K, M)) return wino4_prep(up, weight, Cout, Cin, scale, dgrad, as_stream(stream));
+  if (wino_use_f4(K, M)) {     // both packings: [F(4x4) | F(2x2)]
+    const int rc = wino4_prep(up, weight, Cout, Cin, scale, dgrad, as_stream(stream));
+    if (rc) return rc;
+    up += wino4_packed_elems(K, M);
+  }
   const int Kp = wino_kp(K), mb = wino_mb(M), mtiles = cdiv(M, mb * 16);
   hipLaunchKernelGGL(k_wino_pack, dim3(cdiv((int64_t)mtiles * Kp * 64, 256)), dim3(256), 0, as_stream(stream), up, weight,
                      Cout, Cin, Kp, mtiles, mb, scale, dgrad);
@@ -587,10 +589,11 @@ extern "C" int cagc_wino_conv3x3(float* out, const float* x, const float* up, co
   a.in = x; a.out = out; a.up = up; a.in_scale = s; a.out_scale = out_scale; a.noise = noise; a.noise_w = noise_w; a.bias = bias;
   a.B = B; a.Cin = Cin; a.Kp = wino_kp(Cin); a.Cout = Cout; a.Mp = round_up(Cout, 16); a.H = H; a.W = W;
   a.epi = epi; a.noise_bstride_on = (noise_batch == B) ? 1 : 0; a.alpha = alpha; a.act_scale = act_scale;
-  if (wino_use_f4(Cin, Cout)) {   // F(4x4,3x3): 2.25 multiplies per output (conv_wino4.hip); `up` was packed for it by the same predicate
+  if (wino4_for_launch(Cin, Cout, B, H, W)) {   // F(4x4,3x3): 2.25 multiplies per output (conv_wino4.hip), first part of `up`
     CAGC_REQUIRE(((uintptr_t)out % 16) == 0 && (!noise || ((uintptr_t)noise % 16) == 0), "%s: unaligned tensor", what);
     return run_wino4(a, false, as_stream(stream), what);
   }
+  a.up = wino2_part(up, Cin, Cout);
   return wino_dispatch<false>(a, Cout, as_stream(stream), what);
 }
 
@@ -614,9 +617,10 @@ extern "C" int cagc_wino_conv3x3_act_dgrad(float* gx, const float* gout, const f
   a.in = gout; a.gate = act_out; a.gate_alpha = alpha; a.gate_scale = act_scale; a.out = gx; a.up = up; a.residual = residual;
   a.B = B; a.Cin = Cout; a.Kp = wino_kp(Cout); a.Cout = Cin; a.Mp = round_up(Cin, 16); a.H = H; a.W = W;
   a.epi = CAGC_EPI_LINEAR; a.alpha = alpha; a.act_scale = 1.f;
-  if (wino_use_f4(Cout, Cin)) {
+  if (wino4_for_launch(Cout, Cin, B, H, W)) {
     CAGC_REQUIRE(((uintptr_t)gx % 16) == 0 && (!residual || ((uintptr_t)residual % 16) == 0), "%s: unaligned tensor", what);
     return run_wino4(a, true, as_stream(stream), what);
   }
+  a.up = wino2_part(up, Cout, Cin);
   return wino_dispatch<true>(a, Cin, as_stream(stream), what);
 }

@@ -8,9 +8,12 @@
 // the interpolation points 0, +-1, +-2, inf — their larger constants cost ~1.5 decimal digits against F(2x2) (measured ~1e-5
 // of the output scale; the parity bar is 1e-3).
 //
-// Workgroup = 4 waves, ONE wave per SIMD (up to 512 registers), tile = 128 output channels x (8 x 32 output pixels = 2 x 8
-// Winograd tiles = one MFMA N-block).  Wave (I, J) owns the 3x3 block of positions i in 3I..3I+2, j in 3J..3J+2 for all 8
-// channel blocks: 72 accumulator tiles.  K runs in chunks of 8 input channels:
+// Workgroup = 4 * HV waves (HV = channel halves, 1 or 2), tile = 64 * HV output channels x (8 x 32 output pixels = 2 x 8
+// Winograd tiles = one MFMA N-block).  Wave (h, I, J) owns the 3x3 block of positions i in 3I..3I+2, j in 3J..3J+2 for the 4
+// channel blocks of half h: 36 accumulator tiles.  HV = 2 (512 threads, one workgroup per CU) shares one transformed input
+// tile between 128 channels; HV = 1 (256 threads, two workgroups per CU) is the same code on 64 channels — twice the
+// transform work per MFMA, but any channel count (padded to 64) and twice the workgroups for under-filled launches (small
+// per-GPU batches, 32^2 layers).  K runs in chunks of 8 input channels:
 //   A operand: transformed weights U pre-packed in MFMA register order [mtile][pos][K/4][channel half][lane][4 blocks], global / L2 -> VGPR
 //     (two 16-byte loads per (position, K-step) feed 8 MFMAs), a ring of half a chunk refilled in place;
 //   B operand: raw halo tile [8][10][40] --(registers)--> LDS (2 buffers) --B^T d B, half a patch (3 of the 6 transformed rows)
@@ -99,17 +102,18 @@ __device__ __forceinline__ f32x2 pk_fma_ahi_clo(const f32x2 a, const f32x2 b, co
 // Workgroup = 8 waves (2 per SIMD): wave = (channel half hb, I, J) owns the 3x3 block of positions (3I.., 3J..) for 4 channel
 // blocks: 36 accumulator tiles.  The two waves of a SIMD are (hb = 0, I, J) and (hb = 1, I, J) (waves w and w + 4 share a SIMD):
 // they take turns transforming (even / odd chunks), so every SIMD carries the same VALU work in every chunk.
-template <bool GATED, bool SCALE>
-__global__ __launch_bounds__(512, 1) void k_wino4(const WinoArgs A) {
+template <bool GATED, bool SCALE, int HV>
+__global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoArgs A) {
   constexpr int CK = W4_CK;
-  constexpr int NU = (CK * W4_IH * 10 + 511) / 512;     // raw-tile float4 units per thread (800 / 512 -> 2)
+  constexpr int NT = 256 * HV;                            // threads
+  constexpr int NU = (CK * W4_IH * 10 + NT - 1) / NT;     // raw-tile float4 units per thread (800 / 512 -> 2, 800 / 256 -> 4)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* v_lds = smem;                    // [2][36*CK][16]
   float* raw = v_lds + 2 * W4_VSZ;        // [2][CK][RPS]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hb = wave >> 2, WI = (wave >> 1) & 1, WJ = wave & 1;
+  const int hb = HV == 2 ? wave >> 2 : 0, WI = (wave >> 1) & 1, WJ = wave & 1;
   const int lm = lane & 15, g = lane >> 4;
 
   int pix_id, mtile;
@@ -124,18 +128,18 @@ __global__ __launch_bounds__(512, 1) void k_wino4(const WinoArgs A) {
   const int ty_i = (pix_id / A.tiles_x) % A.tiles_y;
   const int b = pix_id / (A.tiles_x * A.tiles_y);
   const int x0 = tx_i * 32, y0 = ty_i * 8;
-  const int m0 = mtile * 128;
+  const int m0 = mtile * 64 * HV;
   const int HW = A.H * A.W;
   const int nch = A.Kp / CK;
   const int KQ = A.Kp / 4;
 
-  // ---- raw-tile staging: CK x 10 rows x 10 float4 = 800 units over 512 threads ---------------------------------------------
+  // ---- raw-tile staging: CK x 10 rows x 10 float4 = 800 units over the workgroup's threads ----------------------------------
   constexpr unsigned OOR = 0x80000000u;
   unsigned e_boff[NU], e_soff[NU];
   int e_loff[NU];
 #pragma unroll
   for (int i = 0; i < NU; ++i) {
-    int e = tid + 512 * i;
+    int e = tid + NT * i;
     if (e >= CK * W4_IH * 10) e -= CK * W4_IH * 10;       // spare lanes of the last round repeat a unit (same value, same address)
     const int r = e / 10, q = e - r * 10;
     const int c = r / W4_IH, iy = r - c * W4_IH;
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(512, 1) void k_wino4(const WinoArgs A) {
   };
 
   // ---- input transform: work item = (half h of the transformed rows, channel c, tile); 256 items per chunk -----------------
-  // done by the 256 threads of channel half hb == (chunk & 1): both waves of a SIMD alternate
+  // done by the 256 threads of channel half hb == (chunk & 1): both waves of a SIMD alternate (HV = 1: by every thread, every chunk)
   const int wt = tid & 255;
   const int t_h = wt >> 7, t_c = (wt >> 4) & 7, t_t = wt & 15;
   const int t_src = t_c * W4_RPS + (4 * (t_t >> 3)) * W4_IWP + 3 + 4 * (t_t & 7);   // patch origin: row y0-1+4ty, col x0-1+4tx
@@ -229,13 +233,15 @@ __global__ __launch_bounds__(512, 1) void k_wino4(const WinoArgs A) {
   };
 
   // ---- A operand ring: half a chunk = 9 (position, K-step) groups of ONE float4 (this wave's 4 channel blocks) ----------------
+  // packed in 64-channel tiles [tile64][pos][K/4][lane][4 blocks]: this wave's tile is 2 * mtile + hb (HV = 2) / mtile; a wave's
+  // 64 lanes read one contiguous KB per load
   const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(A.up) + (int64_t)mtile * 36 * KQ * 512, 0, 0x7fffffff, 0x00020000);
-  const unsigned ua_lane = (unsigned)lane * 16u + (unsigned)hb * 1024u;   // [half][lane][4 blocks]: one contiguous KB per wave and load
+      const_cast<float*>(A.up) + (int64_t)(mtile * HV + hb) * 36 * KQ * 256, 0, 0x7fffffff, 0x00020000);
+  const unsigned ua_lane = (unsigned)lane * 16u;
   auto a_soff = [&](int gi, int chunk) {
     const int p = gi >> 1, s = gi & 1;
     const int pos = (3 * WI + p / 3) * 6 + 3 * WJ + p % 3;
-    return ((pos * KQ + 2 * chunk + s) * 512) * 4;
+    return ((pos * KQ + 2 * chunk + s) * 256) * 4;
   };
 #ifndef CAGC_W4_RING
 #define CAGC_W4_RING 6
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void k_wino4(const WinoArgs A) {
     const float* vbn = v_lds + (cur ^ 1) * W4_VSZ + vb_wave;
     float* vnext = v_lds + (cur ^ 1) * W4_VSZ;
     const float* rnext = raw + (cur ^ 1) * W4_RSZ;      // chunk j+1, transformed during this chunk by the waves of half (j+1)&1
-    const bool xf = (hb == (cur ^ 1));                  // uniform per wave: (j + 1) & 1 == cur ^ 1
+    const bool xf = HV == 1 || (hb == (cur ^ 1));       // uniform per wave: (j + 1) & 1 == cur ^ 1
     const int jn = (j + 1 < nch) ? j + 1 : j;           // last chunk: re-read valid weights instead of branching
 #pragma unroll
     for (int gi = 0; gi < 18; ++gi) {
@@ -395,42 +401,67 @@ __global__ __launch_bounds__(256) void k_wino4_pack(float* __restrict__ up, cons
 int wino4_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad, hipStream_t st) {
   const int K = dgrad ? Cout : Cin, M = dgrad ? Cin : Cout;
   const int Kp = round_up(K, 16);
-  const int64_t n = (int64_t)(M / 128) * Kp * 128;
+  const int64_t n = (int64_t)cdiv(M, 64) * Kp * 64;      // one thread per (64-channel tile, K/4 group, lane, block): 36 positions each
   hipLaunchKernelGGL(k_wino4_pack, dim3(cdiv(n, 256)), dim3(256), 0, st, up, weight, Cout, Cin, Kp, n, scale, dgrad);
   return check_launch("cagc_wino_prep(F4)");
 }
 
-int run_wino4(WinoArgs& a, bool gated, hipStream_t st, const char* what) {
-  CAGC_REQUIRE(a.Cout % 128 == 0 && a.H % 8 == 0 && a.W % 32 == 0, "%s: F(4x4) needs Cout %% 128 == 0, H %% 8 == 0, W %% 32 == 0", what);
-  a.Kp = round_up(a.Cin, 16);
-  a.tiles_x = a.W / 32; a.tiles_y = a.H / 8; a.nblocks = a.B * a.tiles_x * a.tiles_y;
-  a.mtiles = a.Cout / 128;
-  CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
-  CAGC_REQUIRE((int64_t)36 * a.Kp * 128 * 4 < (1ll << 31), "%s: weight tile too large for 32-bit offsets", what);
-  size_t smem = sizeof(float) * (size_t)(2 * W4_VSZ + 2 * W4_RSZ);
-  const size_t exch = sizeof(float) * 8 * 4 * 4 * 4 * 64;     // [wave 8][a][r][lane] float4
-  if (smem < exch) smem = exch;
-  const bool sc = a.in_scale != nullptr;
-  const void* fn = gated ? (sc ? reinterpret_cast<const void*>(&k_wino4<true, true>) : reinterpret_cast<const void*>(&k_wino4<true, false>))
-                         : (sc ? reinterpret_cast<const void*>(&k_wino4<false, true>) : reinterpret_cast<const void*>(&k_wino4<false, false>));
-  static bool attr[4][64] = {};
+// launches with fewer 64-channel workgroups than this take the F(2x2) kernel (prep_device.h wino4_for_launch)
+int& wino4_min_wgs() {
+  static int v = getenv("CAGC_WINO4_MIN_WGS") ? atoi(getenv("CAGC_WINO4_MIN_WGS")) : 256;
+  return v;
+}
+
+// workgroup shape: 0 = per launch (below), 1 / 2 = forced (cagc_set_tuning("wino4_hv"), CAGC_WINO4_HV; 2 only where Cout % 128 == 0)
+int& wino4_hv_tuning() {
+  static int v = getenv("CAGC_WINO4_HV") ? atoi(getenv("CAGC_WINO4_HV")) : 0;
+  return v;
+}
+
+template <bool GATED, bool SCALE, int HV>
+static int launch_wino4(const WinoArgs& a, size_t smem, hipStream_t st, const char* what) {
+  static bool attr[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const int vi = (gated ? 2 : 0) + (sc ? 1 : 0);
-  if (dev >= 0 && dev < 64 && !attr[vi][dev]) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (dev >= 0 && dev < 64 && !attr[dev]) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino4<GATED, SCALE, HV>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipGetLastError();
-    attr[vi][dev] = true;
+    CAGC_REQUIRE(e == hipSuccess, "%s: cannot reserve %zu bytes of LDS: %s", what, smem, hipGetErrorString(e));
+    attr[dev] = true;
   }
-  dim3 grid((unsigned)(a.nblocks * a.mtiles));
-  if (gated) {
-    if (sc) hipLaunchKernelGGL((k_wino4<true, true>), grid, dim3(512), smem, st, a);
-    else hipLaunchKernelGGL((k_wino4<true, false>), grid, dim3(512), smem, st, a);
-  } else {
-    if (sc) hipLaunchKernelGGL((k_wino4<false, true>), grid, dim3(512), smem, st, a);
-    else hipLaunchKernelGGL((k_wino4<false, false>), grid, dim3(512), smem, st, a);
-  }
+  hipLaunchKernelGGL((k_wino4<GATED, SCALE, HV>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(256 * HV), smem, st, a);
   return check_launch(what);
+}
+
+int run_wino4(WinoArgs& a, bool gated, hipStream_t st, const char* what) {
+  CAGC_REQUIRE(a.H % 8 == 0 && a.W % 32 == 0, "%s: F(4x4) needs H %% 8 == 0, W %% 32 == 0", what);
+  a.Kp = round_up(a.Cin, 16);
+  a.tiles_x = a.W / 32; a.tiles_y = a.H / 8; a.nblocks = a.B * a.tiles_x * a.tiles_y;
+  // One 8-wave workgroup per CU on 128 channels, or two 4-wave workgroups on 64 each?  CU-time model: a CU runs its
+  // workgroups back to back at the matrix pipe's rate; the 64-channel shape pays ~12 % more per channel (the input transform
+  // is shared by half as many MFMAs) but comes in half-size pieces — it wins when the 128-channel grid leaves CUs idle or
+  // ends on a partial round.
+  int hv = 1;
+  if (a.Cout % 128 == 0) {
+    const int64_t w2 = (int64_t)a.nblocks * (a.Cout / 128);
+    const double t2 = (double)cdiv(w2, 256), t1 = 0.56 * (double)cdiv(2 * w2, 256);
+    hv = t1 < t2 ? 1 : 2;
+    if (wino4_hv_tuning() == 1 || wino4_hv_tuning() == 2) hv = wino4_hv_tuning();
+  }
+  a.mtiles = cdiv(a.Cout, 64 * hv);
+  CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
+  CAGC_REQUIRE((int64_t)36 * a.Kp * 64 * 4 * cdiv(a.Cout, 64) < (1ll << 31), "%s: packed weights too large for 32-bit offsets", what);
+  size_t smem = sizeof(float) * (size_t)(2 * W4_VSZ + 2 * W4_RSZ);
+  const size_t exch = sizeof(float) * (size_t)(4 * hv) * 4 * 4 * 4 * 64;     // [wave][a][r][lane] float4
+  if (smem < exch) smem = exch;
+  const bool sc = a.in_scale != nullptr;
+  if (hv == 2) {
+    if (gated) return sc ? launch_wino4<true, true, 2>(a, smem, st, what) : launch_wino4<true, false, 2>(a, smem, st, what);
+    return sc ? launch_wino4<false, true, 2>(a, smem, st, what) : launch_wino4<false, false, 2>(a, smem, st, what);
+  }
+  if (gated) return sc ? launch_wino4<true, true, 1>(a, smem, st, what) : launch_wino4<true, false, 1>(a, smem, st, what);
+  return sc ? launch_wino4<false, true, 1>(a, smem, st, what) : launch_wino4<false, false, 1>(a, smem, st, what);
 }
 
 }  // namespace cagc

@@ -9,19 +9,19 @@ namespace cagc {
 
 struct PrepAllArgs {
   const float* w;
-  float* out[5];      // wp_fwd, wp_bwd, wsq, up_fwd, up_bwd (null = skipped)
-  int64_t n[5];       // elements of each job
-  int end[5];         // block prefix sums
+  float* out[7];      // wp_fwd, wp_bwd, wsq, up_fwd, up_bwd, F(2x2) part of up_fwd / up_bwd where F(4x4) leads (null = skipped)
+  int64_t n[7];       // elements of each job
+  int end[7];         // block prefix sums
   int Cout, Cin, kk;
   int Kp_f, Mp_f, Kp_b, Mp_b;           // packed dims fwd / bwd
   int wKp_f, wMB_f, wKp_b, wMB_b;       // Winograd packing dims
-  int f4_f, f4_b;                       // F(4x4) packing instead of F(2x2) (wino_use_f4)
+  int f4_f, f4_b;                       // F(4x4) packing in front of the F(2x2) one (wino_use_f4)
   float scale;
 };
 
 __global__ __launch_bounds__(256) void k_prep_all(const PrepAllArgs A) {
   int job = 0;
-  while (job < 4 && (int)blockIdx.x >= A.end[job]) ++job;
+  while (job < 6 && (int)blockIdx.x >= A.end[job]) ++job;
   const int b0 = job ? A.end[job - 1] : 0;
   const int64_t idx = (int64_t)(blockIdx.x - b0) * 256 + threadIdx.x;
   if (idx >= A.n[job]) return;
@@ -33,10 +33,12 @@ __global__ __launch_bounds__(256) void k_prep_all(const PrepAllArgs A) {
       if (A.f4_f) wino4_pack_elem(A.out[3], A.w, idx, A.Cout, A.Cin, A.wKp_f, A.scale, 0);
       else wino_pack_elem(A.out[3], A.w, idx, A.Cout, A.Cin, A.wKp_f, A.wMB_f, A.scale, 0);
       break;
-    default:
+    case 4:
       if (A.f4_b) wino4_pack_elem(A.out[4], A.w, idx, A.Cout, A.Cin, A.wKp_b, A.scale, 1);
       else wino_pack_elem(A.out[4], A.w, idx, A.Cout, A.Cin, A.wKp_b, A.wMB_b, A.scale, 1);
       break;
+    case 5: wino_pack_elem(A.out[5], A.w, idx, A.Cout, A.Cin, A.wKp_f, A.wMB_f, A.scale, 0); break;
+    default: wino_pack_elem(A.out[6], A.w, idx, A.Cout, A.Cin, A.wKp_b, A.wMB_b, A.scale, 1); break;
   }
 }
 
@@ -62,10 +64,15 @@ extern "C" int cagc_modconv_prep_all(float* wp_fwd, float* wp_bwd, float* wsq, f
   if (a.f4_f) a.wKp_f = wino4_kp(Cin);
   if (a.f4_b) a.wKp_b = wino4_kp(Cout);
   // elements = threads: one per (tile, K/4 group, lane, block) — each writes its 16 / 36 positions
-  a.n[3] = up_fwd ? (a.f4_f ? (int64_t)(Cout / 128) * a.wKp_f * 128 : (int64_t)cdiv(Cout, a.wMB_f * 16) * a.wKp_f * 64) : 0;
-  a.n[4] = up_bwd ? (a.f4_b ? (int64_t)(Cin / 128) * a.wKp_b * 128 : (int64_t)cdiv(Cin, a.wMB_b * 16) * a.wKp_b * 64) : 0;
+  const int64_t n2_f = (int64_t)cdiv(Cout, a.wMB_f * 16) * a.wKp_f * 64, n2_b = (int64_t)cdiv(Cin, a.wMB_b * 16) * a.wKp_b * 64;
+  a.n[3] = up_fwd ? (a.f4_f ? (int64_t)cdiv(Cout, 64) * a.wKp_f * 64 : n2_f) : 0;
+  a.n[4] = up_bwd ? (a.f4_b ? (int64_t)cdiv(Cin, 64) * a.wKp_b * 64 : n2_b) : 0;
+  a.out[5] = (up_fwd && a.f4_f) ? up_fwd + wino4_packed_elems(Cin, Cout) : nullptr;    // [F(4x4) | F(2x2)] (prep_device.h)
+  a.out[6] = (up_bwd && a.f4_b) ? up_bwd + wino4_packed_elems(Cout, Cin) : nullptr;
+  a.n[5] = a.out[5] ? n2_f : 0;
+  a.n[6] = a.out[6] ? n2_b : 0;
   int64_t blocks = 0;
-  for (int j = 0; j < 5; ++j) {
+  for (int j = 0; j < 7; ++j) {
     blocks += (a.n[j] + 255) / 256;
     CAGC_REQUIRE(blocks < (1ll << 31), "cagc_modconv_prep_all: too large");
     a.end[j] = (int)blocks;

@@ -113,28 +113,35 @@ inline int igemm_kp(int K) { return round_up(K, 8); }
 inline int wino_kp(int K) { return round_up(K, 16); }
 
 // ---- Winograd F(4x4, 3x3) (conv_wino4.hip): 36 positions, 2.25 multiplies per output instead of F(2x2)'s 4 ----------------
-// Used for layers whose GEMM M (output channels; input channels for a data gradient) is a multiple of 128 and whose K is long
-// enough to amortise the 6x6 output transform (teacher / discriminator layers).  The same predicate decides the PACKING
+// Used for layers whose GEMM M (output channels; input channels for a data gradient) and K are both >= 128: K long enough to
+// amortise the 6x6 output transform, M at least two 64-channel tiles (teacher / discriminator layers, the student's
+// 154-channel ones).  The same predicate decides the PACKING
 // (cagc_wino_prep, cagc_modconv_prep_all, cagc_wino_packed_elems) and the KERNEL, so a packed buffer is always read by the
 // kernel it was packed for.  CAGC_WINO_F4=0 turns it off everywhere.
 inline bool wino_f4_enabled() {
   static const int v = getenv("CAGC_WINO_F4") ? atoi(getenv("CAGC_WINO_F4")) : 1;
   return v != 0;
 }
-inline bool wino_use_f4(int K, int M) { return wino_f4_enabled() && M % 128 == 0 && K >= 128; }
+inline bool wino_use_f4(int K, int M) { return wino_f4_enabled() && M >= 128 && K >= 128; }
 inline int wino4_kp(int K) { return round_up(K, 16); }     // two chunks of 8 per main-loop iteration
-inline int64_t wino4_packed_elems(int K, int M) { return (int64_t)(M / 128) * 36 * wino4_kp(K) * 128; }
+inline int64_t wino4_packed_elems(int K, int M) { return (int64_t)cdiv(M, 64) * 36 * wino4_kp(K) * 64; }   // 64-channel tiles, zero-padded
+// An F(4x4)-eligible layer carries BOTH packings back to back, [F(4x4) | F(2x2)]: the kernel is chosen per LAUNCH (run-time batch
+// and resolution decide whether the F(4x4) grid — 64 channels x 8x32 pixels per workgroup, K un-split — fills the chip; the
+// F(2x2) kernel has finer tiles for under-filled launches: per-GPU batch 2 / 4, 32^2 layers).
+int& wino4_min_wgs();      // conv_wino4.hip; cagc_set_tuning("wino4_min_wgs"), CAGC_WINO4_MIN_WGS (default 256)
+inline bool wino4_for_launch(int K, int M, int B, int H, int W) {
+  return wino_use_f4(K, M) && (int64_t)B * (H / 8) * (W / 32) * cdiv(M, 64) >= wino4_min_wgs();
+}
 
 // U[pos=(i,j)][k][m] = scale * (G g G^T)[i][j], G the 6x3 matrix of F(4,3) (interpolation points 0, +-1, +-2, inf); stored in
-// MFMA A-operand order  up[mtile(128)][pos 36][K/4][channel half][lane = (k%4, m%16)][4 channel blocks];  idx over [mtiles][Kp/4][2][64][4]
+// MFMA A-operand order  up[tile of 64 channels][pos 36][K/4][lane = (k%4, m%16)][4 channel blocks];  idx over [tiles][Kp/4][64][4]
 __device__ __forceinline__ void wino4_pack_elem(float* __restrict__ up, const float* __restrict__ w, int64_t idx, int Cout, int Cin,
                                                 int Kp, float scale, int dgrad) {
-  // per (mtile, pos, K/4 group): [channel half 2][lane 64][4 blocks] — the 4 blocks of a lane that ONE wave feeds to the MFMAs
-  // are 16 contiguous bytes and a wave's 64 lanes read one contiguous KB
-  const int b4 = (int)(idx & 3), ln = (int)((idx >> 2) & 63), half = (int)((idx >> 8) & 1);
-  const int blk = half * 4 + b4;
-  const int kq = (int)((idx >> 9) % (Kp / 4)), mt = (int)((idx >> 9) / (Kp / 4));
-  const int k = 4 * kq + (ln >> 4), m = mt * 128 + blk * 16 + (ln & 15);
+  // per (tile, pos, K/4 group): [lane 64][4 blocks] — the 4 blocks of a lane that ONE wave feeds to the MFMAs are 16 contiguous
+  // bytes and a wave's 64 lanes read one contiguous KB
+  const int b4 = (int)(idx & 3), ln = (int)((idx >> 2) & 63);
+  const int kq = (int)((idx >> 8) % (Kp / 4)), mt = (int)((idx >> 8) / (Kp / 4));
+  const int k = 4 * kq + (ln >> 4), m = mt * 64 + b4 * 16 + (ln & 15);
   const int o = dgrad ? k : m, c = dgrad ? m : k;
   float gk[3][3];
 #pragma unroll
@@ -152,8 +159,8 @@ __device__ __forceinline__ void wino4_pack_elem(float* __restrict__ up, const fl
   for (int i = 0; i < 6; ++i)
 #pragma unroll
     for (int bb = 0; bb < 3; ++bb) t[i][bb] = G[i][0] * gk[0][bb] + G[i][1] * gk[1][bb] + G[i][2] * gk[2][bb];
-  const int64_t ps = (int64_t)(Kp / 4) * 512;                                   // stride between positions
-  float* dst = up + ((int64_t)mt * 36 * (Kp / 4) + kq) * 512 + half * 256 + ln * 4 + b4;
+  const int64_t ps = (int64_t)(Kp / 4) * 256;                                   // stride between positions
+  float* dst = up + ((int64_t)mt * 36 * (Kp / 4) + kq) * 256 + ln * 4 + b4;
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -167,5 +174,11 @@ inline int wino_mb(int M) {
   if (nblk % 4 != 0 && nblk % 3 == 0) return 3;
   return 4;
 }
+inline int64_t wino2_packed_elems(int K, int M) { return (int64_t)cdiv(M, wino_mb(M) * 16) * 16 * wino_kp(K) * 64; }
+inline int64_t wino_packed_total(int K, int M) {
+  return (wino_use_f4(K, M) ? wino4_packed_elems(K, M) : 0) + wino2_packed_elems(K, M);
+}
+// the F(2x2) operand inside a layer's packed buffer
+inline const float* wino2_part(const float* up, int K, int M) { return wino_use_f4(K, M) ? up + wino4_packed_elems(K, M) : up; }
 
 }  // namespace cagc

@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("CAGC_WINO4_MIN_WGS", "0")   # parity on small launches: keep them on the F(4x4) kernel
 """F(4x4,3x3) Winograd kernel vs float64: plain linear / styled epilogue / gated data gradient, and timing against F(2x2).
 CAGC_WINO_F4=0|1 python scripts/check_wino4.py"""
 import os, sys, time, torch

@@ -4,13 +4,13 @@
 # markdown by scripts/rocpd_stats.py / rocpd_pmc.py.  Copy the summaries you keep into profiles/.
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-export CAGC_OVERLAP_TEACHER=0   # one stream: per-kernel durations in isolation, as in bench.py's roofline pass
+export CAGC_OVERLAP_TEACHER=0 CAGC_SIDE_WGRAD=0   # one stream: per-kernel durations in isolation, as in bench.py's roofline pass
 CMD="python bench.py --no-graph --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-full-iteration --no-proxy --sweep 0 $PROFILE_EXTRA"   # PROFILE_EXTRA="--local-batch 2": the per-GPU batch of an 8-GPU run
 mkdir -p gpurun_out
 rm -rf /tmp/prof_kt
 rocprofv3 --kernel-trace -d /tmp/prof_kt -o kt -- $CMD > gpurun_out/${TAG}_kt.log 2>&1
 DB=$(find /tmp/prof_kt -name '*.db' | head -1)
-{ echo "command: rocprofv3 --kernel-trace -- $CMD  (CAGC_OVERLAP_TEACHER=0: eager launches on one stream, per-kernel view of the step bench.py times)"; echo;
+{ echo "command: rocprofv3 --kernel-trace -- $CMD  (CAGC_OVERLAP_TEACHER=0 CAGC_SIDE_WGRAD=0: eager launches on one stream, per-kernel view of the step bench.py times)"; echo;
   python scripts/rocpd_stats.py "$DB" --marker k_masked_l1 --last 4 --top 45; } > gpurun_out/${TAG}_kernel_stats.md
 if [ -n "$PROFILE_KT_ONLY" ]; then head -60 gpurun_out/${TAG}_kernel_stats.md; exit 0; fi
 for C in FETCH_SIZE WRITE_SIZE; do

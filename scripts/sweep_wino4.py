@@ -4,7 +4,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "content-aware-gan-compression_amd")]
 from cagc import _lib
 from cagc.op import modconv as mc
 dev = "cuda"
-SHAPES = [(16, 512, 64), (16, 512, 64), (16, 512, 32), (16, 512, 16), (16, 512, 8), (16, 512, 4), (16, 256, 128), (16, 128, 256), (8, 512, 32), (4, 512, 32), (2, 512, 32), (2, 512, 64), (2, 256, 128), (2, 128, 256)]
+SHAPES = [(16, 512, 64), (16, 512, 64), (16, 512, 32), (16, 256, 128), (16, 128, 256), (8, 512, 32), (4, 512, 32), (2, 512, 32), (4, 512, 64), (2, 512, 64), (2, 256, 128), (2, 128, 256), (16, 154, 64), (16, 154, 32), (2, 154, 64)]
 for (B, C, H) in SHAPES:
     x = torch.randn(B, C, H, H, device=dev); w = torch.randn(C, C, 3, 3, device=dev)
     up = mc.pack_wino(w, 0.01, False); out = torch.empty_like(x)
@@ -15,4 +15,4 @@ for (B, C, H) in SHAPES:
     for _ in range(10): run()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
     fl = 2.0 * B * C * C * 9 * H * H
-    print(f"F4={os.environ.get('CAGC_WINO_F4', '1')} B{B} C{C} H{H}: {dt*1e3:.3f} ms  direct-equiv {fl/dt/1e12:.1f} TF", flush=True)
+    print(f"F4={os.environ.get('CAGC_WINO_F4', '1')} hv={os.environ.get('CAGC_WINO4_HV', 'auto')} B{B} C{C} H{H}: {dt*1e3:.3f} ms  direct-equiv {fl/dt/1e12:.1f} TF", flush=True)

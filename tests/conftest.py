@@ -21,6 +21,19 @@ def golden_dir():
     return GOLDEN
 
 
+@pytest.fixture(params=["launch_policy", "f4_forced"])
+def wino4_policy(request):
+    """Which Winograd kernel an F(4x4)-eligible layer's launch takes: the library's per-launch choice (F(4x4,3x3) when its grid of
+    64-channel workgroups fills the chip, else the F(2x2,3x3) packing the layer also carries — what the B = 1-2 per-layer tests
+    get), or F(4x4) forced (`cagc_set_tuning("wino4_min_wgs", 0)`: the kernel the same layer runs on at the bench's batch 16)."""
+    from cagc import _lib
+    if request.param == "f4_forced":
+        _lib.call("cagc_set_tuning", b"wino4_min_wgs", 0)
+    yield request.param
+    if request.param == "f4_forced":
+        _lib.call("cagc_set_tuning", b"wino4_min_wgs", 256)
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():

@@ -17,11 +17,11 @@ TIGHT = 2e-5
 
 
 def wino_f4(k_ch, m_ch, H, W, up=False):
-    """The layer's 3x3 conv (GEMM K = k_ch, M = m_ch) runs on the Winograd F(4x4,3x3) kernel (csrc/conv_wino4.hip: M % 128 == 0,
+    """The layer's 3x3 conv (GEMM K = k_ch, M = m_ch) runs on the Winograd F(4x4,3x3) kernel (csrc/conv_wino4.hip: M >= 128,
     K >= 128, Winograd-eligible size, CAGC_WINO_F4 != 0) — its transforms cost ~1.5 digits against F(2x2): the per-layer float64
     bar is 5e-5 there (observed 1-2.2e-5), 5e-6 elsewhere (observed 2-7e-7)."""
     import os
-    return (not up and os.environ.get("CAGC_WINO_F4", "1") != "0" and m_ch % 128 == 0 and k_ch >= 128 and H % 8 == 0 and W % 32 == 0)
+    return (not up and os.environ.get("CAGC_WINO_F4", "1") != "0" and m_ch >= 128 and k_ch >= 128 and H % 8 == 0 and W % 32 == 0)
 DEV = "cuda"
 
 
@@ -476,7 +476,7 @@ def test_pruned_1024_generator_vs_oracle_image_and_grads():
                                  (512, 512, 32, False, 2), (512, 512, 64, False, 1), (512, 256, 64, True, 1), (256, 256, 128, False, 1),
                                  (256, 128, 128, True, 1), (128, 128, 256, False, 1), (154, 77, 64, True, 2), (77, 77, 128, False, 1),
                                  (77, 39, 128, True, 1), (39, 39, 256, False, 1)])
-def test_styled_conv_layers_vs_float64(cfg):
+def test_styled_conv_layers_vs_float64(cfg, wino4_policy):
     """Single StyledConv layers (direct, transposed and Winograd paths) against the oracle evaluated in float64:
     output and every gradient within 5e-6 — the fp32 MFMA path is as accurate as the fp32 CPU reference (2-7e-7)."""
     cin, cout, H, up, B = cfg

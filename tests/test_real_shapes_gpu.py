@@ -26,7 +26,7 @@ D_LAYERS = [(128, 128, 256, False, 1), (128, 256, 256, True, 1), (256, 256, 128,
 
 
 @pytest.mark.parametrize("cfg", D_LAYERS)
-def test_discriminator_conv_layers_real_shapes_vs_float64(cfg):
+def test_discriminator_conv_layers_real_shapes_vs_float64(cfg, wino4_policy):
     """ConvLayer = [Blur ->] EqualConv2d -> FusedLeakyReLU on the HIP kernels (Winograd / register-direct stride-2 conv,
     register-direct weight gradient incl. the phase-planar role swap) vs the same layer evaluated in float64: output,
     input gradient, weight gradient, bias gradient."""
@@ -55,9 +55,9 @@ def test_discriminator_conv_layers_real_shapes_vs_float64(cfg):
     # (|pre-activation| < 1e-5 of the layer scale) and be few; the float64 layer is then evaluated on the HIP run's gate pattern
     gate = (yg.detach() > 0).cpu()
     dis = gate != (pre.detach() > 0)
-    # stride-1 layers of D run on the Winograd F(4x4,3x3) kernel (cout % 128 == 0): per-layer bar 5e-5 (observed 1-2e-5), F(2x2) /
+    # stride-1 layers of D run on the Winograd F(4x4,3x3) kernel (cout, cin >= 128): per-layer bar 5e-5 (observed 1-2e-5), F(2x2) /
     # register-direct layers 5e-6
-    f4 = (not down) and os.environ.get("CAGC_WINO_F4", "1") != "0" and cout % 128 == 0 and cin >= 128
+    f4 = (not down) and os.environ.get("CAGC_WINO_F4", "1") != "0" and cout >= 128 and cin >= 128
     bar = 5e-5 if f4 else 5e-6
     if int(dis.sum()):
         assert float(pre.detach()[dis].abs().max()) < (1e-4 if f4 else 1e-5) * float(pre.detach().abs().max()), "gate flip above rounding level"

@@ -21,15 +21,29 @@ def rel(a, b):
     return float((a.double().cpu() - b).abs().max() / b.abs().max())
 
 
-# (B, cin, cout, H, W)
+# (B, cin, cout, H, W): channel counts that are multiples of 128 (teacher / discriminator) and ragged ones (the pruned student's
+# 154; 200 = 3 tiles + 8 channels), K tails, one and several pixel blocks per image
 SHAPES = [(1, 128, 128, 8, 32), (2, 136, 128, 16, 32), (3, 200, 256, 8, 64), (2, 256, 384, 24, 32), (1, 512, 512, 32, 32),
-          (2, 128, 128, 64, 96)]
+          (2, 128, 128, 64, 96), (2, 154, 154, 16, 32), (1, 160, 200, 8, 64)]
+
+
+@pytest.fixture(params=[0, 1, 2], ids=["hv_auto", "hv1_64ch_4waves", "hv2_128ch_8waves"])
+def hv(request):
+    """Workgroup shape of k_wino4 pinned through cagc_set_tuning("wino4_hv"): 64 channels x 4 waves (two workgroups per CU) or
+    128 channels x 8 waves (taken only where Cout % 128 == 0; other layers keep the 64-channel shape)."""
+    _lib.call("cagc_set_tuning", b"wino4_hv", request.param)
+    _lib.call("cagc_set_tuning", b"wino4_min_wgs", 0)       # these small launches would otherwise take the layer's F(2x2) packing
+    yield request.param
+    _lib.call("cagc_set_tuning", b"wino4_hv", 0)
+    _lib.call("cagc_set_tuning", b"wino4_min_wgs", 256)
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-def test_wino4_forward_linear_and_styled(shape):
+def test_wino4_forward_linear_and_styled(shape, hv):
     B, cin, cout, H, W = shape
-    assert _lib.query("cagc_wino_packed_elems", cin, cout) == (cout // 128) * 36 * ((cin + 15) // 16 * 16) * 128   # the F(4x4) packing
+    kp = (cin + 15) // 16 * 16
+    n4 = ((cout + 63) // 64) * 36 * kp * 64          # F(4x4) part: 64-channel tiles x 36 positions
+    assert _lib.query("cagc_wino_packed_elems", cin, cout) > n4 and (_lib.query("cagc_wino_packed_elems", cin, cout) - n4) % (16 * kp * 64) == 0   # + F(2x2) part
     torch.manual_seed(41)
     x, w = torch.randn(B, cin, H, W), torch.randn(cout, cin, 3, 3)
     s, d = torch.rand(B, cin) + 0.5, torch.rand(B, cout) + 0.5
@@ -54,10 +68,10 @@ def test_wino4_forward_linear_and_styled(shape):
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-def test_wino4_gated_data_gradient(shape):
+def test_wino4_gated_data_gradient(shape, hv):
     """gx = conv_transpose(gout * lrelu'(act_out), W) + residual in one launch (frozen discriminator ConvLayer, model.py:694-716);
     the GEMM's M is the layer's INPUT channel count here."""
-    B, cout, cin, H, W = shape          # roles swapped so that M = cin is the multiple of 128
+    B, cout, cin, H, W = shape          # roles swapped: the GEMM's M = cin takes the shapes' channel-tile cases
     torch.manual_seed(42)
     w = torch.randn(cout, cin, 3, 3)
     scale = 1.0 / (cin * 9) ** 0.5
