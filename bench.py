@@ -37,6 +37,7 @@ def wino_f4(k_ch, m_ch, B, H, W):
     """csrc/prep_device.h wino4_for_launch: this launch runs on the F(4x4,3x3) kernel (conv_wino4.hip) — eligible layer
     (K, M >= 128) whose grid of 64-channel x 8x32-pixel workgroups fills the chip; otherwise F(2x2,3x3)."""
     return (os.environ.get("CAGC_WINO_F4", "1") != "0" and m_ch >= 128 and k_ch >= 128
+            and (m_ch % 128 == 0 or os.environ.get("CAGC_WINO_F4_RAGGED", "1") != "0")
             and B * (H // 8) * (W // 32) * (-(-m_ch // 64)) >= int(os.environ.get("CAGC_WINO4_MIN_WGS", "256")))
 
 
