@@ -84,6 +84,7 @@ class _nullctx:
 # the weight gradient's workgroups fill the tail of the data-gradient launch it runs beside; per-GPU batch 2: 7.98 -> 7.83 ms).
 _SIDE_LIMIT = int(os.environ.get("CAGC_SIDE_WGRAD", str(1 << 40)))
 _side_streams = {}
+SIDE_SKIP_GEMM = os.environ.get("CAGC_SIDE_SKIP_GEMM", "1") == "1"   # ResBlock backward: skip branch's 1x1 data-gradient GEMM beside the conv branch
 
 
 def _side_stream_small(numel):
@@ -711,7 +712,7 @@ class _ResBlockFrozen(Function):
             # side stream next to the conv branch (its workgroups fill the tails of that chain's launches) and joins in front
             # of the adjoint FIR that adds it onto gx
             side = None
-            if _SIDE_LIMIT > 0:
+            if _SIDE_LIMIT > 0 and SIDE_SKIP_GEMM:
                 main = torch.cuda.current_stream()
                 side = _side_stream(dev)
                 side.wait_stream(main)
