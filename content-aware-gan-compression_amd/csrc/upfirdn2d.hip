@@ -467,6 +467,89 @@ __global__ __launch_bounds__(256) void k_blur_up_fwd(float* __restrict__ out, co
   *reinterpret_cast<float4*>(out + ((int64_t)plane * OH + Y) * OW + X) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// Same as k_blur_up_fwd on a 64-wide x 32-tall output tile: the aligned superset of phase-plane columns staged per tile is 40 for
+// 34 needed (32-wide: 24 for 18), so the tile reads 1.41x instead of 1.69x its output in halo, and one barrier serves twice the
+// outputs.  Taken when the output is at least 64 wide.
+__global__ __launch_bounds__(256) void k_blur_up_fwd_w64(float* __restrict__ out, const float* __restrict__ t,
+                                                         const float* __restrict__ fir, const float* __restrict__ d,
+                                                         const float* __restrict__ noise, int noise_bstride_on,
+                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                         int C, int H, int W, int tiles_x, int tiles_y, float alpha,
+                                                         float act_scale) {
+  constexpr int TW = 64;
+  constexpr int LR = FT + 4, LW = TW + 4 + 1;      // rows Y0-2 .. Y0+33, cols X0-2 .. X0+65 (+1 pad)
+  constexpr int HR = LR / 2, HC = (TW + 4) / 2;     // 18 phase rows, 34 phase columns
+  constexpr int NQ = (HC + 3 + 3) / 4;              // float4 loads per phase row from the aligned start n0 - 3: 10
+  __shared__ float tile[LR * LW];
+  __shared__ float kf[16];
+  int bid = blockIdx.x;
+  const int X0 = (bid % tiles_x) * TW;
+  bid /= tiles_x;
+  const int Y0 = (bid % tiles_y) * FT;
+  const int plane = bid / tiles_y;  // b*C + c
+  const int b = plane / C, c = plane - b * C;
+  const int PH = H + 1, PW = W + 1, PWp = (W + 1 + 3) & ~3;
+  const float* tp = t + (int64_t)plane * 4 * PH * PWp;
+  if (threadIdx.x < 16) kf[threadIdx.x] = fir[15 - threadIdx.x];
+  const int m0 = (Y0 - 2) / 2, n0 = (X0 - 2) / 2;   // exact (Y0 % 32 == 0, X0 % 64 == 0); n0 == 3 (mod 4)
+  for (int e = threadIdx.x; e < 4 * HR * NQ; e += 256) {
+    const int q = e % NQ;
+    const int mr = (e / NQ) % HR;
+    const int ph = e / (NQ * HR);
+    const int m = m0 + mr, na = n0 - 3 + 4 * q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m >= 0 && m < PH && na >= 0 && na < PWp) v = *reinterpret_cast<const float4*>(tp + ((int64_t)ph * PH + m) * PWp + na);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    float* trow = tile + (2 * mr + (ph >> 1)) * LW + (ph & 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int n = na + k, nc = n - n0;
+      if (nc >= 0 && nc < HC) trow[2 * nc] = (n >= 0 && n < PW) ? vv[k] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int OH = 2 * H, OW = 2 * W;
+  const int cg = threadIdx.x & 15, y0 = threadIdx.x >> 4;      // 16 column groups of 4, 16 rows per pass
+  const int X = X0 + 4 * cg;
+  if (X >= OW) return;
+  const float dv = d ? d[plane] : 1.f;
+  const float nw = noise ? noise_w[0] : 0.f;
+  const float bv = bias ? bias[c] : 0.f;
+  const bool act = (bias != nullptr);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int yy = y0 + 16 * pass, Y = Y0 + yy;
+    if (Y >= OH) break;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float w[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) w[j] = tile[(yy + 1 + a) * LW + 4 * cg + 1 + j];
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const float k = kf[a * 4 + bb];
+        acc[0] += w[bb] * k; acc[1] += w[bb + 1] * k; acc[2] += w[bb + 2] * k; acc[3] += w[bb + 3] * k;
+      }
+    }
+    float4 nzv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act && noise)
+      nzv = *reinterpret_cast<const float4*>(noise + (noise_bstride_on ? (int64_t)b * OH * OW : 0) + (int64_t)Y * OW + X);
+    const float nn[4] = {nzv.x, nzv.y, nzv.z, nzv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = acc[k] * dv;
+      if (act) {
+        v += bv + nw * nn[k];
+        v = (v > 0.f ? v : v * alpha) * act_scale;
+      }
+      o[k] = v;
+    }
+    *reinterpret_cast<float4*>(out + ((int64_t)plane * OH + Y) * OW + X) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // gT_full[Yt,Xt] = sum_{a,b} kf[a][b] * gz[Yt+1-a, Xt+1-b]  for Yt in [0,2H], Xt in [0,2W]; the phase
 // planes' extra entries (Yt = 2H+1 or Xt = 2W+1) are written as zero.
 __global__ __launch_bounds__(256) void k_blur_up_bwd(float* __restrict__ gt, const float* __restrict__ gz,
@@ -576,7 +659,12 @@ extern "C" int cagc_blur_up_fwd(float* out, const float* t, const float* fir, co
   const int64_t nb = (int64_t)B * C * tx * ty;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_blur_up_fwd: too large");
   const bool vec = (W % 2 == 0) && (((uintptr_t)out | (uintptr_t)t | (uintptr_t)noise) % 16 == 0);
-  if (vec)
+  static const int w64_on = getenv("CAGC_BLUR_W64") ? atoi(getenv("CAGC_BLUR_W64")) : 1;
+  if (vec && w64_on && 2 * W >= 64) {
+    const int tx64 = cdiv(2 * W, 64);
+    hipLaunchKernelGGL(k_blur_up_fwd_w64, dim3((unsigned)((int64_t)B * C * tx64 * ty)), dim3(256), 0, as_stream(stream), out, t, fir,
+                       d, noise, noise_batch == B ? 1 : 0, noise_w, bias, C, H, W, tx64, ty, alpha, act_scale);
+  } else if (vec)
     hipLaunchKernelGGL(k_blur_up_fwd, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, t, fir, d, noise,
                        noise_batch == B ? 1 : 0, noise_w, bias, C, H, W, tx, ty, alpha, act_scale);
   else
