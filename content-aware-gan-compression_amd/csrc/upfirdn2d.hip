@@ -266,16 +266,19 @@ __global__ __launch_bounds__(256) void k_fir4_down2(float* __restrict__ out, con
 // 32 x 32 output tile; the input footprint is staged with float4 loads from the aligned superset of columns
 // [tx0 - 4, tx0 + 36); every thread produces 4 horizontally adjacent outputs (4 x 7 register window) and stores them
 // as one float4 — 3.5x fewer memory instructions than the scalar kernel on the discriminator's large blurs.
+// TW = output tile width: 32, or 64 for tensors at least that wide (72 staged columns per 64 instead of 40 per 32).
+template <int TW>
 __global__ __launch_bounds__(256) void k_fir4_vec(float* __restrict__ out, const float* __restrict__ x,
                                                   const float* __restrict__ kern, int in_h, int in_w, int in_pitch,
                                                   int out_h, int out_w, int out_pitch, int pad_x0, int pad_y0,
                                                   int tiles_x, int tiles_y) {
   constexpr int FTH = 2 * FT;                                      // 64 output rows per workgroup: more loads in flight
-  constexpr int IH = FTH + 3, Q = (FT + 8) / 4, LW = FT + 8 + 1;   // 67 rows x 10 float4; odd row stride
+  constexpr int IH = FTH + 3, Q = (TW + 8) / 4, LW = TW + 8 + 1;   // 67 rows x 10 / 18 float4; odd row stride
+  constexpr int NCG = TW / 4, RPP = 256 / NCG;                     // column groups of 4 outputs, rows per pass
   __shared__ float tile[IH * LW];
   __shared__ float kf[16];
   int bid = blockIdx.x;
-  const int tx0 = (bid % tiles_x) * FT;
+  const int tx0 = (bid % tiles_x) * TW;
   bid /= tiles_x;
   const int ty0 = (bid % tiles_y) * FTH;
   const int64_t p = bid / tiles_y;
@@ -297,12 +300,12 @@ __global__ __launch_bounds__(256) void k_fir4_vec(float* __restrict__ out, const
     t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
   }
   __syncthreads();
-  const int cg = threadIdx.x & 7;
+  const int cg = threadIdx.x % NCG;
   const int ox = tx0 + 4 * cg;
   if (ox >= out_pitch) return;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int row = (threadIdx.x >> 3) + 32 * half;
+  for (int half = 0; half < FTH / RPP; ++half) {
+    const int row = threadIdx.x / NCG + RPP * half;
     const int oy = ty0 + row;
     if (oy >= out_h) continue;
     const float* w0 = tile + row * LW + (4 - pad_x0) + 4 * cg;   // LDS col 0 <-> global col tx0 - 4
@@ -595,6 +598,13 @@ __global__ __launch_bounds__(256) void k_blur_up_bwd(float* __restrict__ gt, con
   }
 }
 
+// CAGC_BLUR_W64=0: 32-wide tiles everywhere; 1 (default): 64-wide tiles for the blur behind the transposed conv (0.85 -> 0.70
+// ms/step); 2: also for the plain 4x4 FIR (k_fir4_vec<64>: 18 staged float4 per 64 columns instead of 10 per 32 — no gain measured)
+static int fir_w64() {
+  static const int v = getenv("CAGC_BLUR_W64") ? atoi(getenv("CAGC_BLUR_W64")) : 1;
+  return v;
+}
+
 }  // namespace cagc
 
 using namespace cagc;
@@ -618,8 +628,13 @@ extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, i
     CAGC_REQUIRE(nb < (1ll << 31), "cagc_upfirdn2d: too large");
     if (in_w % 4 == 0 && out_w % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0) {
       const int ty2 = cdiv(out_h, 2 * FT);
-      hipLaunchKernelGGL(k_fir4_vec, dim3((unsigned)(planes * tx * ty2)), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w, out_h,
-                         out_w, out_w, pad_x0, pad_y0, tx, ty2);
+      if (fir_w64() == 2 && out_w >= 64) {   // measured neutral-to-worse (1.134 vs 1.119 ms/step): opt-in only (CAGC_BLUR_W64=2)
+        const int tx64 = cdiv(out_w, 64);
+        hipLaunchKernelGGL(k_fir4_vec<64>, dim3((unsigned)(planes * tx64 * ty2)), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w,
+                           out_h, out_w, out_w, pad_x0, pad_y0, tx64, ty2);
+      } else
+        hipLaunchKernelGGL(k_fir4_vec<32>, dim3((unsigned)(planes * tx * ty2)), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w,
+                           out_h, out_w, out_w, pad_x0, pad_y0, tx, ty2);
     }
     else
       hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, in_w, out_h, out_w,
@@ -659,8 +674,7 @@ extern "C" int cagc_blur_up_fwd(float* out, const float* t, const float* fir, co
   const int64_t nb = (int64_t)B * C * tx * ty;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_blur_up_fwd: too large");
   const bool vec = (W % 2 == 0) && (((uintptr_t)out | (uintptr_t)t | (uintptr_t)noise) % 16 == 0);
-  static const int w64_on = getenv("CAGC_BLUR_W64") ? atoi(getenv("CAGC_BLUR_W64")) : 1;
-  if (vec && w64_on && 2 * W >= 64) {
+  if (vec && fir_w64() && 2 * W >= 64) {
     const int tx64 = cdiv(2 * W, 64);
     hipLaunchKernelGGL(k_blur_up_fwd_w64, dim3((unsigned)((int64_t)B * C * tx64 * ty)), dim3(256), 0, as_stream(stream), out, t, fir,
                        d, noise, noise_batch == B ? 1 : 0, noise_w, bias, C, H, W, tx64, ty, alpha, act_scale);
@@ -699,8 +713,13 @@ extern "C" int cagc_fir4x4_pitched(float* out, const float* x, const float* kern
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_fir4x4_pitched: too large");
   if (in_pitch % 4 == 0 && out_pitch % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0) {
     const int ty2 = cdiv(out_h, 2 * FT);
-    hipLaunchKernelGGL(k_fir4_vec, dim3((unsigned)(planes * tx * ty2)), dim3(256), 0, as_stream(stream), out, x, kernel, in_h,
-                       in_w, in_pitch, out_h, out_w, out_pitch, pad_x0, pad_y0, tx, ty2);
+    if (fir_w64() == 2 && out_pitch >= 64) {
+      const int tx64 = cdiv(out_pitch, 64);
+      hipLaunchKernelGGL(k_fir4_vec<64>, dim3((unsigned)(planes * tx64 * ty2)), dim3(256), 0, as_stream(stream), out, x, kernel, in_h,
+                         in_w, in_pitch, out_h, out_w, out_pitch, pad_x0, pad_y0, tx64, ty2);
+    } else
+      hipLaunchKernelGGL(k_fir4_vec<32>, dim3((unsigned)(planes * tx * ty2)), dim3(256), 0, as_stream(stream), out, x, kernel, in_h,
+                         in_w, in_pitch, out_h, out_w, out_pitch, pad_x0, pad_y0, tx, ty2);
   }
   else
     hipLaunchKernelGGL((k_fir_s1<4, 4>), dim3((unsigned)nb), dim3(256), 0, as_stream(stream), out, x, kernel, in_h, in_w,
