@@ -598,6 +598,63 @@ __global__ __launch_bounds__(256) void k_blur_up_bwd(float* __restrict__ gt, con
   }
 }
 
+// 16-byte version of k_blur_up_bwd on a 64-wide x 32-tall tile of the T_full grid (per parity plane: 16 rows x 32 columns):
+// gz staged with float4 loads from the aligned superset of columns [X0-4, X0+68); a thread produces 4 adjacent columns of one
+// plane row from a 4 x 10 register window (10 LDS reads per output instead of 16) and stores them as one float4 — 128-byte row
+// segments per plane instead of 64.  Needs 2W % 4 == 0 and 16-byte aligned tensors (the pitch is a multiple of 4 by definition).
+__global__ __launch_bounds__(256) void k_blur_up_bwd_v(float* __restrict__ gt, const float* __restrict__ gz,
+                                                       const float* __restrict__ fir, int H, int W, int tiles_x,
+                                                       int tiles_y) {
+  constexpr int TW = 64, LR = FT + 3, NQ = (TW + 8) / 4, LW = TW + 8 + 1;   // 35 rows x 18 float4 (72 columns)
+  __shared__ float tile[LR * LW];
+  __shared__ float kf[16];
+  int bid = blockIdx.x;
+  const int X0 = (bid % tiles_x) * TW;
+  bid /= tiles_x;
+  const int Y0 = (bid % tiles_y) * FT;
+  const int plane = bid / tiles_y;
+  const int OH = 2 * H, OW = 2 * W, PH = H + 1, PWp = (W + 1 + 3) & ~3;
+  const float* gp = gz + (int64_t)plane * OH * OW;
+  float* tp = gt + (int64_t)plane * 4 * PH * PWp;
+  if (threadIdx.x < 16) kf[threadIdx.x] = fir[15 - threadIdx.x];
+  for (int e = threadIdx.x; e < LR * NQ; e += 256) {
+    const int r = e / NQ, q = e - r * NQ;
+    const int y = Y0 - 2 + r, x = X0 - 4 + 4 * q;       // x % 4 == 0 and OW % 4 == 0: a float4 is inside or outside as a whole
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y >= 0 && y < OH && x >= 0 && x < OW) v = *reinterpret_cast<const float4*>(gp + (int64_t)y * OW + x);
+    float* t = tile + r * LW + 4 * q;
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+  }
+  __syncthreads();
+  // item = (plane ph, row ml, group ng of 4 columns): 4 x 16 x 8 = 512 items, two per thread; ng fastest -> 128-byte row segments
+  for (int e = threadIdx.x; e < 4 * 16 * 8; e += 256) {
+    const int ng = e & 7, ml = (e >> 3) & 15, ph = e >> 7;
+    const int py = ph >> 1, px = ph & 1;
+    const int m = Y0 / 2 + ml, n = X0 / 2 + 4 * ng;
+    if (m >= PH || n >= PWp) continue;                   // n, PWp multiples of 4: the float4 is inside or outside as a whole
+    const int yl = 2 * ml + py;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (Y0 + yl <= OH) {
+      // gz row Yt+1-a -> LDS row yl + 3 - a; gz column Xt+1-bb with Xt = X0 + 8ng + 2j + px -> LDS column 8ng + px + 2 + (2j + 3 - bb)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float* row = tile + (yl + 3 - a) * LW + 8 * ng + px + 2;
+        float w[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) w[i] = row[i];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const float k = kf[a * 4 + bb];
+          acc[0] += w[3 - bb] * k; acc[1] += w[5 - bb] * k; acc[2] += w[7 - bb] * k; acc[3] += w[9 - bb] * k;
+        }
+      }
+    }
+    const int Xt = X0 + 8 * ng + px;                     // T_full column of output 0; entries past 2W are the planes' zero padding
+    const float4 o = make_float4(Xt <= OW ? acc[0] : 0.f, Xt + 2 <= OW ? acc[1] : 0.f, Xt + 4 <= OW ? acc[2] : 0.f, Xt + 6 <= OW ? acc[3] : 0.f);
+    *reinterpret_cast<float4*>(tp + ((int64_t)ph * PH + m) * PWp + n) = o;
+  }
+}
+
 // CAGC_BLUR_W64=0: 32-wide tiles everywhere; 1 (default): 64-wide tiles for the blur behind the transposed conv (0.85 -> 0.70
 // ms/step); 2: also for the plain 4x4 FIR (k_fir4_vec<64>: 18 staged float4 per 64 columns instead of 10 per 32 — no gain measured)
 static int fir_w64() {
@@ -694,7 +751,12 @@ extern "C" int cagc_blur_up_bwd(float* gt, const float* gz, const float* fir, in
   const int tx = cdiv(2 * W + 2, FT), ty = cdiv(2 * H + 2, FT);
   const int64_t nb = (int64_t)B * C * tx * ty;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_blur_up_bwd: too large");
-  hipLaunchKernelGGL(k_blur_up_bwd, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), gt, gz, fir, H, W, tx, ty);
+  if (fir_w64() && W % 2 == 0 && 2 * W >= 64 && (((uintptr_t)gt | (uintptr_t)gz) % 16) == 0) {
+    const int tx64 = cdiv(2 * W + 2, 64);
+    hipLaunchKernelGGL(k_blur_up_bwd_v, dim3((unsigned)((int64_t)B * C * tx64 * ty)), dim3(256), 0, as_stream(stream), gt, gz, fir, H, W,
+                       tx64, ty);
+  } else
+    hipLaunchKernelGGL(k_blur_up_bwd, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), gt, gz, fir, H, W, tx, ty);
   return check_launch("cagc_blur_up_bwd");
 }
 
