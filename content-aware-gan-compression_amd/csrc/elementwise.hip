@@ -209,9 +209,13 @@ __global__ __launch_bounds__(EW_THREADS) void k_styled_act_bwd(float* __restrict
   const float s2 = block_sum(r2, sm);
   if (threadIdx.x == 0) {
     const int64_t BC = (int64_t)B * C;
-    sink_add(det, red + plane, s0);
-    sink_add(det, red + BC + plane, s1);
-    sink_add(det, red + 2 * BC + plane, s2);
+    if (nchunk == 1) {       // the plane's only workgroup: plain stores, `red` needs no zero-fill (small layers, small batches)
+      red[plane] = s0; red[BC + plane] = s1; red[2 * BC + plane] = s2;
+    } else {
+      sink_add(det, red + plane, s0);
+      sink_add(det, red + BC + plane, s1);
+      sink_add(det, red + 2 * BC + plane, s2);
+    }
   }
 }
 
@@ -371,13 +375,13 @@ extern "C" int cagc_styled_act_bwd(float* gz, float* red, const float* gout, con
   CAGC_REQUIRE(!noise || noise_batch == 1 || noise_batch == B, "cagc_styled_act_bwd: noise batch %d not in {1,%d}",
                noise_batch, B);
   hipStream_t st = as_stream(stream);
-  { int zrc = zero_fill(red, sizeof(float) * 3 * (size_t)B * C, st); if (zrc) return zrc; }
   const int nchunk = cdiv(HW, EW_CHUNK);
+  if (nchunk > 1) { int zrc = zero_fill(red, sizeof(float) * 3 * (size_t)B * C, st); if (zrc) return zrc; }
   const int64_t nb = (int64_t)B * C * nchunk;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_styled_act_bwd: too large");
   const bool vec = (HW % 4 == 0) && (((uintptr_t)gz | (uintptr_t)gout | (uintptr_t)out | (uintptr_t)noise) % 16 == 0);
   DetSink det;
-  { const int drc = det_begin(det, red, 3 * (int64_t)B * C, st, "cagc_styled_act_bwd"); if (drc) return drc; }
+  { const int drc = det_begin(det, nchunk > 1 ? red : nullptr, 3 * (int64_t)B * C, st, "cagc_styled_act_bwd"); if (drc) return drc; }
   if (vec)
     hipLaunchKernelGGL((k_styled_act_bwd<true>), dim3((unsigned)nb), dim3(EW_THREADS), 0, st, gz, red, gout, out, d,
                        noise, noise_batch == B ? 1 : 0, B, C, HW, nchunk, alpha, act_scale, det);

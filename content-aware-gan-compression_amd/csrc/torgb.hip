@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) void k_torgb_bwd(float* __restrict__ gx, float
     const int c = c0 + k;
     if (c < C) {
       const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-      sink_add(det, gws + ((int64_t)b * 3 + o) * C + c, v);
+      if (nsplit == 1) gws[((int64_t)b * 3 + o) * C + c] = v;     // the only workgroup of this (image, channel group): no zero-fill needed
+      else sink_add(det, gws + ((int64_t)b * 3 + o) * C + c, v);
     }
   }
 }
@@ -276,15 +277,15 @@ extern "C" int cagc_torgb_bwd(float* gx, float* gws, const float* g, const float
   CAGC_REQUIRE(gx && gws && g && x && w && s, "%s: null tensor", what);
   CAGC_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "%s: bad shape", what);
   hipStream_t st = as_stream(stream);
-  { int zrc = zero_fill(gws, sizeof(float) * (size_t)B * 3 * C, st); if (zrc) return zrc; }
   const int64_t HW = (int64_t)H * W;
   const int nchunk = cdiv(C, RGB_CCH);
   int nsplit = (2048 + B * nchunk - 1) / (B * nchunk);
   const int maxsplit = cdiv(HW, 1024);
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
+  if (nsplit > 1) { int zrc = zero_fill(gws, sizeof(float) * (size_t)B * 3 * C, st); if (zrc) return zrc; }
   DetSink det;
-  { const int drc = det_begin(det, gws, (int64_t)B * 3 * C, st, what); if (drc) return drc; }
+  { const int drc = det_begin(det, nsplit > 1 ? gws : nullptr, (int64_t)B * 3 * C, st, what); if (drc) return drc; }
   hipLaunchKernelGGL(k_torgb_bwd, dim3((unsigned)(B * nchunk * nsplit)), dim3(256), 0, st, gx, gws, g, x, w, s, C, HW,
                      nchunk, nsplit, scale, det);
   { const int drc = check_launch(what); if (drc) return drc; }
