@@ -243,6 +243,12 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
     const int pos = (3 * WI + p / 3) * 6 + 3 * WJ + p % 3;
     return ((pos * KQ + 2 * chunk + s) * 256) * 4;
   };
+#ifndef W4_XF_AT
+#define W4_XF_AT 8      // group of the chunk at which the transforming waves run chunk j+1's input transform
+#endif
+#ifndef W4_CM_AT
+#define W4_CM_AT 6      // (measured: 12 -> 6 is -4 % on 128 -> 128 @256^2, neutral on 512 channels) group at which the raw tile of chunk j+2 is committed to LDS and chunk j+3 is requested
+#endif
 #ifndef CAGC_W4_RING
 #define CAGC_W4_RING 6
 #endif
@@ -305,8 +311,8 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
         if (gi + RING < 18) load_a(slot, gi + RING, j);
         else load_a(slot, gi + RING - 18, jn);
       }
-      if (xf && gi == 8 && !W4_ABL(1)) transform(rnext, vnext);   // chunk j+1's input transform; the partner wave's MFMAs cover its LDS latency
-      if (gi == 12 && !W4_ABL(2)) {                // raw[cur] (chunk j) was transformed during chunk j-1: refill it with chunk j+2
+      if (xf && gi == W4_XF_AT && !W4_ABL(1)) transform(rnext, vnext);   // chunk j+1's input transform; the partner wave's MFMAs cover its LDS latency
+      if (gi == W4_CM_AT && !W4_ABL(2)) {                // raw[cur] (chunk j) was transformed during chunk j-1: refill it with chunk j+2
         commit(raw + cur * W4_RSZ);
         prefetch(j + 3);
       }
