@@ -636,7 +636,7 @@ class ConvLayer(nn.Sequential):
         # from-RGB layer with frozen weights (generator step): two streaming kernels (3 input channels is no GEMM)
         if (self._fused_1x1 and mc.use_hip(input) and input.dtype == torch.float32 and input.shape[1] == 3
                 and (input.shape[2] * input.shape[3]) % 4 == 0 and self[1].bias is not None and self[1].negative_slope == 0.2
-                and not self[0].weight.requires_grad and not self[1].bias.requires_grad):
+                and not self[0].weight.requires_grad and not self[1].bias.requires_grad and not mc.composed_active()):
             return mc._FromRGBFrozen.apply(input, self[0].weight, self[1].bias, self[0].scale)
         # 1x1 conv + FusedLeakyReLU (the discriminator's from-RGB layer), and the 3x3 ones too small for the Winograd tiling
         # (4^2 .. 16^2), as one implicit-GEMM launch with the bias + LeakyReLU epilogue
@@ -676,8 +676,8 @@ class ResBlock(nn.Module):
         """Generator step (D frozen, only the input gradient wanted), Winograd-sized feature map, the stock layer pattern."""
         c1, c2, sk = self.conv1, self.conv2, self.skip
         if not (mc.FUSE_RESBLOCK and mc.WINO_DGRAD and mc.FUSE_ACT_DGRAD and mc.use_hip(input) and input.dtype == torch.float32
-                and torch.is_grad_enabled() and input.requires_grad and input.dim() == 4):
-            return False
+                and torch.is_grad_enabled() and input.requires_grad and input.dim() == 4 and not mc.composed_active()):
+            return False        # (second-order passes announce themselves with mc.composed_autograd(): layer-by-layer, differentiable)
         if any(p.requires_grad for p in self.parameters()):
             return False
         H, W = input.shape[2], input.shape[3]

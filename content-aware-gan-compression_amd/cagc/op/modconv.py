@@ -52,6 +52,16 @@ def composed_active():
     return getattr(_tls, "depth", 0) > 0
 
 
+def _first_order_only(what):
+    """The frozen-discriminator fused nodes return final kernels' results from backward: they cannot be differentiated again.
+    Under create_graph=True autograd runs backward with grad mode ON — say so here, at the first backward, instead of failing
+    with a generic error at double-backward time."""
+    if torch.is_grad_enabled():
+        raise RuntimeError(f"{what}: create_graph=True through the frozen discriminator's fused node is not supported; run the "
+                           "forward inside `with cagc.op.modconv.composed_autograd():` (layer-by-layer, twice differentiable) or "
+                           "leave the discriminator's parameters trainable")
+
+
 _flip_cache = {}
 
 
@@ -505,8 +515,13 @@ class _FromRGBFrozen(Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gout):
+        _first_order_only("from-RGB layer (frozen)")
+        with torch.no_grad():
+            return _FromRGBFrozen._backward(ctx, gout)
+
+    @staticmethod
+    def _backward(ctx, gout):
         out, w = ctx.saved_tensors
         B, C, H, W = out.shape
         gout = gout.contiguous()
@@ -699,8 +714,13 @@ class _ResBlockFrozen(Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g):
+        _first_order_only("ResBlock (frozen)")
+        with torch.no_grad():
+            return _ResBlockFrozen._backward(ctx, g)
+
+    @staticmethod
+    def _backward(ctx, g):
         from .upfirdn2d import _launch
         y1, y2a, up1_bwd, wp2_bwd, wpsk_bwd, fir2, firsk = ctx.saved_tensors
         B, C, H, W, cout, ho, wo, hb, wb, pitch, pad2, padsk = ctx.cfg

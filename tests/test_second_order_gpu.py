@@ -228,3 +228,37 @@ def test_modulation_bank_matches_per_layer_linears():
             assert_close(a, b, 1e-5, f"bank s (B={B})")
         for nm, a, b in zip(["latent"] + ["w"] * 5 + ["b"] * 5, grads, gref):
             assert_close(a, b, 1e-5, f"bank grad {nm} (B={B})")
+
+
+def test_frozen_discriminator_second_order_needs_composed_mode():
+    """a create_graph pass through the FROZEN discriminator's fused nodes (ResBlock / from-RGB as one autograd node whose
+    backward returns final kernel results) must not fail with a generic error at double-backward time: it raises at the FIRST
+    backward and names the remedy — `composed_autograd()`, under which the layer-by-layer, twice-differentiable path runs and
+    gives the trainable discriminator's numbers."""
+    from cagc.op import modconv as mc
+    torch.manual_seed(3)
+    d = M.Discriminator(32).to(DEV)
+    x = torch.randn(2, 3, 32, 32, device=DEV)
+
+    def penalty_grad(xin):
+        pred = d(xin)
+        (g,) = torch.autograd.grad(pred.sum(), xin, create_graph=True)
+        (gg,) = torch.autograd.grad(g.pow(2).sum(), xin)
+        return gg
+
+    ref = penalty_grad(x.clone().requires_grad_(True))            # trainable D: the R1 path (tested against float64 above)
+    kd.requires_grad(d, False)
+    with pytest.raises(RuntimeError, match="composed_autograd"):
+        penalty_grad(x.clone().requires_grad_(True))
+    with mc.composed_autograd():
+        got = penalty_grad(x.clone().requires_grad_(True))
+    # same function, other kernels (composed ops vs the fused Winograd layers): activations differ at 1e-5, which moves a few
+    # LeakyReLU gates of this random net — the numbers are pinned against float64 by the tests above; here: same result class
+    assert_close(got, ref, 5e-3, "second-order input gradient through the frozen discriminator (composed mode)")
+    # and the first-order fused path is untouched
+    xin = x.clone().requires_grad_(True)
+    (g1,) = torch.autograd.grad(d(xin).sum(), xin)
+    kd.requires_grad(d, True)
+    xin2 = x.clone().requires_grad_(True)
+    (g2,) = torch.autograd.grad(d(xin2).sum(), xin2)
+    assert_close(g1, g2, 1e-4, "first-order input gradient: fused frozen nodes vs layer-by-layer")
