@@ -34,11 +34,10 @@ PEAK_HBM_GBS = 8000.0
 
 
 def wino_f4(k_ch, m_ch, B, H, W):
-    """csrc/prep_device.h wino4_for_launch: this launch runs on the F(4x4,3x3) kernel (conv_wino4.hip) — eligible layer
-    (K, M >= 128) whose grid of 64-channel x 8x32-pixel workgroups fills the chip; otherwise F(2x2,3x3)."""
-    return (os.environ.get("CAGC_WINO_F4", "1") != "0" and m_ch >= 128 and k_ch >= 128
-            and (m_ch % 128 == 0 or os.environ.get("CAGC_WINO_F4_RAGGED", "1") != "0")
-            and B * (H // 8) * (W // 32) * (-(-m_ch // 64)) >= int(os.environ.get("CAGC_WINO4_MIN_WGS", "256")))
+    """This launch runs on the F(4x4,3x3) kernel (conv_wino4.hip) — the LIBRARY's own per-launch decision under its current
+    tuning (include/cagc.h cagc_wino_plan = csrc/prep_device.h wino4_for_launch), not a re-derivation."""
+    from cagc import _lib
+    return _lib.query("cagc_wino_plan", int(B), int(k_ch), int(m_ch), int(H), int(W)) == 4
 
 
 def wino_macs(k_ch, m_ch, B, H, W):
@@ -124,7 +123,7 @@ def pmc_traffic(symbol):
         return None, "the committed PMC passes profile the 256 px workload"
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_{c}.md") for r in ("r03", "r02", "r01")) if os.path.exists(q)), None)
+        path = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_{c}.md") for r in ("r04", "r03")) if os.path.exists(q)), None)
         if path is None:
             return None, "no committed PMC summary"
         for line in open(path):
@@ -225,7 +224,7 @@ def cpu_baseline(steps=3, batch=16, budget_s=120.0, threads=None):
     while len(times) < steps and sum(times) < budget_s:
         times.append(one(batch))
     med = sorted(times)[len(times) // 2]
-    return {"value": round(batch / med, 4), "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": round(batch / med, 4), "unit": "images/s", "cores": cores, "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{len(times)} timed KD generator step(s) at batch {batch} of the 256px bs16 workload after a batch-2 warm-up; "
                       f"median {med:.1f} s/step (all: {', '.join(f'{t:.1f}' for t in times)} s)",
             "cpu_model": _cpu_model()}
@@ -281,6 +280,7 @@ def main():
                          "(per-GPU batch 4) is timed, the secondary legs are skipped")
     ap.add_argument("--local-batch", type=int, default=0, help="per-GPU batch override (default: global batch 16 / world size; "
                                                                "--size 1024 at --gpus 1: 4)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the compact configs[3] (1024 px, per-GPU batch 4) leg")
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong-scaling proxy table (per-GPU batch 8/4/2 on this GPU)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed bs-16 steps of the CPU baseline (SURVEY 8-d: 3)")
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -313,7 +313,7 @@ def main():
     if bs * world != GLOBAL_BATCH:
         share = f"one GPU at per-GPU batch {bs} = the share of one rank of a {GLOBAL_BATCH // bs}-GPU run of global batch {GLOBAL_BATCH}"
     if SIZE != 256:            # the secondary legs belong to the 256 px headline configuration
-        args.no_full_iteration, args.no_proxy, args.sweep, args.no_cpu_baseline = True, True, 0, True
+        args.no_full_iteration, args.no_proxy, args.sweep, args.no_cpu_baseline, args.no_config3 = True, True, 0, True, True
 
     student, teacher, disc = kd.build_synthetic_workload(SIZE, dev, seed=0)
     n_params = sum(p.numel() for p in student.parameters())
@@ -515,6 +515,46 @@ def main():
         for lb in (8, 4, 2):
             tb = min(v for k, v in proxy[str(lb)].items() if k.endswith("_ms") and v is not None)
             proxy[str(lb)]["max_strong_scaling_efficiency"] = round(t16 / ((GLOBAL_BATCH // lb) * tb), 3)
+    det = None
+    if world == 1 and not args.no_proxy and not os.environ.get("CAGC_BENCH_LOCAL_BS"):
+        # The same step in deterministic mode (cagc_set_tuning("deterministic", 1): no fp32-atomic K split, every backward reduction
+        # through the order-independent sink — forward AND gradients bit-reproducible run to run): the price of reproducibility
+        det = {}
+        with _lib.tuning(deterministic=1):
+            for lb in (16, 2):
+                try:
+                    det[str(lb)] = {"graph_ms": round(_time_mode(kd, cd, student, teacher, disc, lb, kd.ellipse_mask(lb, SIZE, dev), 1, dev, rng, gen, "graph"), 3)}
+                except Exception as e:  # noqa: BLE001
+                    det[str(lb)] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+        for lb in (16, 2):
+            base = (proxy or {}).get(str(lb), {}).get("graph_ms")
+            if base and det[str(lb)].get("graph_ms"):
+                det[str(lb)]["default_mode_graph_ms"] = base
+                det[str(lb)]["overhead"] = round(det[str(lb)]["graph_ms"] / base - 1.0, 4)
+    c3 = None
+    if world == 1 and SIZE == 256 and not args.no_config3:
+        # BASELINE configs[3] (1024 px pruned student [..,20,20,10,10] + full 1024 px teacher + D(1024), global batch 16 over 4
+        # GPUs): ONE rank's share (per-GPU batch 4) on this GPU, HIP-graph replay, a few steps — the driver-visible figure
+        try:
+            s3, t3, d3 = kd.build_synthetic_workload(1024, dev, seed=0)
+            m3 = kd.ellipse_mask(4, 1024, dev)
+            st3 = kd.GraphedKDStep(s3, t3, d3, 4, m3, random_noise=True, world_size=1)
+            for _ in range(2):
+                st3.sample_and_step(4, m3, rng, gen)
+            torch.cuda.synchronize()
+            t3a = time.perf_counter()
+            for _ in range(6):
+                st3.sample_and_step(4, m3, rng, gen)
+            torch.cuda.synchronize()
+            dt3 = (time.perf_counter() - t3a) / 6
+            c3 = {"value": round(4 / dt3, 2), "unit": "images/s", "ms_per_step": round(dt3 * 1e3, 3), "per_gpu_batch": 4, "steps": 6,
+                  "what": "configs[3]: 1024px 70%-pruned student [154x10,77,77,39,39,20,20,10,10] + full 1024px teacher + D(1024) KD generator "
+                          "step; one rank's share (per-GPU batch 4 of the 4-GPU global batch 16), HIP-graph replay; x4 = the job's upper bound"}
+            del st3, s3, t3, d3
+        except Exception as e:  # noqa: BLE001
+            c3 = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     sweep = None
     if world == 1 and args.sweep:
         # BASELINE configs[4]: prune.py's content-aware saliency sweep over the FULL 256 px generator, bs 64 (forward +
@@ -539,20 +579,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_steps, args.cpu_batch)
         allc = os.cpu_count() or 1
-        if allc > cpu["cores"]:
-            # SURVEY 8-d names torch.set_num_threads(os.cpu_count()).  Measured once on the GPU box (gpurun_out/bench_r3_d.json,
-            # 2x EPYC 9575F = 256 hardware threads): ONE bs-4 step took 297.7 s = 0.0134 img/s — the grouped-conv CPU kernels
-            # oversubscribe badly beyond ~32 threads — so the default line quotes that measurement and re-times it only on request
-            if args.cpu_all_cores:
-                try:
-                    ac = cpu_baseline(1, 4, 60.0, threads=allc)
-                    cpu["all_cores"] = {"value": ac["value"], "unit": "images/s", "cores": allc, "sample": ac["sample"]}
-                except Exception as e:  # noqa: BLE001
-                    cpu["all_cores"] = {"error": f"{type(e).__name__}: {e}", "cores": allc}
-            else:
-                cpu["all_cores"] = {"value": 0.0134, "unit": "images/s", "cores": 256, "measured": "round 3, gpurun_out/bench_r3_d.json",
-                                    "sample": "1 timed KD generator step at batch 4 after a batch-2 warm-up: 297.7 s (256 threads "
-                                              "oversubscribe the grouped-conv CPU kernels); re-time with --cpu-all-cores (+5 min)"}
+        if allc > cpu["cores"] and args.cpu_all_cores:
+            # SURVEY 8-d names torch.set_num_threads(os.cpu_count()); the grouped-conv CPU kernels oversubscribe badly beyond ~32
+            # threads (round 3, 2x EPYC 9575F = 256 hardware threads: 0.0134 img/s), so it is timed only on request (+5 min)
+            try:
+                ac = cpu_baseline(1, 4, 60.0, threads=allc)
+                cpu["all_cores"] = {"value": ac["value"], "unit": "images/s", "cores": allc, "sample": ac["sample"]}
+            except Exception as e:  # noqa: BLE001
+                cpu["all_cores"] = {"error": f"{type(e).__name__}: {e}", "cores": allc}
 
     if rank == 0:
         shape_txt = "[154x10,77,77,39,39]" if SIZE == 256 else "[154x10,77,77,39,39,20,20,10,10]"
@@ -568,7 +602,7 @@ def main():
                           "global_batch": bs * world, "per_gpu_batch": bs, "parallelism": f"dp{world}", "launch_mode": mode, "launch_mode_calibration_ms": calib,
                           "student_params": n_params},
                "roofline": roof, "cpu_baseline": cpu, "full_iteration": full, "saliency_sweep": sweep,
-               "strong_scaling_proxy_1gpu": proxy}
+               "strong_scaling_proxy_1gpu": proxy, "deterministic_mode": det, "config3_1024": c3}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -18,6 +18,7 @@ _PROTOS = {
     "cagc_last_error": [],
     "cagc_arch": [],
     "cagc_set_tuning": [ctypes.c_char_p, _i],
+    "cagc_get_tuning": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)],
     "cagc_fused_bias_act_fwd": [_p, _p, _p, _i64, _i64, _i64, _f, _f, _p],
     "cagc_fused_bias_act_bwd": [_p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _p],
     "cagc_fused_bias_act_bwd2": [_p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _p],
@@ -48,6 +49,7 @@ _PROTOS = {
     "cagc_styled_bwd_finish": [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "cagc_torgb_bwd_finish": [_p, _p, _p, _p, _p, _i, _i, _f, _p],
     "cagc_wino_eligible": [_i, _i],
+    "cagc_wino_plan": [_i, _i, _i, _i, _i],
     "cagc_wino_packed_elems": [_i, _i],
     "cagc_wino_prep": [_p, _p, _i, _i, _f, _i, _p],
     "cagc_wino_conv3x3": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _f, _f, _p],
@@ -149,6 +151,43 @@ def call(name, *args):
 
 def query(name, *args):
     return getattr(load(), name)(*args)
+
+
+def get_tuning(key):
+    """Current value of a launch-policy knob (include/cagc.h cagc_get_tuning)."""
+    lib = load()
+    v = ctypes.c_int(0)
+    k = key.encode() if isinstance(key, str) else key
+    if lib.cagc_get_tuning(k, ctypes.byref(v)) != 0:
+        raise RuntimeError(f"cagc_get_tuning({key!r}): {lib.cagc_last_error().decode()}")
+    return v.value
+
+
+def set_tuning(key, value):
+    """Set a launch-policy knob (process-wide, see include/cagc.h); returns the previous value."""
+    lib = load()
+    prev = get_tuning(key)
+    k = key.encode() if isinstance(key, str) else key
+    if lib.cagc_set_tuning(k, int(value)) != 0:
+        raise RuntimeError(f"cagc_set_tuning({key!r}): {lib.cagc_last_error().decode()}")
+    return prev
+
+
+class tuning:
+    """`with tuning(deterministic=1, wino4_min_wgs=0): ...` — set knobs, restore the PREVIOUS values on exit."""
+
+    def __init__(self, **kv):
+        self.kv, self.prev = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.prev[k] = set_tuning(k, v)
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.prev.items():
+            set_tuning(k, v)
+        return False
 
 
 class on_device:

@@ -39,8 +39,9 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def wrap_student(student, device, bucket_cap_mb=4):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def wrap_student(student, device, bucket_cap_mb=4, force=False):
+    """force: wrap even at world size 1 (RCCL smoke test on a 1-GPU box: the bucket hooks and the collective still run)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return student
     from torch.nn.parallel import DistributedDataParallel as DDP
     kw = dict(broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)

@@ -312,9 +312,12 @@ class GraphedKDStep(KDStep):
 
     Gradients live in one flat buffer (param.grad are views), which is what the all-reduce moves: 22.3 MB at 256 px."""
 
-    def __init__(self, student, teacher, discriminator, batch, mask, random_noise=True, world_size=1, **kw):
+    def __init__(self, student, teacher, discriminator, batch, mask, random_noise=True, world_size=1, always_reduce=False, **kw):
+        """always_reduce: run the flat gradient all-reduce between the two graphs even at world size 1 (RCCL smoke test on a
+        1-GPU box: same stream ordering around the replays as a multi-GPU run)."""
         kw.setdefault("fused_adam", True)
         super().__init__(student, teacher, discriminator, **kw)
+        self.always_reduce = always_reduce
         for g in self.optim.param_groups:
             g["capturable"] = True
         self.batch, self.world = batch, world_size
@@ -395,7 +398,7 @@ class GraphedKDStep(KDStep):
         self._inj_host[0] = self.n_latent if inject_index is None else int(inject_index)
         self.inj.copy_(self._inj_host, non_blocking=True)
         self.graph_fb.replay()
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             import torch.distributed as dist
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
             self.flat_grad.div_(self.world)
@@ -413,6 +416,17 @@ class GraphedKDStep(KDStep):
         ids = [i for g in state_dict["param_groups"] for i in g["params"]]
         params = [p for g in self.optim.param_groups for p in g["params"]]
         assert len(ids) == len(params), "optimizer state does not match this student's parameters"
+        # hyper-parameters are baked into the captured Adam graph: a checkpoint written with others cannot be honoured here
+        for gs, gl in zip(state_dict["param_groups"], self.optim.param_groups):
+            for key in ("lr", "betas", "eps", "weight_decay", "amsgrad"):
+                if key not in gs:
+                    continue
+                a, b = gs[key], gl[key]
+                same = (all(abs(float(x) - float(y)) <= 1e-12 * max(1.0, abs(float(y))) for x, y in zip(a, b))
+                        if isinstance(a, (tuple, list)) else (bool(a) == bool(b) if isinstance(b, bool) else abs(float(a) - float(b)) <= 1e-12 * max(1.0, abs(float(b)))))
+                if not same:
+                    raise ValueError(f"GraphedKDStep.load_optim_state: saved Adam {key} = {a} differs from the captured graph's {b}; "
+                                     "construct the step with the checkpoint's hyper-parameters (they are captured, not reloadable)")
         with torch.no_grad():
             for i, p in zip(ids, params):
                 if i not in saved:
@@ -422,6 +436,11 @@ class GraphedKDStep(KDStep):
                     if torch.is_tensor(v):
                         assert k in live and live[k].shape == v.shape, f"optimizer state '{k}' mismatch"
                         live[k].copy_(v.to(live[k].device, live[k].dtype))
+                    elif isinstance(v, (int, float)) and not isinstance(v, bool):
+                        # torch 1.6 (the reference's pin, README.md:58-61) stores Adam's `step` as a Python int: the captured
+                        # capturable-Adam graph reads it from a device tensor — without this the bias correction restarts at t = 1
+                        assert k in live and torch.is_tensor(live[k]), f"optimizer state '{k}' has no live tensor"
+                        live[k].fill_(float(v))
         M.invalidate_caches(self.student)
 
     def sample_and_step(self, batch=None, mask=None, rng=random, generator=None):

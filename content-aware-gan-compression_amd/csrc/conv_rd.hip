@@ -600,3 +600,24 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   else { cagc::set_error("cagc_set_tuning: unknown key '%s'", key); return CAGC_ERR_INVALID; }
   return CAGC_OK;
 }
+
+extern "C" int cagc_get_tuning(const char* key, int* value) {
+  CAGC_REQUIRE(key && value, "cagc_get_tuning: null argument");
+  const cagc::RdTuning& t = cagc::rd_tuning();
+  int wm = 0, wt = 0;
+  cagc::wgrad_rd_get_tuning(&wm, &wt);
+  if (!strcmp(key, "rd")) *value = t.mode;
+  else if (!strcmp(key, "rd_min_wgs")) *value = t.min_wgs;
+  else if (!strcmp(key, "rd_mb")) *value = t.force_mb;
+  else if (!strcmp(key, "rd_kw")) *value = t.force_kw;
+  else if (!strcmp(key, "rd_split")) *value = t.split_on;
+  else if (!strcmp(key, "rd_atomic_below")) *value = t.atomic_below;
+  else if (!strcmp(key, "rd_split_wgs")) *value = t.split_target;
+  else if (!strcmp(key, "deterministic")) *value = cagc::deterministic_mode();
+  else if (!strcmp(key, "wgrad_rd")) *value = wm;
+  else if (!strcmp(key, "wgrad_rd_wgs")) *value = wt;
+  else if (!strcmp(key, "wino4_hv")) *value = cagc::wino4_hv_tuning();
+  else if (!strcmp(key, "wino4_min_wgs")) *value = cagc::wino4_min_wgs();
+  else { cagc::set_error("cagc_get_tuning: unknown key '%s'", key); return CAGC_ERR_INVALID; }
+  return CAGC_OK;
+}

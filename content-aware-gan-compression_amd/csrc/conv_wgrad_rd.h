@@ -23,5 +23,6 @@ int run_wgrad_rd(const WgrPlan& P, float* ws, const float* g, const float* x, co
 
 // mode < 0 / target_wgs <= 0: leave unchanged
 void wgrad_rd_set_tuning(int mode, int target_wgs);
+void wgrad_rd_get_tuning(int* mode, int* target_wgs);
 
 }  // namespace cagc

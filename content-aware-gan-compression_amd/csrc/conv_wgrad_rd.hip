@@ -221,6 +221,7 @@ void wgrad_rd_set_tuning(int mode, int target_wgs) {
   if (mode >= 0) wgr_mode() = mode;
   if (target_wgs > 0) wgr_target() = target_wgs;
 }
+void wgrad_rd_get_tuning(int* mode, int* target_wgs) { *mode = wgr_mode(); *target_wgs = wgr_target(); }
 static bool wgr_tuning_on() { return wgr_mode() != 0; }
 
 bool wgrad_rd_plan(WgrPlan& P, int B, int Cin, int Cout, int H, int W, int ksize, int up, bool modulated) {

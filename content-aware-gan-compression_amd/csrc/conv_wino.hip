@@ -549,6 +549,11 @@ extern "C" int cagc_wino_trace_dump(long long* host) {
 
 extern "C" int cagc_wino_eligible(int H, int W) { return (H % 8 == 0 && W % WTW == 0) ? 1 : 0; }
 
+extern "C" int cagc_wino_plan(int B, int K, int M, int H, int W) {
+  if (B <= 0 || K <= 0 || M <= 0 || !cagc_wino_eligible(H, W)) return 0;
+  return wino4_for_launch(K, M, B, H, W) ? 4 : 2;
+}
+
 extern "C" int64_t cagc_wino_packed_elems(int K, int M) {
   if (K <= 0 || M <= 0) return 0;
   return wino_packed_total(K, M);

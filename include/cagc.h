@@ -15,11 +15,22 @@
  *   - all tensors are fp32, contiguous, NCHW unless stated ("planes" = N*C flattened); the two reference operators also
  *     exist in an any-dtype form (fp32 / fp16 / fp64: cagc_fused_bias_act_any, cagc_upfirdn2d_any).
  *   - OWNERSHIP: the caller allocates every output and workspace (PyTorch caching allocator) and
- *     passes data_ptr(); the library never allocates, frees or retains a pointer.
+ *     passes data_ptr(); the library never frees or retains a caller's pointer.  ONE exception to "never
+ *     allocates": in deterministic mode (cagc_set_tuning("deterministic", 1) / CAGC_DETERMINISTIC=1) the
+ *     order-independent reduction sink keeps a library-owned scratch per (device, stream) — 16 bytes per reduced
+ *     element, < 1 MB on this path — obtained with hipMalloc on first use (also under stream capture, relaxed mode),
+ *     grown by allocating a new block and never freed before process exit (earlier launches / captured graphs may
+ *     still reference the old one); the table of scratches is mutex-guarded.  Default mode allocates nothing.
  *   - ERRORS: every function returns CAGC_OK (0) or a negative code; the message is available from
  *     cagc_last_error() (thread-local).  Nothing throws across the ABI.
- *   - THREADING: re-entrant; no global mutable state except the thread-local error string.  The
- *     device is the caller's current HIP device; kernels are enqueued on `stream` and not synchronised.
+ *   - THREADING: the data path is re-entrant — entry points may be called concurrently from several host threads
+ *     (one per device / stream, as the reference's DataParallel workers do).  Process-wide state, all of it
+ *     launch-shape policy that never changes results beyond fp32 summation order / the Winograd flavour: the tuning
+ *     table behind cagc_set_tuning / cagc_get_tuning (plain ints, initialised from CAGC_* environment variables at
+ *     first use, NOT synchronised: set them before worker threads start or while no launch is in flight), the
+ *     per-device "LDS limit already raised" flags of the large-LDS kernels (idempotent: a race costs one redundant
+ *     hipFuncSetAttribute call), and the deterministic-mode scratch table above (mutex).  The device is the caller's
+ *     current HIP device; kernels are enqueued on `stream` and not synchronised.
  *   - nullable pointers are marked [nullable].
  */
 #ifndef CAGC_H
@@ -58,6 +69,8 @@ const char* cagc_last_error(void);
  * order-independent fixed-point sink on a library-owned per-stream scratch — forward passes AND gradients become
  * bit-reproducible run to run (slower at small per-GPU batch).  The same knobs are read from CAGC_RD* at first use. */
 int cagc_set_tuning(const char* key, int value);
+/* Current value of a tuning key (same keys); CAGC_ERR_INVALID for an unknown key. */
+int cagc_get_tuning(const char* key, int* value);
 /* "gfx950" — the only architecture the library is built for. */
 const char* cagc_arch(void);
 
@@ -269,6 +282,10 @@ int cagc_torgb_bwd_finish(float* gw, float* gs, const float* gws, const float* s
  *   (Cin, Cout) swapped IS the data gradient of the conv.
  * ---------------------------------------------------------------------------------------------- */
 int cagc_wino_eligible(int H, int W);
+/* Which Winograd kernel a launch of cagc_wino_conv3x3 (GEMM K = reduction channels, M = produced channels; a data gradient
+ * swaps the layer's Cin / Cout) takes under the current tuning: 0 = not eligible, 2 = F(2x2,3x3), 4 = F(4x4,3x3).  Benchmarks
+ * use it to attribute executed FLOPs to the kernel that really ran. */
+int cagc_wino_plan(int B, int K, int M, int H, int W);
 int64_t cagc_wino_packed_elems(int K, int M);
 int cagc_wino_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad, cagc_stream_t stream);
 int cagc_wino_conv3x3(float* out, const float* x, const float* up, const float* s, int B, int Cin, int Cout, int H,

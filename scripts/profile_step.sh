@@ -5,7 +5,7 @@
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export CAGC_OVERLAP_TEACHER=0 CAGC_SIDE_WGRAD=0   # one stream: per-kernel durations in isolation, as in bench.py's roofline pass
-CMD="python bench.py --no-graph --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-full-iteration --no-proxy --sweep 0 $PROFILE_EXTRA"   # PROFILE_EXTRA="--local-batch 2": the per-GPU batch of an 8-GPU run
+CMD="python bench.py --no-graph --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-full-iteration --no-proxy --no-config3 --sweep 0 $PROFILE_EXTRA"   # PROFILE_EXTRA="--local-batch 2": the per-GPU batch of an 8-GPU run
 mkdir -p gpurun_out
 rm -rf /tmp/prof_kt
 rocprofv3 --kernel-trace -d /tmp/prof_kt -o kt -- $CMD > gpurun_out/${TAG}_kt.log 2>&1

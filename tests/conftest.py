@@ -28,10 +28,10 @@ def wino4_policy(request):
     get), or F(4x4) forced (`cagc_set_tuning("wino4_min_wgs", 0)`: the kernel the same layer runs on at the bench's batch 16)."""
     from cagc import _lib
     if request.param == "f4_forced":
-        _lib.call("cagc_set_tuning", b"wino4_min_wgs", 0)
-    yield request.param
-    if request.param == "f4_forced":
-        _lib.call("cagc_set_tuning", b"wino4_min_wgs", 256)
+        with _lib.tuning(wino4_min_wgs=0):      # restores the PREVIOUS value (a CAGC_WINO4_MIN_WGS override survives)
+            yield request.param
+    else:
+        yield request.param
 
 
 def pytest_collection_modifyitems(config, items):

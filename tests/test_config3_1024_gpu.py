@@ -139,13 +139,13 @@ def test_kd_step_1024_properties():
     # the same property in deterministic mode (no fp32-atomic K split: the three forward passes are bit-identical, so are
     # their gates): additivity to summation-order rounding of the backward reductions — the 3e-3 above is gate flips only
     from cagc import _lib
-    _lib.call("cagc_set_tuning", b"deterministic", 1)
+    prev_det = _lib.set_tuning("deterministic", 1)
     try:
         _, _, img_d, d_all = grads(1.0, 1.0)
         _, _, img_d2, d_g = grads(1.0, 0.0)
         _, _, _, d_k = grads(0.0, 1.0)
     finally:
-        _lib.call("cagc_set_tuning", b"deterministic", 0)
+        _lib.set_tuning("deterministic", prev_det)
     assert torch.equal(img_d, img_d2), "deterministic mode: forward not bit-reproducible"
     for p, a, b, c in zip(student.named_parameters(), d_all, d_g, d_k):
         if a is not None:

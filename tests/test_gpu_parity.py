@@ -518,7 +518,9 @@ def test_styled_conv_layers_vs_float64(cfg, wino4_policy):
         assert rel(a, b) <= (bar if b.numel() > 1 else 1e-3), f"{cfg} grad {nm}: {rel(a, b):.2e}"
 
 
-def test_full_256_teacher_forward_vs_oracle():
+def test_full_256_teacher_forward_vs_oracle(wino4_policy):
+    """Full 256 px teacher, all seven RGB outputs vs the oracle — under the per-launch Winograd policy (B = 1: the 32^2 / 64^2
+    layers on F(2x2)) and with F(4x4) forced on every eligible layer (the kernels the bs-16 bench's launches select)."""
     torch.manual_seed(6)
     net = M.Generator(256, 512, 8)
     with torch.no_grad():
@@ -575,13 +577,13 @@ def test_graphed_kd_step_matches_eager_step(deterministic):
     sg, tg, dg = build()
     eager = kd.KDStep(se, te, de, latent=24)
     B = g["mask"].shape[0]
-    if deterministic:
-        _lib.call("cagc_set_tuning", b"deterministic", 1)
+    prev = _lib.set_tuning("deterministic", 1) if deterministic else _lib.get_tuning("deterministic")
+    deterministic = deterministic or bool(prev)       # the whole suite may run under CAGC_DETERMINISTIC=1
     try:
         graphed = kd.GraphedKDStep(sg, tg, dg, B, cu(g["mask"]), random_noise=False, latent=24)
         _graph_vs_eager_steps(g, meta, se, sg, eager, graphed, deterministic)
     finally:
-        _lib.call("cagc_set_tuning", b"deterministic", 0)
+        _lib.set_tuning("deterministic", prev)
 
 
 def _graph_vs_eager_steps(g, meta, se, sg, eager, graphed, deterministic):
@@ -1033,8 +1035,12 @@ def test_pixelnorm_forward_and_backward_vs_float64(shape):
     assert_close(gz, torch.full_like(gz, 1e4).cpu(), 1e-5, "pixelnorm grad at 0")
 
 
-def test_graphed_kd_step_resumes_from_saved_optimizer_state_and_invalidates_frozen_caches():
-    """Advisor round 2: (1) a GraphedKDStep resumed from a checkpoint's Adam state (checkpoint.restore_optimizers ->
+@pytest.mark.parametrize("int_step", [False, True], ids=["tensor_step", "int_step_torch16"])
+def test_graphed_kd_step_resumes_from_saved_optimizer_state_and_invalidates_frozen_caches(int_step):
+    """(int_step: the checkpoint stores Adam's `step` as a Python int, as torch 1.6 — the reference's pin — writes it; advisor
+    round 3: it must reach the captured graph's device-side counter, or the bias correction restarts at t = 1.)
+
+    Advisor round 2: (1) a GraphedKDStep resumed from a checkpoint's Adam state (checkpoint.restore_optimizers ->
     load_optim_state copies INTO the tensors the captured graph holds) continues exactly like the uninterrupted run;
     (2) a frozen (no-grad) use of the student between replays sees the replayed weights, not stale packed ones."""
     from cagc import checkpoint as ck
@@ -1064,7 +1070,8 @@ def test_graphed_kd_step_resumes_from_saved_optimizer_state_and_invalidates_froz
     run0 = kd.GraphedKDStep(s0, t0, d0, B, cu(g["mask"]), random_noise=False, latent=24)
     run0.g_step(*inputs(steps[0], s0))
     saved = {"g": {k: v.detach().clone() for k, v in s0.state_dict().items()},
-             "g_optim": {"state": {i: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+             "g_optim": {"state": {i: {k: ((int(v.item()) if (int_step and k == "step") else v.detach().clone()) if torch.is_tensor(v) else v)
+                                       for k, v in st.items()}
                                    for i, st in run0.optim.state_dict()["state"].items()},
                          "param_groups": run0.optim.state_dict()["param_groups"]}}
     # frozen use between replays: eval forward must use the UPDATED weights (caches keyed on _version would be stale)
@@ -1091,3 +1098,7 @@ def test_graphed_kd_step_resumes_from_saved_optimizer_state_and_invalidates_froz
     for i in st0:
         assert_close(st1[i]["exp_avg_sq"], st0[i]["exp_avg_sq"], 2e-3, f"resumed Adam second moment {i}")
         assert float(st1[i]["step"]) == float(st0[i]["step"]) == 2.0
+    # hyper-parameters live inside the captured Adam graph: a checkpoint written with others is refused, not silently ignored
+    bad = {"g_optim": {"state": saved["g_optim"]["state"], "param_groups": [dict(pg, lr=pg["lr"] * 2) for pg in saved["g_optim"]["param_groups"]]}}
+    with pytest.raises(ValueError, match="lr"):
+        run1.load_optim_state(bad["g_optim"])

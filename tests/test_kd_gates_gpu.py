@@ -26,9 +26,8 @@ DEV = "cuda"
 @pytest.fixture()
 def deterministic():
     """No fp32-atomic K split: the forward (and with it the gate pattern) is the same in the hooked and the timed pass."""
-    _lib.call("cagc_set_tuning", b"deterministic", 1)
-    yield
-    _lib.call("cagc_set_tuning", b"deterministic", 0)
+    with _lib.tuning(deterministic=1):
+        yield
 
 
 def _nets():

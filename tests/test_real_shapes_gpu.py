@@ -123,7 +123,7 @@ def test_kd_step_256_batch16_properties():
     # forward pass is bit-reproducible.  The LeakyReLU gates of the 10^8 activations of student and discriminator are then the
     # same in every run, and gradients repeat to summation-order rounding instead of to the effect of flipped gates (default
     # mode, measured on this step: 2.3e-3 of a tensor's scale)
-    assert lib.cagc_set_tuning(b"deterministic", 1) == 0
+    prev_det = _lib.set_tuning("deterministic", 1)
     try:
         gl, kl, img, g_all = grads(1.0, 1.0)
         assert torch.isfinite(gl) and torch.isfinite(kl) and kl.item() > 0
@@ -145,7 +145,7 @@ def test_kd_step_256_batch16_properties():
             if a is not None:
                 assert_close(a, b + c, 2e-5 if a.numel() > 1 else 1e-3, "additivity " + n)
     finally:
-        lib.cagc_set_tuning(b"deterministic", 0)
+        _lib.set_tuning("deterministic", prev_det)
     with torch.no_grad():
         one = student([z[3:4] for z in zs], inject_index=5, noise=[n[3:4] for n in sn])
         assert_close(one, img[3:4], 1e-5, "student batch independence")

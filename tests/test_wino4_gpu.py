@@ -31,11 +31,9 @@ SHAPES = [(1, 128, 128, 8, 32), (2, 136, 128, 16, 32), (3, 200, 256, 8, 64), (2,
 def hv(request):
     """Workgroup shape of k_wino4 pinned through cagc_set_tuning("wino4_hv"): 64 channels x 4 waves (two workgroups per CU) or
     128 channels x 8 waves (taken only where Cout % 128 == 0; other layers keep the 64-channel shape)."""
-    _lib.call("cagc_set_tuning", b"wino4_hv", request.param)
-    _lib.call("cagc_set_tuning", b"wino4_min_wgs", 0)       # these small launches would otherwise take the layer's F(2x2) packing
-    yield request.param
-    _lib.call("cagc_set_tuning", b"wino4_hv", 0)
-    _lib.call("cagc_set_tuning", b"wino4_min_wgs", 256)
+    # wino4_min_wgs = 0: these small launches would otherwise take the layer's F(2x2) packing
+    with _lib.tuning(wino4_hv=request.param, wino4_min_wgs=0):
+        yield request.param
 
 
 @pytest.mark.parametrize("shape", SHAPES)
