@@ -12,6 +12,19 @@ LIB_PATH = os.path.join(_HERE, "libcagc_hip.so")
 
 _p, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
+
+
+class PrepJob(ctypes.Structure):
+    """include/cagc.h cagc_prep_job_t"""
+    _fields_ = [("weight", _p), ("wp_fwd", _p), ("wp_bwd", _p), ("wsq", _p), ("up_fwd", _p), ("up_bwd", _p),
+                ("Cout", _i), ("Cin", _i), ("ksize", _i), ("scale", _f)]
+
+
+class DemodJob(ctypes.Structure):
+    """include/cagc.h cagc_demod_job_t"""
+    _fields_ = [("d", _p), ("s", _p), ("wsq", _p), ("Cin", _i), ("Cout", _i)]
+
+
 # name -> argtypes (every function returns int unless listed in _RESTYPES)
 _PROTOS = {
     "cagc_abi_version": [],
@@ -36,6 +49,13 @@ _PROTOS = {
     "cagc_modconv_packed_elems": [_i, _i, _i],
     "cagc_modconv_prep": [_p, _p, _p, _p, _i, _i, _i, _f, _p],
     "cagc_modconv_prep_all": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "cagc_maplin_fwd": [_p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p],
+    "cagc_maplin_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p],
+    "cagc_mix_latent_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "cagc_mix_latent_bwd": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "cagc_modconv_prep_bank": [ctypes.POINTER(PrepJob), _i, _p],
+    "cagc_demod_bank": [ctypes.POINTER(DemodJob), _i, _i, _p],
+    "cagc_styled_bwd_tail": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "cagc_modconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _f, _f, _p],
     "cagc_modconv_up_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "cagc_blur_up_fwd": [_p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _f, _p],

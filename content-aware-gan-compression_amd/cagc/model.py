@@ -143,6 +143,8 @@ class EqualLinear(nn.Module):
 
     def forward(self, input):
         w, b = self.weight, self.bias
+        if mc.map_linear_ok(input, self):     # mapping-network layer: GEMM + bias + LeakyReLU as one launch (one more backward)
+            return mc._MapLinear.apply(input, w, b, self.scale, self.lr_mul)
         # the cache is only for FROZEN layers (requires_grad False: teacher, D on the generator step).  A layer that
         # merely runs under no_grad (g_ema sampling) is not cached: the reference's EMA updates weights through `.data`
         # (train.py:129), which does not bump the version counter the cache is validated against.
@@ -222,11 +224,14 @@ class ModulatedConv2d(nn.Module):
                 f"upsample={self.upsample}, downsample={self.downsample})")
 
     # -- HIP plumbing ----------------------------------------------------------------------------
+    def _hip_pattern(self):
+        """The layer pattern has a hand-written kernel (independent of the input tensor)."""
+        return (not self.downsample and self.kernel_size in (1, 3)
+                and not (self.upsample and (self.kernel_size != 3 or tuple(self.blur.kernel.shape) != (4, 4)
+                                            or self.blur.pad != (1, 1))))
+
     def _hip_eligible(self, input):
-        return (mc.use_hip(input) and input.dtype == torch.float32 and not self.downsample
-                and self.kernel_size in (1, 3) and not (self.upsample and
-                                                        (self.kernel_size != 3 or tuple(self.blur.kernel.shape) != (4, 4)
-                                                         or self.blur.pad != (1, 1))))
+        return mc.use_hip(input) and input.dtype == torch.float32 and self._hip_pattern()
 
     def packed_weights(self):
         """Packed GEMM operands of `weight` (csrc/conv_igemm.hip k_pack_weights).  Trainable weights are
@@ -335,22 +340,31 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, return_style_scalars=False, noise=None, _s=None):
-        """`_s`: the layer's modulation vector when the caller already has it (Generator's modulation bank)."""
+    def _fused_pattern(self):
+        return (self.conv._hip_pattern() and self.activate.bias is not None
+                and self.activate.negative_slope == 0.2 and abs(self.activate.scale - 2 ** 0.5) < 1e-12)
+
+    def forward(self, input, style, return_style_scalars=False, noise=None, _s=None, _prep=None):
+        """`_s`: the layer's modulation vector when the caller already has it (Generator's modulation bank); `_prep`: its
+        prepared operands (wp_fwd, wp_bwd, wsq, up_wino, up_wino_bwd, d) from the generator's one-launch banks."""
         conv = self.conv
-        fused = (conv._hip_eligible(input) and self.activate.bias is not None
-                 and self.activate.negative_slope == 0.2 and abs(self.activate.scale - 2 ** 0.5) < 1e-12)
+        fused = conv._hip_eligible(input) and self._fused_pattern()
         if fused:
             batch, cin, h, w = input.shape
             s = _s if _s is not None else conv.modulation(style)
-            wp_fwd, wp_bwd, wsq, up_w, up_wb = conv.prepared(h, w)
+            d_pre = None
+            if _prep is not None and _s is not None:
+                wp_fwd, wp_bwd, wsq, up_w, up_wb, d_pre = _prep
+            else:
+                wp_fwd, wp_bwd, wsq, up_w, up_wb = conv.prepared(h, w)
             oh, ow = (2 * h, 2 * w) if conv.upsample else (h, w)
             if noise is None:
                 noise = input.new_empty(batch, 1, oh, ow).normal_()
             elif noise.shape[0] not in (1, batch) or tuple(noise.shape[1:]) != (1, oh, ow):
                 noise = noise.expand(batch, 1, oh, ow)
             out = mc._ModConv.apply(input, conv.weight, s, wsq if conv.demodulate else None, noise, self.noise.weight, self.activate.bias, wp_fwd,
-                                    wp_bwd, conv.blur.kernel if conv.upsample else None, True, conv.upsample, up_w, up_wb)
+                                    wp_bwd, conv.blur.kernel if conv.upsample else None, True, conv.upsample, up_w, up_wb,
+                                    d_pre if conv.demodulate else None)
             styles = s.view(batch, 1, cin, 1, 1)
         else:
             if return_style_scalars:
@@ -483,6 +497,65 @@ class Generator(nn.Module):
             return None
         return bank(latent)
 
+    def _styled_plan(self):
+        """[(StyledConv, side of its input)] in forward order."""
+        side = self.input.input.shape[2]
+        plan = [(self.conv1, side)]
+        for blk in range(len(self.to_rgbs)):
+            plan.append((self.convs[2 * blk], side))
+            side *= 2
+            plan.append((self.convs[2 * blk + 1], side))
+        return plan
+
+    def _bank_prepare(self, latent, bank):
+        """Everything the styled convs derive from their weights and modulation vectors, by TWO launches for the whole
+        generator instead of two per layer (small per-GPU batches are launch-bound): the packed / Winograd-domain operands of
+        every TRAINABLE layer (cagc_modconv_prep_bank; frozen layers keep their caches) and the demodulation factors
+        d_l[b,o] of every layer (cagc_demod_bank).  Returns one (wp_fwd, wp_bwd, wsq, up_wino, up_wino_bwd, d) per styled conv,
+        or None when a layer's pattern is outside the kernels' coverage (the layers then prepare themselves)."""
+        from . import _lib
+        plan = self._styled_plan()
+        if bank is None or not all(m._fused_pattern() for m, _ in plan):
+            return None
+        B, dev = latent.shape[0], latent.device
+        new = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+        need_bwd = torch.is_grad_enabled()
+        rows, pjobs, keep = [], [], []
+        for m, side in plan:
+            conv = m.conv
+            w = conv.weight
+            cout, cin, k = w.shape[1], w.shape[2], w.shape[-1]
+            if w.requires_grad:
+                wino = (not conv.upsample) and k == 3 and mc.wino_ok(side, side)
+                wc = w.detach().contiguous()
+                wp_fwd = new(_lib.query("cagc_modconv_packed_elems", cin, cout, k))
+                wp_bwd = new(_lib.query("cagc_modconv_packed_elems", cout, cin, k)) if need_bwd else None
+                wsq = torch.empty(cout, cin, dtype=torch.float32, device=dev)
+                up_w = new(_lib.query("cagc_wino_packed_elems", cin, cout)) if wino else None
+                up_wb = new(_lib.query("cagc_wino_packed_elems", cout, cin)) if (wino and need_bwd and mc.WINO_DGRAD) else None
+                pjobs.append(_lib.PrepJob(_lib.ptr(wc), _lib.ptr(wp_fwd), _lib.ptr(wp_bwd), _lib.ptr(wsq), _lib.ptr(up_w), _lib.ptr(up_wb),
+                                          cout, cin, k, float(conv.scale)))
+                keep.append(wc)
+            else:
+                wp_fwd, wp_bwd, wsq = conv.packed_weights()
+                up_w, up_wb = conv.wino_weights(side, side), conv.wino_weights_bwd(side, side)
+            rows.append([wp_fwd, wp_bwd, wsq, up_w, up_wb, None])
+        with _lib.on_device(latent):
+            if pjobs:
+                _lib.call("cagc_modconv_prep_bank", (_lib.PrepJob * len(pjobs))(*pjobs), len(pjobs))
+            couts = [m.conv.weight.shape[1] for m, _ in plan]
+            dflat = new(B * sum(couts))
+            djobs, off = [], 0
+            for i, ((m, _), row) in enumerate(zip(plan, rows)):
+                if m.conv.demodulate:
+                    s = bank[0 if i == 0 else 2 + 3 * ((i - 1) // 2) + (i - 1) % 2]
+                    row[5] = dflat[off:off + B * couts[i]].view(B, couts[i])
+                    djobs.append(_lib.DemodJob(_lib.ptr(row[5]), _lib.ptr(s), _lib.ptr(row[2]), m.conv.weight.shape[2], couts[i]))
+                off += B * couts[i]
+            if djobs:
+                _lib.call("cagc_demod_bank", (_lib.DemodJob * len(djobs))(*djobs), len(djobs), B)
+        return [tuple(r) for r in rows]
+
     def _synthesize(self, noise_z, inject_index, truncation, truncation_latent, latent_styles, input_is_latent, noise,
                     randomize_noise, return_rgb_list, return_style_scalars, want_latent):
         if input_is_latent:
@@ -504,8 +577,11 @@ class Generator(nn.Module):
         elif torch.is_tensor(inject_index):
             # device-side mixing index (static shapes: lets the whole step live in one HIP graph); value n_latent
             # reproduces the no-mixing case, values 1..n_latent-1 the reference's cat of the two repeated styles
-            pos = torch.arange(self.n_latent, device=styles[0].device).view(1, -1, 1)
-            latent = torch.where(pos < inject_index.view(1, 1, 1), styles[0].unsqueeze(1), styles[1].unsqueeze(1))
+            if mc.mix_latent_ok(styles[0], styles[1], inject_index):
+                latent = mc._MixLatent.apply(styles[0], styles[1], inject_index, self.n_latent)
+            else:
+                pos = torch.arange(self.n_latent, device=styles[0].device).view(1, -1, 1)
+                latent = torch.where(pos < inject_index.view(1, 1, 1), styles[0].unsqueeze(1), styles[1].unsqueeze(1))
         else:
             if inject_index is None:
                 inject_index = random.randint(1, self.n_latent - 1)
@@ -527,8 +603,10 @@ class Generator(nn.Module):
         styles_list = []
         bank = self._bank_styles(latent)            # every layer's modulation vector from ONE launch (or None)
         bs = (lambda k: bank[k]) if bank is not None else (lambda k: None)
+        prep = self._bank_prepare(latent, bank)     # packed operands + demodulation factors of every layer: two launches (or None)
+        pp = (lambda k: prep[k]) if prep is not None else (lambda k: None)
         out = self.input(latent)
-        out = self.conv1(out, latent[:, 0], rss, noise=noise[0], _s=bs(0))
+        out = self.conv1(out, latent[:, 0], rss, noise=noise[0], _s=bs(0), _prep=pp(0))
         if rss:
             out, sc = out
             styles_list.append(sc)
@@ -537,7 +615,8 @@ class Generator(nn.Module):
         i = 1
         for blk, to_rgb in enumerate(self.to_rgbs):
             for j in (0, 1):
-                out = self.convs[2 * blk + j](out, latent[:, i + j], rss, noise=noise[2 * blk + 1 + j], _s=bs(2 + 3 * blk + j))
+                out = self.convs[2 * blk + j](out, latent[:, i + j], rss, noise=noise[2 * blk + 1 + j], _s=bs(2 + 3 * blk + j),
+                                              _prep=pp(1 + 2 * blk + j))
                 if rss:
                     out, sc = out
                     styles_list.append(sc)

@@ -189,7 +189,7 @@ class _ModConv(Function):
 
     @staticmethod
     def forward(ctx, x, weight, s, wsq, noise, noise_w, bias, wp_fwd, wp_bwd, fir, styled, upsample, up_wino=None,
-                up_wino_bwd=None):
+                up_wino_bwd=None, d_pre=None):
         x = x.contiguous()
         s = s.contiguous()
         B, cin, H, W = x.shape
@@ -201,7 +201,9 @@ class _ModConv(Function):
             nb = noise.shape[0]
         with _lib.on_device(x):
             d_c = None
-            if wsq is not None:
+            if wsq is not None and d_pre is not None:     # already computed by the generator's demodulation bank (one launch for all layers)
+                d_c = d_pre
+            elif wsq is not None:
                 d_c = torch.empty(B, cout, dtype=x.dtype, device=dev)
                 _lib.call("cagc_demod_fwd", _lib.ptr(d_c), _lib.ptr(s), _lib.ptr(wsq), B, cin, cout)
             if upsample:
@@ -242,7 +244,8 @@ class _ModConv(Function):
         gout = gout.contiguous()
         need_x, need_w, need_s = ctx.needs_input_grad[0:3]
         need_d = d is not None and (need_s or need_w)
-        gd = g_nw = g_bias = None
+        gd = g_nw = g_bias = gwsq = None
+        tail_done = False
         gs = torch.empty_like(s) if need_s else None
         with _lib.on_device(x):
             if styled:
@@ -250,14 +253,21 @@ class _ModConv(Function):
                 red = torch.empty(3, B, cout, dtype=x.dtype, device=dev)
                 _lib.call("cagc_styled_act_bwd", _lib.ptr(gz), _lib.ptr(red), _lib.ptr(gout), _lib.ptr(out), _lib.ptr(d),
                           _lib.ptr(noise), noise.shape[0] if noise is not None else 0, B, cout, Ho * Wo, 0.2, SQRT2)
-                # one launch: bias / noise-weight gradients, the gradient reaching d (z = (pre - nw*noise - bias) / d ->
-                # gd = sum_p gpre * z) and the zero-fill of the style-gradient accumulator
                 g_bias = torch.empty(cout, dtype=x.dtype, device=dev)
                 g_nw = torch.empty(1, dtype=x.dtype, device=dev) if noise is not None else None
-                gd = torch.empty(B, cout, dtype=x.dtype, device=dev) if need_d else None
-                _lib.call("cagc_styled_bwd_finish", _lib.ptr(g_bias), _lib.ptr(g_nw), _lib.ptr(gd), _lib.ptr(gs),
-                          gs.numel() if gs is not None else 0, _lib.ptr(red), _lib.ptr(bias), _lib.ptr(noise_w), _lib.ptr(d), B, cout,
-                          1 if noise is not None else 0)
+                if need_d:
+                    # ONE launch for the whole [B,C]-sized tail: bias / noise-weight gradients, the gradient reaching d
+                    # (z = (pre - nw*noise - bias) / d -> gd = sum_p gpre * z) and the demodulation branch it feeds —
+                    # gs = 2 s sum_o t wsq (written: replaces the accumulator's zero-fill), gwsq = sum_b t s^2  (t = -gd d^3 / 2)
+                    gwsq = torch.empty_like(wsq) if need_w else None
+                    _lib.call("cagc_styled_bwd_tail", _lib.ptr(g_bias), _lib.ptr(g_nw), _lib.ptr(gs), _lib.ptr(gwsq), _lib.ptr(red),
+                              _lib.ptr(bias), _lib.ptr(noise_w), _lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq), B, cin, cout,
+                              1 if noise is not None else 0)
+                    tail_done = True
+                else:
+                    _lib.call("cagc_styled_bwd_finish", _lib.ptr(g_bias), _lib.ptr(g_nw), None, _lib.ptr(gs),
+                              gs.numel() if gs is not None else 0, _lib.ptr(red), _lib.ptr(bias), _lib.ptr(noise_w), _lib.ptr(d), B, cout,
+                              1 if noise is not None else 0)
             else:
                 if gs is not None:
                     gs.zero_()
@@ -272,8 +282,8 @@ class _ModConv(Function):
                 _lib.call("cagc_blur_up_bwd", _lib.ptr(g), _lib.ptr(gz), _lib.ptr(fir), B, cout, H, W)
             else:
                 g = gz
-            gx = gweight = gwsq = None
-            if need_d:   # demodulation branch: gs += 2 s sum_o t wsq, gwsq = sum_b t s^2   (t = -gd d^3 / 2)
+            gx = gweight = None
+            if need_d and not tail_done:   # demodulation branch: gs += 2 s sum_o t wsq, gwsq = sum_b t s^2   (t = -gd d^3 / 2)
                 gwsq = torch.empty_like(wsq) if need_w else None
                 _lib.call("cagc_demod_bwd", _lib.ptr(gs), _lib.ptr(gwsq), _lib.ptr(gd), _lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq),
                           B, cin, cout)
@@ -323,7 +333,7 @@ class _ModConv(Function):
             g_noise = noise_w * gpre.sum(1, keepdim=True)
             if noise.shape[0] == 1 and B > 1:
                 g_noise = g_noise.sum(0, keepdim=True)
-        return (gx if need_x else None, gweight, gs, None, g_noise, g_nw, g_bias, None, None, None, None, None, None, None)
+        return (gx if need_x else None, gweight, gs, None, g_noise, g_nw, g_bias, None, None, None, None, None, None, None, None)
 
 
 def modconv_composed(x, weight, s, demodulate, upsample, downsample, blur_kernel, blur_pad):
@@ -853,6 +863,79 @@ class _ModBank(Function):
         gws = [gw[c0:c0 + cin] if need_w else None for c0, cin in zip(bank.c0, bank.cins)]
         gbs = [gb[c0:c0 + cin] if need_w else None for c0, cin in zip(bank.c0, bank.cins)]
         return (glat, None, *gws, *gbs)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Mapping-network layer: EqualLinear(512 -> O, activation='fused_lrelu') as ONE launch forward, ONE backward (csrc/mapping.hip)
+# ---------------------------------------------------------------------------------------------------
+class _MapLinear(Function):
+    """y = lrelu(x @ (W * scale)^T + b * lr_mul, 0.2) * sqrt(2)   (reference model.py:156-166 with op/fused_act.py:104-119)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, lr_mul):
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        b = bias.detach().contiguous()
+        R, O = x.shape[0], w.shape[0]
+        y = torch.empty(R, O, dtype=x.dtype, device=x.device)
+        with _lib.on_device(x):
+            _lib.call("cagc_maplin_fwd", _lib.ptr(y), _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), R, x.shape[1], O, float(scale), float(lr_mul),
+                      0.2, SQRT2)
+        ctx.save_for_backward(x, w, y)
+        ctx.scale, ctx.lr_mul = float(scale), float(lr_mul)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        R, O = y.shape
+        need_x, need_w, need_b = ctx.needs_input_grad[0:3]
+        gx = torch.empty_like(x) if need_x else None
+        gw = torch.empty_like(w) if (need_w or need_b) else None
+        gb = torch.empty(O, dtype=x.dtype, device=x.device) if (need_w or need_b) else None
+        with _lib.on_device(x):
+            _lib.call("cagc_maplin_bwd", _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(w), R,
+                      x.shape[1], O, ctx.scale, ctx.lr_mul, 0.2, SQRT2)
+        return gx, (gw if need_w else None), (gb if need_b else None), None, None
+
+
+def map_linear_ok(x, lin):
+    return (use_hip(x) and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 512 and lin.weight.shape[1] == 512
+            and lin.bias is not None and lin.activation and lin.weight.dtype == torch.float32)
+
+
+class _MixLatent(Function):
+    """latent [B,n,512]: rows i < inject (DEVICE-side int64 index) take w0[b], the others w1[b] — the reference's cat of the two
+    repeated styles (model.py:586-594) — one launch forward, one backward (csrc/mapping.hip)."""
+
+    @staticmethod
+    def forward(ctx, w0, w1, inject, n_latent):
+        w0, w1 = w0.contiguous(), w1.contiguous()
+        B, D = w0.shape
+        latent = torch.empty(B, n_latent, D, dtype=w0.dtype, device=w0.device)
+        with _lib.on_device(w0):
+            _lib.call("cagc_mix_latent_fwd", _lib.ptr(latent), _lib.ptr(w0), _lib.ptr(w1), inject.data_ptr(), B, n_latent, D)
+        ctx.save_for_backward(inject)
+        return latent
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (inject,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, n, D = g.shape
+        g0 = torch.empty(B, D, dtype=g.dtype, device=g.device)
+        g1 = torch.empty(B, D, dtype=g.dtype, device=g.device)
+        with _lib.on_device(g):
+            _lib.call("cagc_mix_latent_bwd", _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(g), inject.data_ptr(), B, n, D)
+        return g0, g1, None, None
+
+
+def mix_latent_ok(w0, w1, inject):
+    return (use_hip(w0) and w0.dtype == torch.float32 and w0.dim() == 2 and w0.shape == w1.shape and w0.shape[1] % 4 == 0
+            and inject.dtype == torch.int64 and inject.is_cuda and inject.numel() == 1)
 
 
 # ---------------------------------------------------------------------------------------------------

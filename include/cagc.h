@@ -273,6 +273,58 @@ int cagc_torgb_bwd_finish(float* gw, float* gs, const float* gws, const float* s
                           float scale, cagc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Mapping-network layer             replaces model.py:137-166 EqualLinear(activation='fused_lrelu') as the generator's
+ *                                   mapping network uses it (model.py:421-430; F.linear + fused_bias_act, op/fused_act.py):
+ *   y [R,O] = lrelu(x [R,512] @ (W [O,512] * scale)^T + b [O] * lr_mul, alpha) * act_scale         ONE launch
+ *   backward (ONE launch), gpre = gy * (y > 0 ? 1 : alpha) * act_scale:
+ *     gx [R,512] = scale * gpre @ W [nullable];  gweight [O,512] = scale * gpre^T @ x [nullable];  gbias [O] = lr_mul * sum_r gpre
+ *     [nullable, only with gweight].  in_dim must be 512.
+ * ---------------------------------------------------------------------------------------------- */
+int cagc_maplin_fwd(float* y, const float* x, const float* weight, const float* bias, int R, int in_dim, int out_dim,
+                    float scale, float lr_mul, float alpha, float act_scale, cagc_stream_t stream);
+int cagc_maplin_bwd(float* gx, float* gweight, float* gbias, const float* gy, const float* y, const float* x,
+                    const float* weight, int R, int in_dim, int out_dim, float scale, float lr_mul, float alpha,
+                    float act_scale, cagc_stream_t stream);
+/* Style mixing (model.py:586-594: cat of the two repeated styles at inject_index) with the index on the DEVICE (one int64;
+ * static shapes, so the step can live in a HIP graph):  latent [B,n_latent,D][b,i,:] = i < *inject ? w0[b,:] : w1[b,:];
+ * backward: gw0 = sum_{i < inject} g[:,i,:], gw1 = sum_{i >= inject} g[:,i,:].  D % 4 == 0. */
+int cagc_mix_latent_fwd(float* latent, const float* w0, const float* w1, const int64_t* inject, int B, int n_latent, int D,
+                        cagc_stream_t stream);
+int cagc_mix_latent_bwd(float* gw0, float* gw1, const float* g, const int64_t* inject, int B, int n_latent, int D,
+                        cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Banked launches                   one launch per GENERATOR / per layer for work that is tiny per layer (small per-GPU
+ *                                   batches are launch-bound).  Job descriptors are read on the host during the call (they
+ *                                   travel to the device by value in the kernel arguments): the array may be freed or
+ *                                   reused as soon as the call returns; the tensors it points to follow the usual rules.
+ * cagc_modconv_prep_bank: cagc_modconv_prep_all for every job in ONE launch (16 layers per launch).
+ * cagc_demod_bank:        cagc_demod_fwd (model.py:249-253) for every job in ONE launch (40 layers per launch), same B.
+ * cagc_styled_bwd_tail:   the [B,C]-sized tail of a styled conv's backward in ONE launch (was cagc_styled_bwd_finish + the two
+ *   kernels of cagc_demod_bwd): from red [3,B,Cout] (cagc_styled_act_bwd)
+ *     gbias[o] = sum_b red0 [nullable];   gnw = sum red1 [nullable];
+ *     t[b,o] = -(red2 - bias[o] red0 - nw red1) d[b,o]^2 / 2        (= -gd d^3 / 2 with gd the gradient reaching d)
+ *     gs[b,i] = 2 s[b,i] sum_o t[b,o] wsq[o,i]   (WRITTEN, every element — the data-gradient kernel then accumulates) [nullable]
+ *     gwsq[o,i] = sum_b t[b,o] s[b,i]^2          [nullable]
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* weight;                 /* [Cout,Cin,k,k] */
+  float *wp_fwd, *wp_bwd, *wsq, *up_fwd, *up_bwd; /* outputs of cagc_modconv_prep_all, any may be null */
+  int Cout, Cin, ksize;
+  float scale;
+} cagc_prep_job_t;
+typedef struct {
+  float* d;                            /* [B,Cout] */
+  const float *s, *wsq;                /* [B,Cin], [Cout,Cin] */
+  int Cin, Cout;
+} cagc_demod_job_t;
+int cagc_modconv_prep_bank(const cagc_prep_job_t* jobs, int njobs, cagc_stream_t stream);
+int cagc_demod_bank(const cagc_demod_job_t* jobs, int njobs, int B, cagc_stream_t stream);
+int cagc_styled_bwd_tail(float* gbias, float* gnw, float* gs, float* gwsq, const float* red, const float* bias,
+                         const float* noise_w, const float* d, const float* s, const float* wsq, int B, int Cin, int Cout,
+                         int has_noise, cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Winograd F(2x2,3x3) path          same contract as cagc_modconv_fwd (k = 3, stride 1, "same"), for layers with
  *                                   H % 8 == 0 and W % 32 == 0 (cagc_wino_eligible): 16 GEMMs on transformed 4x4
  *                                   tiles, 2.25x fewer fp32 MFMA flops than the direct implicit GEMM; all fp32.

@@ -61,8 +61,13 @@ def _generator_gates(acts_map, acts_conv, B, n_z):
 
 
 def _hook_discriminator(disc):
+    """Post-activation outputs of every module that runs as a module: from-RGB, the final conv / linear, and conv1 / conv2 of the
+    ResBlocks that take the layer-by-layer path (16^2 and below: not Winograd-sized, so no fused `_ResBlockFrozen` node)."""
     outs, hooks = {}, []
-    for name, m in (("fromrgb", disc.convs[0]), ("final_conv", disc.final_conv), ("final_linear0", disc.final_linear[0])):
+    mods = [("fromrgb", disc.convs[0]), ("final_conv", disc.final_conv), ("final_linear0", disc.final_linear[0])]
+    for r in range(1, len(disc.convs)):
+        mods += [(f"res{r}.conv1", disc.convs[r].conv1), (f"res{r}.conv2", disc.convs[r].conv2)]
+    for name, m in mods:
         hooks.append(m.register_forward_hook(lambda mod, inp, out, name=name: outs.__setitem__(name, out.detach())))
     return outs, hooks
 
@@ -83,11 +88,19 @@ def _frozen_resblock_activations(pred):
     return found
 
 
-def _discriminator_gates(outs, pred, n_res):
+def _discriminator_gates(outs, pred, n_res, n_fused):
+    """Gates in the oracle's call order: from-RGB, (conv1, conv2) per ResBlock, final conv, final linear.  The first `n_fused`
+    ResBlocks (Winograd-sized maps) must have run as fused nodes — their activations come off the autograd graph — the others
+    layer by layer (forward hooks)."""
     blocks = _frozen_resblock_activations(pred)
-    assert len(blocks) == n_res, f"{len(blocks)} fused ResBlock nodes on the graph, expected {n_res}: the frozen fast path did not run"
+    assert len(blocks) == n_fused, f"{len(blocks)} fused ResBlock nodes on the graph, expected {n_fused}: the frozen fast path did not run"
     g = [(outs["fromrgb"] > 0).cpu()]
-    for y1, y2a in blocks:
+    for r in range(1, n_res + 1):
+        if r <= n_fused:
+            assert f"res{r}.conv1" not in outs
+            y1, y2a = blocks[r - 1]
+        else:
+            y1, y2a = outs[f"res{r}.conv1"], outs[f"res{r}.conv2"]
         g += [(y1 > 0).cpu(), (y2a > 0).cpu()]
     return g + [(outs["final_conv"] > 0).cpu(), (outs["final_linear0"] > 0).cpu()]
 
@@ -107,7 +120,7 @@ def test_discriminator_256_frozen_f4_forced_vs_float64(f4_everywhere):
     pred = dg(xg)
     for h in hooks:
         h.remove()
-    gates_g = _discriminator_gates(outs, pred, 6)
+    gates_g = _discriminator_gates(outs, pred, 6, 4)
     (gx,) = torch.autograd.grad(F.softplus(-pred).mean(), xg)
     with torch.no_grad(), ref_ops.gates() as rec:
         pred64_own = ref_model.discriminator_forward_ref(sd64, x.double())
@@ -155,13 +168,13 @@ def test_kd_step_configs1_f4_forced_vs_float64(f4_everywhere):
     g_loss, kd_l1, img = step.g_losses([cu(z) for z in zs], inj, cu(mask), [cu(n) for n in sn], [cu(n) for n in tn])
     for h in h1 + h2 + h3:
         h.remove()
+    # oracle call order (oracle/ref_kd.py): student, discriminator, teacher.  (Read BEFORE backward frees the fused nodes' saved tensors.)
+    gates_g = (_generator_gates(s_map, s_conv, B, 2) + _discriminator_gates(d_outs, pred_box[0], 6, 4)
+               + _generator_gates(t_map, t_conv, B, 2))
     params = dict(sg.named_parameters())
     grads = dict(zip(names, torch.autograd.grad(g_loss + kd_l1, [params[k] for k in names], allow_unused=True)))
     with torch.no_grad():
         t_img = tg([cu(z) for z in zs], inject_index=inj, noise=[cu(n) for n in tn])
-    # oracle call order (oracle/ref_kd.py): student, discriminator, teacher
-    gates_g = (_generator_gates(s_map, s_conv, B, 2) + _discriminator_gates(d_outs, pred_box[0], 6)
-               + _generator_gates(t_map, t_conv, B, 2))
 
     # ---- float64 oracle: own gates (disagreements must be at rounding level), then the HIP run's pattern
     z64, sn64, tn64, m64 = [z.double() for z in zs], [n.double() for n in sn], [n.double() for n in tn], mask.double()
@@ -202,9 +215,11 @@ def test_kd_step_configs1_f4_forced_vs_float64(f4_everywhere):
 def test_full_generator_fwd_bwd_batch64_properties():
     """BASELINE configs[4] at its real size (full 256 px generator, bs 64: the saliency sweep's batch, reference
     Util/content_aware_pruning.py:152-249): every launch takes F(4x4) / the batch-64 launch plans no B <= 2 test selects.  Checked
-    through size-independent properties: finite image and weight gradients, batch independence of the image (samples 5 and 40
-    alone == inside the batch), and additivity of the weight gradient over a split of the batch (16 + 48) — exact up to fp32
-    summation order, because with fixed latents and noise every sample's forward is the same in both runs."""
+    through size-independent properties: finite image and weight gradients; batch independence of the image (samples 5 and 40
+    alone == inside the batch); and, on ONE forward pass (so every backward sees the same LeakyReLU gates), the backward pass is
+    linear in the upstream gradient and ADDITIVE OVER A SPLIT OF THE BATCH: the weight gradients for an upstream gradient
+    restricted to samples [0,16) plus those for [16,64) equal the full-batch ones — each sample's contribution is summed, none is
+    dropped or counted twice by the batch-64 launch plans (weight-gradient K split over pixel tiles and images)."""
     torch.manual_seed(43)
     net = M.Generator(256, 512, 8).to(DEV)
     with torch.no_grad():
@@ -216,24 +231,21 @@ def test_full_generator_fwd_bwd_batch64_properties():
     w = torch.randn(B, net.n_latent, 512, device=DEV, generator=gen)          # latents given: the mapping network is row-wise anyway
     noise = [torch.randn(B, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), device=DEV, generator=gen) for i in range(net.num_layers)]
     proj = torch.randn(B, 3, 256, 256, device=DEV, generator=gen)
-    convs = [m.conv.weight for m in [net.conv1] + list(net.convs)]
-
-    def run(sl):
-        img = net(None, input_is_latent=True, latent_styles=[w[sl]], noise=[n[sl] for n in noise])
-        gs = torch.autograd.grad((img * proj[sl]).sum(), convs)
-        return img.detach(), gs
-
-    # F(4x4) forced in every run (the 1-sample runs would otherwise take F(2x2) on the under-filled layers); deterministic mode:
-    # no fp32-atomic K split, so a sample's forward does not depend on which launch computed it beyond summation order
-    with _lib.tuning(deterministic=1, wino4_min_wgs=0):
-        img, g_all = run(slice(0, B))
-        img_a, g_a = run(slice(0, 16))
-        img_b, g_b = run(slice(16, B))
-        i5, _ = run(slice(5, 6))
-        i40, _ = run(slice(40, 41))
-    assert torch.isfinite(img).all() and all(torch.isfinite(g).all() for g in g_all)
-    assert _rel(i5, img[5:6].cpu()) <= 1e-4 and _rel(i40, img[40:41].cpu()) <= 1e-4, "batch independence"
-    assert _rel(img_a, img[:16].cpu()) <= 1e-4 and _rel(img_b, img[16:].cpu()) <= 1e-4
+    convs = [m.conv.weight for m in [net.conv1] + list(net.convs)] + [m.conv.modulation.weight for m in [net.conv1] + list(net.convs)]
+    part = torch.zeros(B, 1, 1, 1, device=DEV)
+    part[:16] = 1.0
+    img = net(None, input_is_latent=True, latent_styles=[w], noise=noise)
+    assert tuple(img.shape) == (B, 3, 256, 256) and torch.isfinite(img).all()
+    assert _lib.query("cagc_wino_plan", B, 512, 512, 32, 32) == 4 and _lib.query("cagc_wino_plan", B, 128, 128, 256, 256) == 4
+    g_all = torch.autograd.grad((img * proj).sum(), convs, retain_graph=True)
+    g_a = torch.autograd.grad((img * proj * part).sum(), convs, retain_graph=True)
+    g_b = torch.autograd.grad((img * proj * (1 - part)).sum(), convs)
+    assert all(torch.isfinite(g).all() and float(g.abs().max()) > 0 for g in g_all)
     worst = max(_rel(a + b, c.cpu()) for a, b, c in zip(g_a, g_b, g_all))
-    print(f"full generator bs 64: weight-gradient additivity over a 16 + 48 split {worst:.2e}")
-    assert worst <= 1e-3, f"weight-gradient additivity {worst:.2e}"
+    print(f"full generator bs 64: gradient additivity over a 16 + 48 split of the batch (one forward) {worst:.2e}")
+    assert worst <= 2e-5, f"gradient additivity over the batch split {worst:.2e}"
+    with torch.no_grad():
+        for i in (5, 40):
+            one = net(None, input_is_latent=True, latent_styles=[w[i:i + 1]], noise=[n[i:i + 1] for n in noise])
+            # the 1-sample launches take other plans (F(2x2) on under-filled layers, K split across waves): 1e-4, not rounding level
+            assert _rel(one, img[i:i + 1].detach().cpu()) <= 1e-4, f"batch independence of sample {i}"
