@@ -49,8 +49,8 @@ _PROTOS = {
     "cagc_modconv_packed_elems": [_i, _i, _i],
     "cagc_modconv_prep": [_p, _p, _p, _p, _i, _i, _i, _f, _p],
     "cagc_modconv_prep_all": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
-    "cagc_maplin_fwd": [_p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p],
-    "cagc_maplin_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p],
+    "cagc_maplin_fwd": [_p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _f, _f, _p],
+    "cagc_maplin_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _f, _f, _p],
     "cagc_mix_latent_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "cagc_mix_latent_bwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "cagc_modconv_prep_bank": [ctypes.POINTER(PrepJob), _i, _p],

@@ -869,41 +869,52 @@ class _ModBank(Function):
 # Mapping-network layer: EqualLinear(512 -> O, activation='fused_lrelu') as ONE launch forward, ONE backward (csrc/mapping.hip)
 # ---------------------------------------------------------------------------------------------------
 class _MapLinear(Function):
-    """y = lrelu(x @ (W * scale)^T + b * lr_mul, 0.2) * sqrt(2)   (reference model.py:156-166 with op/fused_act.py:104-119)."""
+    """y = x @ (W * scale)^T + b * lr_mul, with activation: lrelu(y, 0.2) * sqrt(2)   (reference model.py:156-166 with
+    op/fused_act.py:104-119)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, scale, lr_mul):
+    def forward(ctx, x, weight, bias, scale, lr_mul, act):
         x = x.contiguous()
         w = weight.detach().contiguous()
-        b = bias.detach().contiguous()
+        b = bias.detach().contiguous() if bias is not None else None
         R, O = x.shape[0], w.shape[0]
         y = torch.empty(R, O, dtype=x.dtype, device=x.device)
         with _lib.on_device(x):
             _lib.call("cagc_maplin_fwd", _lib.ptr(y), _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), R, x.shape[1], O, float(scale), float(lr_mul),
-                      0.2, SQRT2)
-        ctx.save_for_backward(x, w, y)
-        ctx.scale, ctx.lr_mul = float(scale), float(lr_mul)
+                      1 if act else 0, 0.2, SQRT2)
+        ctx.save_for_backward(x, weight, y if act else x.new_empty(0))
+        ctx.scale, ctx.lr_mul, ctx.act = float(scale), float(lr_mul), bool(act)
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gy):
-        x, w, y = ctx.saved_tensors
-        gy = gy.contiguous()
-        R, O = y.shape
+        x, weight, y = ctx.saved_tensors
         need_x, need_w, need_b = ctx.needs_input_grad[0:3]
+        if torch.is_grad_enabled():
+            # create_graph=True (R1 through the discriminator's final linears, train.py:194-200): the same maps from
+            # differentiable ops — the gate is a constant of the second differentiation, as in op/fused_act.py:46-53
+            gpre = gy * (torch.where(y > 0, 1.0, 0.2) * SQRT2).to(gy.dtype) if ctx.act else gy
+            gx = (gpre @ weight) * ctx.scale if need_x else None
+            gw = (gpre.t() @ x) * ctx.scale if need_w else None
+            gb = gpre.sum(0) * ctx.lr_mul if need_b else None
+            return gx, gw, gb, None, None, None
+        w = weight.detach().contiguous()
+        gy = gy.contiguous()
+        R, O = gy.shape
         gx = torch.empty_like(x) if need_x else None
         gw = torch.empty_like(w) if (need_w or need_b) else None
         gb = torch.empty(O, dtype=x.dtype, device=x.device) if (need_w or need_b) else None
         with _lib.on_device(x):
-            _lib.call("cagc_maplin_bwd", _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(w), R,
-                      x.shape[1], O, ctx.scale, ctx.lr_mul, 0.2, SQRT2)
-        return gx, (gw if need_w else None), (gb if need_b else None), None, None
+            _lib.call("cagc_maplin_bwd", _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(gy), _lib.ptr(y) if ctx.act else None, _lib.ptr(x),
+                      _lib.ptr(w), R, x.shape[1], O, ctx.scale, ctx.lr_mul, 1 if ctx.act else 0, 0.2, SQRT2)
+        return gx, (gw if need_w else None), (gb if need_b else None), None, None, None
 
 
 def map_linear_ok(x, lin):
-    return (use_hip(x) and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 512 and lin.weight.shape[1] == 512
-            and lin.bias is not None and lin.activation and lin.weight.dtype == torch.float32)
+    """Few-row EqualLinear on the one-launch kernels: the mapping network (512 -> 512, activation) and D's final linears."""
+    return (use_hip(x) and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] <= 256 and x.shape[1] % 512 == 0
+            and lin.weight.shape[1] == x.shape[1] and lin.weight.dtype == torch.float32
+            and (lin.bias is not None or not lin.activation) and lin.activation in (None, "fused_lrelu"))
 
 
 class _MixLatent(Function):

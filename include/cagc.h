@@ -273,17 +273,17 @@ int cagc_torgb_bwd_finish(float* gw, float* gs, const float* gws, const float* s
                           float scale, cagc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Mapping-network layer             replaces model.py:137-166 EqualLinear(activation='fused_lrelu') as the generator's
- *                                   mapping network uses it (model.py:421-430; F.linear + fused_bias_act, op/fused_act.py):
- *   y [R,O] = lrelu(x [R,512] @ (W [O,512] * scale)^T + b [O] * lr_mul, alpha) * act_scale         ONE launch
- *   backward (ONE launch), gpre = gy * (y > 0 ? 1 : alpha) * act_scale:
- *     gx [R,512] = scale * gpre @ W [nullable];  gweight [O,512] = scale * gpre^T @ x [nullable];  gbias [O] = lr_mul * sum_r gpre
- *     [nullable, only with gweight].  in_dim must be 512.
+ * EqualLinear on few rows           replaces model.py:137-166 (F.linear + fused_bias_act, op/fused_act.py) for the generator's
+ *                                   mapping network (model.py:421-430) and the discriminator's final linears (:773-776):
+ *   y [R,O] = x [R,D] @ (W [O,D] * scale)^T + b [O] * lr_mul,   act != 0: y = lrelu(y, alpha) * act_scale          ONE launch
+ *   backward (ONE launch), gpre = act ? gy * (y > 0 ? 1 : alpha) * act_scale : gy:
+ *     gx [R,D] = scale * gpre @ W [nullable];  gweight [O,D] = scale * gpre^T @ x [nullable];  gbias [O] = lr_mul * sum_r gpre
+ *     [nullable, only with gweight].  D must be a multiple of 512; bias [nullable] forward; y [nullable iff act == 0] backward.
  * ---------------------------------------------------------------------------------------------- */
 int cagc_maplin_fwd(float* y, const float* x, const float* weight, const float* bias, int R, int in_dim, int out_dim,
-                    float scale, float lr_mul, float alpha, float act_scale, cagc_stream_t stream);
+                    float scale, float lr_mul, int act, float alpha, float act_scale, cagc_stream_t stream);
 int cagc_maplin_bwd(float* gx, float* gweight, float* gbias, const float* gy, const float* y, const float* x,
-                    const float* weight, int R, int in_dim, int out_dim, float scale, float lr_mul, float alpha,
+                    const float* weight, int R, int in_dim, int out_dim, float scale, float lr_mul, int act, float alpha,
                     float act_scale, cagc_stream_t stream);
 /* Style mixing (model.py:586-594: cat of the two repeated styles at inject_index) with the index on the DEVICE (one int64;
  * static shapes, so the step can live in a HIP graph):  latent [B,n_latent,D][b,i,:] = i < *inject ? w0[b,:] : w1[b,:];

@@ -23,13 +23,18 @@ def _rel(a, b):
     return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max() / b.detach().double().abs().max().clamp_min(1e-300))
 
 
-@pytest.mark.parametrize("R,O,lr_mul", [(2, 512, 0.01), (4, 512, 0.01), (32, 512, 0.01), (130, 512, 1.0), (3, 40, 0.5)])
-def test_mapping_layer_forward_backward_vs_float64(R, O, lr_mul):
+@pytest.mark.parametrize("R,D,O,lr_mul,act", [(2, 512, 512, 0.01, True), (4, 512, 512, 0.01, True), (32, 512, 512, 0.01, True),
+                                             (130, 512, 512, 1.0, True), (3, 512, 40, 0.5, True), (16, 8192, 512, 1.0, True),
+                                             (2, 8192, 512, 1.0, True), (16, 512, 1, 1.0, False), (5, 1024, 77, 1.0, False)])
+def test_few_row_equal_linear_forward_backward_vs_float64(R, D, O, lr_mul, act):
+    """Mapping-network layers (512 -> 512, lr_mul 0.01, fused lrelu) and the discriminator's final linears (8192 -> 512 with
+    activation, 512 -> 1 without) on cagc_maplin_fwd / _bwd: output and all three gradients vs float64; the frozen form (input
+    gradient only); and the differentiable backward that create_graph=True asks for (R1 through D's final linears)."""
     torch.manual_seed(51)
-    lin = M.EqualLinear(512, O, lr_mul=lr_mul, activation="fused_lrelu")
+    lin = M.EqualLinear(D, O, lr_mul=lr_mul, activation="fused_lrelu" if act else None)
     with torch.no_grad():
         lin.bias.copy_(torch.randn(O))
-    x = torch.randn(R, 512)
+    x = torch.randn(R, D)
     gy = torch.randn(R, O)
     x64 = x.double().requires_grad_(True)
     w64, b64 = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
@@ -39,16 +44,26 @@ def test_mapping_layer_forward_backward_vs_float64(R, O, lr_mul):
     assert mc.map_linear_ok(xg, ling)
     yg = ling(xg)
     assert type(yg.grad_fn).__name__ == "_MapLinearBackward"
-    gate = (yg.detach() > 0).cpu()
-    dis = gate != (pre.detach() > 0)
-    assert int(dis.sum()) == 0 or float(pre.detach()[dis].abs().max()) < 1e-5 * float(pre.detach().abs().max())
-    y64 = torch.where(gate, pre, 0.2 * pre) * math.sqrt(2)
-    g64 = torch.autograd.grad(y64, [x64, w64, b64], gy.double())
-    gg = torch.autograd.grad(yg, [xg, ling.weight, ling.bias], gy.to(DEV))
+    if act:
+        gate = (yg.detach() > 0).cpu()
+        dis = gate != (pre.detach() > 0)
+        assert int(dis.sum()) == 0 or float(pre.detach()[dis].abs().max()) < 1e-5 * float(pre.detach().abs().max())
+        y64 = torch.where(gate, pre, 0.2 * pre) * math.sqrt(2)
+    else:
+        y64 = pre
+    g64 = torch.autograd.grad(y64, [x64, w64, b64], gy.double(), retain_graph=True)
+    gg = torch.autograd.grad(yg, [xg, ling.weight, ling.bias], gy.to(DEV), retain_graph=True)
     assert _rel(yg, y64) <= 5e-6
     for nm, a, b in zip(("x", "weight", "bias"), gg, g64):
         assert _rel(a, b) <= 5e-6, (nm, _rel(a, b))
-    # a frozen layer (teacher): same kernel, no weight gradient requested
+    # second order: d/d(weight) of |d y / d x . v|^2  (the R1 pattern) — the backward built from differentiable ops
+    v = torch.randn(R, O)
+    (gx_c,) = torch.autograd.grad(yg, xg, v.to(DEV), create_graph=True)
+    (gw2,) = torch.autograd.grad(gx_c.pow(2).sum(), ling.weight)
+    (gx64_c,) = torch.autograd.grad(y64, x64, v.double(), create_graph=True)
+    (gw2_64,) = torch.autograd.grad(gx64_c.pow(2).sum(), w64)
+    assert _rel(gw2, gw2_64) <= 2e-5, ("second order", _rel(gw2, gw2_64))
+    # a frozen layer (teacher / D on the generator step): same kernel, input gradient only
     for p in ling.parameters():
         p.requires_grad_(False)
     xg2 = x.to(DEV).requires_grad_(True)

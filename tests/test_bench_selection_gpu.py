@@ -124,7 +124,7 @@ def test_discriminator_256_frozen_f4_forced_vs_float64(f4_everywhere):
     (gx,) = torch.autograd.grad(F.softplus(-pred).mean(), xg)
     with torch.no_grad(), ref_ops.gates() as rec:
         pred64_own = ref_model.discriminator_forward_ref(sd64, x.double())
-    n_dis = ref_ops.gate_disagreements(rec, gates_g, rounding=1e-3, max_fraction=1e-3)
+    n_dis = ref_ops.gate_disagreements(rec, gates_g, rounding=1e-4, max_fraction=1e-5)      # observed: 21 of 6.2e7, worst at 1.1e-6
     worst_pre = max((float(p[o != g.reshape(o.shape)].abs().max()) / float(p.abs().max())) if bool((o != g.reshape(o.shape)).any()) else 0.0
                     for p, o, g in zip(rec.pre, rec.own, gates_g))
     x64 = x.double().requires_grad_(True)
@@ -135,9 +135,10 @@ def test_discriminator_256_frozen_f4_forced_vs_float64(f4_everywhere):
     n_gates = sum(g.numel() for g in gates_g)
     print(f"D(256) F(4x4) forced: {n_dis} of {n_gates} gates disagree with float64 (worst at {worst_pre:.1e} of its layer's scale); "
           f"scores vs float64 {e_own:.2e}, on the common pattern {e_y:.2e}, input gradient {e_gx:.2e}")
+    # observed (gpurun_out/r4_c_newtests.log): scores 9.4e-6, input gradient 2.5e-6 — the bars keep a decade of margin below 1e-3
     assert e_own <= 1e-3, f"D(256) scores vs float64 (own gates): {e_own:.2e}"
-    assert e_y <= 2e-4, f"D(256) scores on the common gate pattern: {e_y:.2e}"
-    assert e_gx <= 5e-4, f"D(256) input gradient on the common gate pattern: {e_gx:.2e}"
+    assert e_y <= 1e-4, f"D(256) scores on the common gate pattern: {e_y:.2e}"
+    assert e_gx <= 5e-5, f"D(256) input gradient on the common gate pattern: {e_gx:.2e}"
 
 
 def test_kd_step_configs1_f4_forced_vs_float64(f4_everywhere):
@@ -180,7 +181,7 @@ def test_kd_step_configs1_f4_forced_vs_float64(f4_everywhere):
     z64, sn64, tn64, m64 = [z.double() for z in zs], [n.double() for n in sn], [n.double() for n in tn], mask.double()
     with torch.no_grad(), ref_ops.gates() as rec:
         gl_own, kl_own, img_own = ref_kd.kd_generator_losses_ref(s_sd, t_sd, d_sd, z64, inj, m64, sn64, tn64)
-    n_dis = ref_ops.gate_disagreements(rec, gates_g, rounding=1e-3, max_fraction=1e-3)
+    n_dis = ref_ops.gate_disagreements(rec, gates_g, rounding=1e-4, max_fraction=1e-5)      # observed: 72 of 1.4e8
     leaves = {k: s_sd[k].clone().requires_grad_(True) for k in names}
     sdr = dict(s_sd)
     sdr.update(leaves)
@@ -201,15 +202,17 @@ def test_kd_step_configs1_f4_forced_vs_float64(f4_everywhere):
             worst, worst_k = e, k
     print(f"configs[1] KD step, F(4x4) forced, B = {B}: {n_dis} of {n_gates} gates disagree with float64; student image vs float64 "
           f"{e_img_own:.2e} (common pattern {e_img:.2e}), teacher image {e_t:.2e}, worst student gradient {worst:.2e} ({worst_k}); "
-          f"g_loss {float(g_loss):.6f} vs {float(gl64):.6f}, kd_l1 {float(kd_l1):.6f} vs {float(kl64):.6f}")
+          f"g_loss {float(g_loss.detach()):.6f} vs {float(gl64.detach()):.6f}, kd_l1 {float(kd_l1.detach()):.6f} vs {float(kl64.detach()):.6f}")
     assert e_img_own <= 1e-3 and e_t <= 1e-3, f"images vs float64: student {e_img_own:.2e}, teacher {e_t:.2e}"
-    assert e_img <= 2e-4, f"student image on the common gate pattern: {e_img:.2e}"
-    assert abs(float(g_loss) - float(gl64)) <= 1e-3 * max(1.0, abs(float(gl64))) and abs(float(kd_l1) - float(kl64)) <= 1e-3 * max(1.0, abs(float(kl64)))
+    assert e_img <= 2e-5, f"student image on the common gate pattern: {e_img:.2e}"        # observed 1.7e-6
+    gl, kl, gl_r, kl_r = float(g_loss.detach()), float(kd_l1.detach()), float(gl64.detach()), float(kl64.detach())
+    assert abs(gl - gl_r) <= 1e-4 * max(1.0, abs(gl_r)) and abs(kl - kl_r) <= 1e-4 * max(1.0, abs(kl_r))
     for k in names:
         if g64[k] is not None:
             e = _rel(grads[k], g64[k])
             # single-element gradients (noise.weight) are cancelling sums over up to 10^6 pixels
-            assert e <= (1e-3 if g64[k].numel() > 1 else 1e-2), f"student gradient {k} on the common gate pattern ({n_dis} disagreements): {e:.2e}"
+            # observed worst 2.2e-6 (gpurun_out/r4_c_newtests.log); north-star bar 1e-3
+            assert e <= (5e-5 if g64[k].numel() > 1 else 1e-3), f"student gradient {k} on the common gate pattern ({n_dis} disagreements): {e:.2e}"
 
 
 def test_full_generator_fwd_bwd_batch64_properties():
