@@ -49,6 +49,9 @@ _PROTOS = {
     "cagc_modconv_packed_elems": [_i, _i, _i],
     "cagc_modconv_prep": [_p, _p, _p, _p, _i, _i, _i, _f, _p],
     "cagc_modconv_prep_all": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "cagc_gemm1x1_packed_elems": [_i, _i],
+    "cagc_gemm1x1_pack": [_p, _p, _i, _i, _f, _i, _p],
+    "cagc_gemm1x1": [_p, _p, _p, _p, _i, _i, _i, _i64, _f, _f, _p],
     "cagc_maplin_fwd": [_p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _f, _f, _p],
     "cagc_maplin_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _f, _f, _p],
     "cagc_mix_latent_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
@@ -95,6 +98,7 @@ _RESTYPES = {
     "cagc_modconv_packed_elems": _i64,
     "cagc_modconv_wgrad_workspace": _i64,
     "cagc_wino_packed_elems": _i64,
+    "cagc_gemm1x1_packed_elems": _i64,
     "cagc_content_mask_workspace": _i64,
 }
 EXPORTS = tuple(_PROTOS)

@@ -30,7 +30,8 @@ def init_from_env(backend=None):
             # (graph capture per rank, flat-gradient all-reduce, max-over-ranks timing) on a 1-GPU box
             if os.environ.get("CAGC_SINGLE_DEVICE") == "1":
                 local = 0
-            torch.cuda.set_device(local)
+            if backend != "gloo" or local < torch.cuda.device_count():   # CPU-tensor gloo runs on a box with fewer GPUs than ranks
+                torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)

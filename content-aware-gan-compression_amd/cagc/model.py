@@ -681,14 +681,13 @@ class ConvLayer(nn.Sequential):
         return super()._apply(fn, *a, **k)
 
     def _gemm_weights(self, conv):
-        """(scale*W [Cout,Cin], its transpose) of a 1x1 conv, for the plain-GEMM formulation of the ResBlock skip (a 1x1
-        convolution over NCHW is out[b] = W @ x[b]: a library batched SGEMM, rocBLAS reaches 90-130 TFLOP/s on these
-        shapes where the implicit-GEMM kernel's 8-channel chunks give 63-90 — scripts/time_1x1.py).  Cached for frozen
-        weights like the packed operands."""
+        """(A operand of scale*W, of its transpose) of a 1x1 conv, packed for the per-image GEMM kernel of the ResBlock skip
+        (csrc/conv1x1.hip; a 1x1 convolution over NCHW is out[b] = W @ x[b]).  Cached for frozen weights like the other packed
+        operands."""
         w = conv.weight
         def make():
-            w2 = (w.detach().reshape(w.shape[0], w.shape[1]) * conv.scale).contiguous()
-            return w2, w2.t().contiguous()
+            w2 = w.detach().reshape(w.shape[0], w.shape[1])
+            return mc.pack_gemm1x1(w2, conv.scale, False), mc.pack_gemm1x1(w2, conv.scale, True)
         if w.requires_grad:
             return make()
         key = (w._version, w.data_ptr(), w.device)

@@ -172,6 +172,18 @@ def pack_wino(weight4, scale, dgrad):
     return up
 
 
+def pack_gemm1x1(weight2, scale, transpose):
+    """weight [Cout,Cin] -> the 1x1-GEMM kernel's A operand (csrc/conv1x1.hip): forward A = scale * W (M = Cout, K = Cin);
+    transpose: A = scale * W^T (M = Cin, K = Cout), the data gradient."""
+    cout, cin = weight2.shape
+    w = weight2.detach().contiguous()
+    M, K = (cin, cout) if transpose else (cout, cin)
+    ap = torch.empty(_lib.query("cagc_gemm1x1_packed_elems", M, K), dtype=torch.float32, device=w.device)
+    with _lib.on_device(w):
+        _lib.call("cagc_gemm1x1_pack", _lib.ptr(ap), _lib.ptr(w), M, K, float(scale), 1 if transpose else 0)
+    return ap
+
+
 def wino_ok(H, W):
     return bool(_lib.query("cagc_wino_eligible", H, W))
 
@@ -686,7 +698,7 @@ class _ResBlockFrozen(Function):
     launch; backward returns only the input gradient and folds what autograd would add as separate passes into them —
     the 1/sqrt 2 of the merge rides in the activation backward's scale (conv path) and in the adjoint FIR's taps (skip
     path), the skip path's gradient is accumulated in the adjoint FIR's streaming pass (cagc_fir4x4_up2_acc), and the skip's
-    1x1 conv is a library batched SGEMM whose epilogue (alpha, beta) performs the residual merge.  Saves a full-tensor
+    1x1 conv is a per-image GEMM (csrc/conv1x1.hip) whose epilogue (alpha, beta) performs the residual merge.  Saves a full-tensor
     multiply, a full-tensor accumulate and the merge pass per block."""
 
     @staticmethod
@@ -714,10 +726,10 @@ class _ResBlockFrozen(Function):
                       0.2, SQRT2)
             del y2
             ys = _launch(x, firsk, (1, 1), (2, 2), (padsk[0], padsk[1], padsk[0], padsk[1]), (ho, wo))
-            # skip 1x1 conv + residual merge as ONE library batched SGEMM with its epilogue:
-            #   out[b] = (1/sqrt2) * (W_skip @ ys[b]) + (1/sqrt2) * y2a[b]          (wpsk_fwd = scale * W_skip, [Cout,Cin])
-            out = torch.baddbmm(y2a.view(B, cout, ho * wo), wpsk_fwd.unsqueeze(0).expand(B, cout, C), ys.view(B, C, ho * wo),
-                                beta=scale, alpha=scale).view(B, cout, ho, wo)
+            # skip 1x1 conv + residual merge as ONE per-image GEMM with an (alpha, beta) epilogue (csrc/conv1x1.hip):
+            #   out[b] = (1/sqrt2) * (W_skip @ ys[b]) + (1/sqrt2) * y2a[b]          (wpsk_fwd = packed scale * W_skip)
+            out = torch.empty(B, cout, ho, wo, dtype=x.dtype, device=dev)
+            _lib.call("cagc_gemm1x1", _lib.ptr(out), _lib.ptr(ys), _lib.ptr(wpsk_fwd), _lib.ptr(y2a), B, C, cout, ho * wo, scale, scale)
             del ys
         ctx.save_for_backward(y1, y2a, up1_bwd, wp2_bwd, wpsk_bwd, fir2, firsk)
         ctx.cfg = (B, C, H, W, cout, ho, wo, hb, wb, pitch, tuple(pad2), tuple(padsk))
@@ -738,7 +750,7 @@ class _ResBlockFrozen(Function):
         dev = g.device
         scale = 1.0 / SQRT2
         with _lib.on_device(g):
-            # skip branch, first half: the 1x1 data gradient W_skip^T @ g[b] (library SGEMM) depends on g alone — it runs on the
+            # skip branch, first half: the 1x1 data gradient W_skip^T @ g[b] (cagc_gemm1x1) depends on g alone — it runs on the
             # side stream next to the conv branch (its workgroups fill the tails of that chain's launches) and joins in front
             # of the adjoint FIR that adds it onto gx
             side = None
@@ -747,7 +759,8 @@ class _ResBlockFrozen(Function):
                 side = _side_stream(dev)
                 side.wait_stream(main)
             with (torch.cuda.stream(side) if side is not None else _nullctx()):
-                gy = torch.matmul(wpsk_bwd, g.view(B, cout, ho * wo)).view(B, C, ho, wo)
+                gy = torch.empty(B, C, ho, wo, dtype=g.dtype, device=dev)
+                _lib.call("cagc_gemm1x1", _lib.ptr(gy), _lib.ptr(g), _lib.ptr(wpsk_bwd), None, B, cout, C, ho * wo, 1.0, 0.0)
             # conv branch: activation backward carrying the 1/sqrt2, stride-2 data gradient, adjoint blur
             gz2 = torch.empty_like(g)
             _lib.call("cagc_fused_bias_act_bwd", _lib.ptr(gz2), None, _lib.ptr(g), _lib.ptr(y2a), B, cout, ho * wo, 0.2, SQRT2 * scale)

@@ -39,8 +39,12 @@ __global__ __launch_bounds__(256) void k_gemm1x1_pack(float* __restrict__ ap, co
   ap[idx] = v;
 }
 
-template <int MB>
+// KW = 1: the 4 waves of a workgroup own 4 x 64 pixels, each runs the whole K loop.  KW = 4 (under-filled launches: small images, small
+// per-GPU batches — a wave's K loop is a serial chain of K/4 x MB x 4 MFMAs, 31 us for 512 channels however small the image): the 4
+// waves share ONE 64-pixel tile and split K four ways; wave w finishes channel block w from the four partial sums (LDS exchange, no atomics).
+template <int MB, int KW>
 __global__ __launch_bounds__(256, 2) void k_gemm1x1(const G1Args A) {
+  static_assert(KW == 1 || MB == 4, "the K-split shape exchanges one channel block per wave");
   constexpr int NA = MB / 4;                   // float4 A loads per K-step
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lm = lane & 15, g = lane >> 4;
@@ -52,8 +56,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1(const G1Args A) {
     ptile = idx / A.mtiles; mtile = idx - ptile * A.mtiles;
   }
   const int b = ptile / A.nptile;
-  const int64_t p0 = (int64_t)(ptile - b * A.nptile) * 256 + wave * 64;
-  if (p0 >= A.P) return;
+  const int64_t p0 = KW == 1 ? (int64_t)(ptile - b * A.nptile) * 256 + wave * 64 : (int64_t)(ptile - b * A.nptile) * 64;
+  if (KW == 1 && p0 >= A.P) return;
+  const int kq_per = KW == 1 ? A.KQ : (A.KQ + KW - 1) / KW;
+  const int kq0 = KW == 1 ? 0 : wave * kq_per;
+  const int kq1 = KW == 1 ? A.KQ : (kq0 + kq_per < A.KQ ? kq0 + kq_per : A.KQ);       // this wave's K-steps [kq0, kq1)
   const int m0 = mtile * 16 * MB;
   // B operand: x[b][4kq + g][p0 + 4lm ..]: descriptor over the image's K x P plane from p0 on; rows beyond K / pixels beyond P read 0
   const int64_t xbase = (int64_t)b * A.K * A.P + p0;
@@ -101,9 +108,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1(const G1Args A) {
     }
   };
 #pragma unroll
-  for (int s = 0; s < RING; ++s) load(s, s);
-  int kq = 0;
-  for (; kq + RING <= A.KQ; kq += RING) {
+  for (int s = 0; s < RING; ++s) load(s, kq0 + s);
+  int kq = kq0;
+  for (; kq + RING <= kq1; kq += RING) {
 #pragma unroll
     for (int s = 0; s < RING; ++s) {
       mma(s);
@@ -114,15 +121,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1(const G1Args A) {
   }
 #pragma unroll
   for (int s = 0; s < RING; ++s)
-    if (kq + s < A.KQ) mma(s);
+    if (kq + s < kq1) mma(s);
 
+  if (KW > 1) {     // K split: wave w sums the four partials of channel block w
+    __shared__ f32x4 part[4][3][4][64];      // [block][source slot][pixel block j][lane]: 48 KB
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+      if (blk != wave) {
+        const int slot = (wave - blk - 1) & 3;   // 0..2
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[blk][slot][j][lane] = acc[blk][j];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+      if (blk == wave) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v = acc[blk][j];
+          v += part[blk][0][j][lane]; v += part[blk][1][j][lane]; v += part[blk][2][j][lane];
+          acc[0][j] = v;                       // own block moved to index 0 (register renaming only: blk is a compile-time constant)
+        }
+      }
+  }
   // epilogue: acc[blk][0..3][r] = 4 consecutive pixels of channel m0 + 16 blk + 4g + r
   if (!pix_ok) return;
 #pragma unroll
-  for (int blk = 0; blk < MB; ++blk)
+  for (int blk = 0; blk < (KW > 1 ? 1 : MB); ++blk)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + blk * 16 + 4 * g + r;
+      const int m = m0 + (KW > 1 ? wave : blk) * 16 + 4 * g + r;
       if (m >= A.M) continue;
       const int64_t o = ((int64_t)b * A.M + m) * A.P + p0 + 4 * lm;
       float4 v = make_float4(A.alpha * acc[blk][0][r], A.alpha * acc[blk][1][r], A.alpha * acc[blk][2][r], A.alpha * acc[blk][3][r]);
@@ -134,10 +162,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1(const G1Args A) {
     }
 }
 
-// channel blocks per workgroup tile: 8 (128 channels), or 4 when that grid would leave the chip under-filled / M is small
-static int g1_mb(int B, int M, int64_t P) {
-  const int64_t wg8 = (int64_t)B * cdiv(P, 256) * cdiv(M, 128);
-  return (M > 64 && wg8 >= 256) ? 8 : 4;
+// workgroup shape per launch: 128 channels x 256 pixels (MB 8) when that grid fills the chip, else 64 x 256 (MB 4), else — fewer than
+// two workgroups per CU even so — 64 channels x 64 pixels with K split across the four waves (KW 4)
+struct G1Shape { int mb, kw; };
+static G1Shape g1_shape(int B, int M, int64_t P) {
+  const int64_t wg8 = (int64_t)B * cdiv(P, 256) * cdiv(M, 128), wg4 = (int64_t)B * cdiv(P, 256) * cdiv(M, 64);
+  if (M > 64 && wg8 >= 256) return G1Shape{8, 1};
+  if (wg4 >= 512) return G1Shape{4, 1};
+  return G1Shape{4, 4};
 }
 
 }  // namespace cagc
@@ -168,15 +200,17 @@ extern "C" int cagc_gemm1x1(float* out, const float* x, const float* ap, const f
   CAGC_REQUIRE((int64_t)K * P * 4 < (1ll << 31), "%s: image plane too large for 32-bit offsets", what);
   G1Args a;
   a.out = out; a.x = x; a.res = residual; a.B = B; a.K = K; a.KQ = cdiv(K, 4); a.M = M; a.P = P; a.alpha = alpha; a.beta = beta;
-  a.nptile = cdiv(P, 256);
-  const int mb = g1_mb(B, M, P);
+  const G1Shape sh = g1_shape(B, M, P);
+  const int mb = sh.mb;
+  a.nptile = cdiv(P, sh.kw == 1 ? 256 : 64);
   const int64_t n8 = (int64_t)cdiv(K, 4) * cdiv(M, 128) * 64 * 8;
   a.ap = mb == 8 ? ap : ap + n8;
   a.mtiles = cdiv(M, 16 * mb);
   CAGC_REQUIRE((int64_t)a.KQ * a.mtiles * 64 * mb * 4 < (1ll << 31), "%s: packed weights too large", what);
   const int64_t grid = (int64_t)B * a.nptile * a.mtiles;
   CAGC_REQUIRE(grid < (1ll << 31), "%s: grid too large", what);
-  if (mb == 8) hipLaunchKernelGGL(k_gemm1x1<8>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
-  else hipLaunchKernelGGL(k_gemm1x1<4>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+  if (mb == 8) hipLaunchKernelGGL((k_gemm1x1<8, 1>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+  else if (sh.kw == 1) hipLaunchKernelGGL((k_gemm1x1<4, 1>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((k_gemm1x1<4, 4>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
   return check_launch(what);
 }

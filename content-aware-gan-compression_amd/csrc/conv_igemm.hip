@@ -644,35 +644,9 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
       if (ks > nchunks / 2) ks = nchunks / 2;
       if (ks < 1) ks = 1;
     }
-    // Items with different tap counts (the 4 / 2 / 2 / 1-tap output phases of a transposed conv) make workgroups of very
-    // different duration; when the launch is about one round of the chip, the makespan is the 4-tap workgroups' and half
-    // the CUs idle (256 -> 512 @64^2 at per-GPU batch 2: 351 us for 203 us of MFMA work).  Split K per item in proportion
-    // to its taps instead, so every workgroup carries the same number of (tap, chunk) products.
-    // MEASURED NEGATIVE (gpurun_out/run10.log, per-GPU batch 2): 304 -> 491 us on the 128->256 @257^2 stride-2 data gradient,
-    // 305 -> 433 us on the 256->128 @128^2 transposed conv: the 4-way fp32-atomic accumulation of the 4-tap phase costs more
-    // than the idle CUs it fills.  Kept behind CAGC_TAP_SPLIT=1 for the record; the default is the uniform split.
-    int min_taps = 1 << 20, max_taps = 0;
-    for (int p = 0; p < nitems; ++p) {
-      min_taps = raw[p].ntaps < min_taps ? raw[p].ntaps : min_taps;
-      max_taps = raw[p].ntaps > max_taps ? raw[p].ntaps : max_taps;
-    }
-    const bool by_taps = allow_split && nitems > 1 && raw[0].nph == 1 && max_taps > min_taps && tiles_all * mt <= 512 &&
-                         nchunks >= 8 && getenv("CAGC_TAP_SPLIT") != nullptr;   // OFF by default — measured slower, see below
+    // (K split in proportion to an item's taps — the 4 / 2 / 2 / 1-tap phases of a transposed conv — was measured slower: the 4-way
+    // fp32-atomic accumulation of the 4-tap phase costs more than the idle CUs it fills; the split is uniform.)
     int ks_max = ks;
-    if (by_taps) {
-      int64_t units = 0;   // workgroups if every item is split `ntaps / min_taps` ways
-      for (int p = 0; p < nitems; ++p)
-        units += (int64_t)cdiv(a.B, a.items[p].IPB) * a.items[p].tiles_x * a.items[p].tiles_y * mt * (raw[p].ntaps / min_taps);
-      const int base = units < 256 ? cdiv(256, units) : 1;
-      ks_max = 1;
-      for (int p = 0; p < nitems; ++p) {
-        int k = base * (raw[p].ntaps / min_taps);
-        if (k > nchunks / 2) k = nchunks / 2;
-        if (k < 1) k = 1;
-        a.items[p].ks = k;
-        ks_max = k > ks_max ? k : ks_max;
-      }
-    }
     if (mixed) {   // strips: 4-way K split (their regions are zeroed by the caller), main regions: none
       int kss = 4;
       if (kss > nchunks / 2) kss = nchunks / 2;
@@ -683,7 +657,7 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
     a.ksplit = ks_max;
     for (int p = 0; p < nitems; ++p) {
       ConvItem& I = a.items[p];
-      if (!by_taps && !mixed) I.ks = ks;
+      if (!mixed) I.ks = ks;
       blocks += cdiv(a.B, I.IPB) * I.tiles_x * I.tiles_y * I.ks;
       I.block_end = blocks;
     }
@@ -698,12 +672,11 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
     // phase per 8-channel chunk (32 MFMAs per wave and tap) is short against two barriers + the LDS commit; two buffers
     // need one barrier per chunk and let the commit overlap the draining matrix pipe.  Only while two workgroups still
     // fit a CU (<= 80 KB each).
-    static const bool db_off = getenv("CAGC_NO_DBUF") != nullptr;
     int mtaps = 0;
     for (int p = 0; p < nitems; ++p) mtaps = raw[p].ntaps > mtaps ? raw[p].ntaps : mtaps;
     const size_t a_sz = (size_t)mtaps * CONV_CK * LDA, b_sz = (size_t)CONV_CK * max_ps;
     a.dbuf = 0; a.a_sz = 0; a.b_sz = 0;
-    if (!db_off && nph == 1 && mtaps <= 4 && nchunks >= 4 && 2 * (a_sz + b_sz) * sizeof(float) <= 80 * 1024) {
+    if (nph == 1 && mtaps <= 4 && nchunks >= 4 && 2 * (a_sz + b_sz) * sizeof(float) <= 80 * 1024) {
       a.dbuf = 1; a.a_sz = (int)a_sz; a.b_sz = (int)b_sz;
       smem = 2 * (a_sz + b_sz) * sizeof(float);
     }
@@ -726,17 +699,6 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
                      raw[0].ntaps, mb, nv, smem, (int)(160 * 1024 / smem), blocks * mtiles, ks, a.dbuf, a.Kp, a.Mp);
   }
   int rc;
-  if (nph == 4) {
-    CAGC_REQUIRE(a.vec && nv <= 4 && !a.gs, "%s: fused-phase path needs the aligned small-tile configuration", what);
-    switch (mb) {
-      case 1: rc = launch_conv<1, 4, true, false, 4>(a, smem, grid, st, what); break;
-      case 2: rc = launch_conv<2, 4, true, false, 4>(a, smem, grid, st, what); break;
-      case 3: rc = launch_conv<3, 4, true, false, 4>(a, smem, grid, st, what); break;
-      case 4: rc = launch_conv<4, 4, true, false, 4>(a, smem, grid, st, what); break;
-      default: rc = launch_conv<5, 4, true, false, 4>(a, smem, grid, st, what); break;
-    }
-    return rc;
-  }
   switch (mb) {
     case 1: rc = launch_conv_nv<1>(a, nv, smem, grid, st, what); break;
     case 2: rc = launch_conv_nv<2>(a, nv, smem, grid, st, what); break;
@@ -756,74 +718,6 @@ static int run_conv(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st,
   return rc;
 }
 
-
-// Fused-phase work item for a stride-2 transposed 3x3 conv over the exact H x W main region: taps ordered by phase
-// (py,px) = (0,0),(0,1),(1,0),(1,1) with 4/2/2/1 taps.
-static RawItem fused_phase_item(RawTap* taps9, int H, int W, bool planar_out) {
-  RawItem it{};
-  int n = 0;
-  for (int py = 0; py < 2; ++py)
-    for (int px = 0; px < 2; ++px) {
-      const int ph = py * 2 + px;
-      int cnt = 0;
-      for (int jy = 0; jy < (py ? 1 : 2); ++jy)
-        for (int jx = 0; jx < (px ? 1 : 2); ++jx) { taps9[n++] = RawTap{0, -jy, -jx, (py + 2 * jy) * 3 + (px + 2 * jx)}; ++cnt; }
-      it.ph_ntaps[ph] = cnt;
-      it.ph_out_plane[ph] = planar_out ? ph : 0;
-      it.ph_ooy[ph] = planar_out ? 0 : py;
-      it.ph_oox[ph] = planar_out ? 0 : px;
-    }
-  it.ntaps = n; it.taps = taps9; it.out_plane = 0; it.vy_base = 0; it.vx_base = 0; it.Hv = H; it.Wv = W; it.nph = 4;
-  return it;
-}
-// The fused-phase kernel needs the 16-byte staging path with the small (NV = 4) tile: W % 4 == 0 and a 32-wide or
-// whole-row tile; tiny layers that would be split over K keep the per-phase path (atomics).
-static bool fused_phase_ok(int B, int H, int W, int Mp) {
-  // Measured on MI355X (bench_11 vs bench_10): the fused-phase variant needs 4 accumulator sets -> 1 wave / SIMD and
-  // 64-channel tiles, and loses to the per-phase launches at 2 waves / SIMD (up_fwd 7.6 vs 7.0 ms, s2 dgrad 7.5 vs
-  // 6.7 ms per step).  Re-measured in round 2 with the low-VALU staging: 1743 us vs 1453 us per-phase on 512->256 @64^2, and
-  // 1682 us with 32-channel tiles at 2 waves / SIMD.  Kept selectable for tuning, off by default.
-  static const bool enabled = getenv("CAGC_FUSED_PHASES") != nullptr;
-  if (!enabled) return false;
-  if (W % 4 != 0 || W < 16) return false;
-  const int64_t tiles = (int64_t)B * cdiv(H, CONV_NT / (W < 32 ? W : 32)) * cdiv(W, 32);
-  return tiles * cdiv(Mp, 64) >= 256;
-}
-
-// Balanced per-phase launches for under-filled transposed-conv style launches (4 output phases with 4 / 2 / 2 / 1 taps):
-// one launch per phase with 2 / 4 / 4 / 8 channel blocks per workgroup, so every workgroup carries 8 (tap, block) units
-// and the chip sees ~9/8 * tiles * blocks equal workgroups — no K split, no atomics, no zero-fill of the main region.
-// (The alternative — splitting K in proportion to the taps — was measured slower: the atomics cost more than the idle CUs.)
-static bool balanced_phases_ok(int B, int Hv, int Wv, int Mp) {
-  // MEASURED NEGATIVE (gpurun_out/run14.log, per-GPU batch 2): 512->256 @64^2 330 -> 597 us, 512->512 @32^2 248 -> 586 us.
-  // A workgroup's cost at these sizes is dominated by staging its input tile, which does not shrink with the number of
-  // channel blocks — four times the workgroups stage the same tiles four times.  Off unless CAGC_PHASE_MB=1.
-  static const bool on = getenv("CAGC_PHASE_MB") != nullptr;
-  if (!on) return false;
-  const int nblk = Mp / 16;
-  if (nblk % 8 != 0) return false;
-  const int TW = pow2ceil(Wv) < 32 ? (pow2ceil(Wv) < 4 ? 4 : pow2ceil(Wv)) : 32;
-  int TH = pow2ceil(Hv);
-  if (TH > CONV_NT / TW) TH = CONV_NT / TW;
-  int IPB = CONV_NT / (TW * TH);
-  if (IPB > pow2ceil(B)) IPB = pow2ceil(B);
-  const int64_t T = (int64_t)cdiv(B, IPB) * cdiv(Wv, TW) * cdiv(Hv, TH);
-  const int64_t old_wgs = 4 * T * (nblk / 8), new_wgs = T * nblk * 9 / 8;
-  return old_wgs < 512 && new_wgs >= 200;
-}
-static int phase_mb(int ntaps) { return ntaps >= 4 ? 2 : (ntaps == 2 ? 4 : 8); }
-
-// Large transposed-conv style launches: main regions and edge strips in ONE launch (strips first: their long K loops start
-// early and the main regions' workgroups fill in behind them).  As two launches the strips' ~50-300 workgroups ran alone on
-// the chip: 226 us of the 1667 us of the 512->256 @64^2 layer for 3 % of its FLOPs (profiles/r02_upfwd_pmc.md).
-// MEASURED (gpurun_out/run23.log vs run21.log, bs 16): 512->256 @64^2 1597 -> 1637 us, 256->128 @128^2 1616 -> 1643 us,
-// stride-2 data gradient 256->512 @129^2 1560 -> 1626 us; only the student's 154->77 @64^2 gains (270 -> 231 us).  The strips,
-// cut down to the main regions' staging footprint (fewer images per tile, 4-way K split), become more and less efficient
-// workgroups that take CU slots from the main regions.  Off unless CAGC_COMBINED_STRIPS=1.
-static bool combined_strips_ok(bool small, bool fused) {
-  static const bool on = getenv("CAGC_COMBINED_STRIPS") != nullptr;
-  return on && !small && !fused;
-}
 
 static void base_args(ConvArgs& a, float* out, const float* in, const float* wp, int B, int K, int M, int kk) {
   memset(&a, 0, sizeof(a));
@@ -928,44 +822,18 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
     RawItem uni[4];
     for (int ph = 0; ph < 4; ++ph) uni[ph] = RawItem{items[ph].ntaps, taps[ph], ph, 0, 0, H + 1, W + 1};
     ConvArgs au = a;
-    static const char* only = getenv("CAGC_UP_PHASE");      // timing aid (scripts/time_upfwd.py): one parity alone
-    const int rd = only ? run_conv_rd(au, uni + (atoi(only) & 3), 1, st, what) : run_conv_rd(au, uni, 4, st, what);
+    const int rd = run_conv_rd(au, uni, 4, st, what);
     if (rd != CAGC_RD_DECLINED) return rd;
   }
-  bool small = (int64_t)B * H * W <= 32768;   // only small layers are ever split over K
+  // fallback (the register-direct kernel declined: tensors beyond its 32-bit offsets, CAGC_RD=0): LDS-staged kernel, main regions
+  // and edge strips as two launches
+  const bool small = (int64_t)B * H * W <= 32768;   // only small layers are ever split over K
   ConvArgs a2 = a;
-  int rc;
-  if (combined_strips_ok(small, fused_phase_ok(B, H, W, a.Mp))) {
-    const int64_t planes = (int64_t)B * Cout * 4;
-    hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (H + 1 + W + 1), 256)), dim3(256), 0, st, t, planes, H + 1,
-                       W + 1, a.Wopitch, H, W);
-    RawItem all[12];
-    int n = 0;
-    for (int q = 0; q < ns; ++q) { all[n] = items[4 + q]; all[n].strip = 1; ++n; }
-    for (int ph = 0; ph < 4; ++ph) all[n++] = items[ph];
-    return run_conv(a, all, n, st, what, false, false);
-  }
-  if (small && balanced_phases_ok(B, H, W, a.Mp)) {
-    for (int ph = 0; ph < 4; ++ph) {
-      ConvArgs ap = a;
-      rc = run_conv(ap, &items[ph], 1, st, what, false, false, phase_mb(items[ph].ntaps));
-      if (rc) return rc;
-    }
-    small = false;      // strips: zero just their regions, as in the large-layer path
-  } else {
   if (small) {
     const size_t bytes = sizeof(float) * (size_t)B * Cout * 4 * (H + 1) * a.Wopitch;
     { int zrc = zero_fill(t, bytes, st); if (zrc) return zrc; }
   }
-  if (fused_phase_ok(B, H, W, a.Mp)) {
-    RawTap t9[9];
-    RawItem fi = fused_phase_item(t9, H, W, /*planar_out=*/true);
-    rc = run_conv(a, &fi, 1, st, what, false, false);
-  } else {
-    rc = run_conv(a, items, 4, st, what, false, small);
-  }
-  if (rc) return rc;
-  }
+  { const int rc = run_conv(a, items, 4, st, what, false, small); if (rc) return rc; }
   if (!small) {   // strips: few workgroups with long K loops -> split K; zero just the strip regions first
     const int64_t planes = (int64_t)B * Cout * 4;
     hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (H + 1 + W + 1), 256)), dim3(256), 0, st, t, planes, H + 1,
@@ -1085,42 +953,15 @@ extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_b
     const int rd = run_conv_rd(au, uni, 4, st, what);
     if (rd != CAGC_RD_DECLINED) return rd;
   }
+  // fallback (the register-direct kernel declined): LDS-staged kernel, main regions and edge strips as two launches.  Low-resolution
+  // layers (too few pixel tiles to fill the chip, a 64-chunk K loop per workgroup) split K with atomics: whole gradient zeroed first
   ConvArgs a2 = a;
-  int rc;
-  // low-resolution layers: too few pixel tiles to fill the chip and a 64-chunk K loop per workgroup -> split K
-  // (atomics), which needs the whole gradient zeroed first
-  bool small = (int64_t)B * Ho * Wo <= 32768;
-  if (combined_strips_ok(small, fused_phase_ok(B, Ho, Wo, a.Mp))) {
-    const int64_t planes = (int64_t)B * Cin;
-    hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (Hin + Win), 256)), dim3(256), 0, st, gx, planes, Hin, Win,
-                       out_pitch, Hin - 1, Win - 1);
-    RawItem all[12];
-    int n = 0;
-    for (int q = 0; q < ns; ++q) { all[n] = strip_items[q]; all[n].strip = 1; ++n; }
-    for (int ph = 0; ph < 4; ++ph) all[n++] = main_items[ph];
-    return run_conv(a, all, n, st, what, false, false);
-  }
-  if (small && balanced_phases_ok(B, Ho, Wo, a.Mp)) {
-    for (int ph = 0; ph < 4; ++ph) {
-      ConvArgs ap = a;
-      rc = run_conv(ap, &main_items[ph], 1, st, what, false, false, phase_mb(main_items[ph].ntaps));
-      if (rc) return rc;
-    }
-    small = false;
-  } else {
+  const bool small = (int64_t)B * Ho * Wo <= 32768;
   if (small) {
     const size_t bytes = sizeof(float) * (size_t)B * Cin * Hin * out_pitch;
     { int zrc = zero_fill(gx, bytes, st); if (zrc) return zrc; }
   }
-  if (fused_phase_ok(B, Ho, Wo, a.Mp)) {
-    RawTap t9[9];
-    RawItem fi = fused_phase_item(t9, Ho, Wo, /*planar_out=*/false);
-    rc = run_conv(a, &fi, 1, st, what, false, false);
-  } else {
-    rc = run_conv(a, main_items, 4, st, what, false, small);
-  }
-  if (rc) return rc;
-  }
+  { const int rc = run_conv(a, main_items, 4, st, what, false, small); if (rc) return rc; }
   if (!small) {
     const int64_t planes = (int64_t)B * Cin;
     hipLaunchKernelGGL(k_zero_rowcol, dim3((unsigned)cdiv(planes * (Hin + Win), 256)), dim3(256), 0, st, gx, planes, Hin, Win,

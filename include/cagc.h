@@ -273,6 +273,19 @@ int cagc_torgb_bwd_finish(float* gw, float* gs, const float* gws, const float* s
                           float scale, cagc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * 1x1 convolution as a per-image GEMM  replaces F.conv2d(k = 1) of the discriminator ResBlock's skip branch (model.py:724-737:
+ *                                   Blur -> EqualConv2d(1x1, stride 2, no bias), then (conv2 + skip) / sqrt 2) on the decimated
+ *                                   blur, and its data gradient.  All fp32, NCHW (P = pixels per image, P % 4 == 0):
+ *   out[b] [M,P] = alpha * A [M,K] @ x[b] [K,P]  (+ beta * residual[b] [M,P]  [nullable]; residual may not alias out)
+ * cagc_gemm1x1_pack: w [M,K] (transpose = 0) or [K,M] (transpose = 1: the data gradient's A = W^T from the same weight tensor)
+ *   times `scale` -> MFMA A-operand order, both workgroup shapes back to back (opaque; cagc_gemm1x1_packed_elems floats).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t cagc_gemm1x1_packed_elems(int M, int K);
+int cagc_gemm1x1_pack(float* ap, const float* w, int M, int K, float scale, int transpose, cagc_stream_t stream);
+int cagc_gemm1x1(float* out, const float* x, const float* ap, const float* residual, int B, int K, int M, int64_t P,
+                 float alpha, float beta, cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * EqualLinear on few rows           replaces model.py:137-166 (F.linear + fused_bias_act, op/fused_act.py) for the generator's
  *                                   mapping network (model.py:421-430) and the discriminator's final linears (:773-776):
  *   y [R,O] = x [R,D] @ (W [O,D] * scale)^T + b [O] * lr_mul,   act != 0: y = lrelu(y, alpha) * act_scale          ONE launch

@@ -22,8 +22,15 @@ for cin, cout, H in [(128, 256, 128), (256, 512, 64), (512, 512, 32), (512, 512,
     xv, gv = x.view(B, cin, H * H), g.view(B, cout, H * H)
     o2 = torch.empty(B, cout, H * H, device="cuda"); gx2 = torch.empty(B, cin, H * H, device="cuda")
     t_fb = bench(lambda: torch.matmul(w2, xv, out=o2))
+    torch.matmul(w2, xv, out=o2)
     t_db = bench(lambda: torch.matmul(w2t, gv, out=gx2))
+    ap_f, ap_b = mc.pack_gemm1x1(w.view(cout, cin), 0.1, False), mc.pack_gemm1x1(w.view(cout, cin), 0.1, True)
+    o3 = torch.empty(B, cout, H * H, device="cuda"); gx3 = torch.empty(B, cin, H * H, device="cuda")
+    t_f1 = bench(lambda: _lib.call("cagc_gemm1x1", _lib.ptr(o3), _lib.ptr(x), _lib.ptr(ap_f), None, B, cin, cout, H * H, 1.0, 0.0))
+    t_d1 = bench(lambda: _lib.call("cagc_gemm1x1", _lib.ptr(gx3), _lib.ptr(g), _lib.ptr(ap_b), None, B, cout, cin, H * H, 1.0, 0.0))
     fl = 2.0 * B * cin * cout * H * H
+    e1 = (o3 - o2).abs().max().item() / o2.abs().max().item()
+    print(f"{cin:3d}->{cout:3d} @{H:3d}^2 B{B}: cagc_gemm1x1 fwd {t_f1*1e6:7.1f} us ({fl/t_f1/1e12:5.1f} TF)  dgrad {t_d1*1e6:7.1f} us ({fl/t_d1/1e12:5.1f} TF)  rel diff vs rocBLAS {e1:.1e}")
     err = (o2.view_as(out) - out).abs().max().item() / out.abs().max().item()
     print(f"{cin:3d}->{cout:3d} @{H:3d}^2 B{B}: fwd cagc {t_f*1e6:7.1f} us ({fl/t_f/1e12:5.1f} TF)  rocBLAS {t_fb*1e6:7.1f} us ({fl/t_fb/1e12:5.1f} TF) | "
           f"dgrad cagc {t_d*1e6:7.1f} us ({fl/t_d/1e12:5.1f} TF)  rocBLAS {t_db*1e6:7.1f} us ({fl/t_db/1e12:5.1f} TF)  rel diff {err:.1e}")
