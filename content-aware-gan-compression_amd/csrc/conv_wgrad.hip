@@ -597,16 +597,12 @@ static bool wgrad2_pf_ok(const Wg2Args& a, int mb, int nb) {
   // (small accumulator sets: 77->39 up-conv on plan {3,1}: 587 -> 433 us), or the plain kernel is at one wave anyway
   const int acc = ((9 * nb + 3) / 4) * mb * 4;
   const bool plain_two = acc <= 110, pf_two = acc + (4 * mb + 4 * nb) * 4 + 110 <= 256;
-  return (pf_two || !plain_two) && cdiv(mb * 16, cpa) <= 4 * mb && cdiv(nb * 16, cpb) <= 4 * nb &&
-         getenv("CAGC_WGRAD_NOPF") == nullptr;
+  return (pf_two || !plain_two) && cdiv(mb * 16, cpa) <= 4 * mb && cdiv(nb * 16, cpb) <= 4 * nb;
 }
 
 struct Wg2Plan { int mb, nb; };
 static Wg2Plan wg2_plan(int Cout, int Cin, int up = 0) {
-  if (up) {   // tuning: CAGC_WGRAD_PLAN_UP="mb,nb" forces the transposed-conv mode's tile plan
-    static const char* e = getenv("CAGC_WGRAD_PLAN_UP");
-    if (e && e[0] && e[1] == ',' && e[2]) return Wg2Plan{e[0] - '0', e[2] - '0'};
-  }
+  (void)up;
   // least padded work first; among equals prefer a plan that runs 2 waves / SIMD (<= 110 accumulator registers), then
   // the larger tile
   // {4,2} / {4,4}: the discriminator's channel counts (multiples of 64: 128 .. 512) — a 64-channel M tile halves the
@@ -615,9 +611,7 @@ static Wg2Plan wg2_plan(int Cout, int Cin, int up = 0) {
   auto occ2 = [](const Wg2Plan& c) { return ((9 * c.nb + 3) / 4) * c.mb * 4 <= 110; };
   Wg2Plan best = cands[0];
   long best_cost = -1;
-  static const bool no4 = getenv("CAGC_WGRAD_NO4") != nullptr;   // A/B switch for the 64-channel plans
   for (const Wg2Plan& c : cands) {
-    if (no4 && c.mb == 4) continue;
     const long cost = (long)cdiv(Cout, 16 * c.mb) * c.mb * cdiv(Cin, 16 * c.nb) * c.nb;
     bool better = best_cost < 0 || cost < best_cost;
     if (!better && cost == best_cost) {
@@ -629,14 +623,8 @@ static Wg2Plan wg2_plan(int Cout, int Cin, int up = 0) {
   return best;
 }
 
-// Transposed-conv mode by planes (CAGC_WGRAD_UP_PLANES=1; MEASURED NEGATIVE, off by default): the four phase planes of the
-// gradient as FOUR launches, each a plain-mode weight gradient of its own taps (plane (ky&1, kx&1): 4 / 2 / 2 / 1 taps) on one
-// staged plane — a quarter of the A tile in LDS, so 128 K-pixels per staged tile instead of 64.  The launches write disjoint
-// tap slabs of one workspace; one reduce.  Results identical, but 154->77 @64^2 328 -> 437 us, 77->39 @128^2 389 -> 772 us, the
-// discriminator's stride-2 weight gradient 3.5 -> 4.7 ms: the B operand is staged four times and the 1- / 2-tap planes leave
-// waves without a (tap, block) pair.
-static bool wgrad_up_by_planes() { static const bool v = getenv("CAGC_WGRAD_UP_PLANES") && atoi(getenv("CAGC_WGRAD_UP_PLANES")) == 1; return v; }
-
+// (The transposed-conv mode as four per-plane launches — a quarter of the A tile staged, 128 K-pixels per tile — was measured slower:
+// 154->77 @64^2 328 -> 437 us, D's stride-2 weight gradient 3.5 -> 4.7 ms: B staged four times, idle waves on the 1- / 2-tap planes.)
 static void wgrad2_geometry(Wg2Args& a, Wg2Plan pl, int B, int Cin, int Cout, int H, int W, int ksize, int up, int plane = -1) {
   const bool by_plane = up && plane >= 0;
   memset(&a, 0, sizeof(a));
@@ -657,7 +645,7 @@ static void wgrad2_geometry(Wg2Args& a, Wg2Plan pl, int B, int Cin, int Cout, in
     }
   }
   a.TW = tw;
-  static const int up_pix = getenv("CAGC_WGRAD_UP_PIX") ? atoi(getenv("CAGC_WGRAD_UP_PIX")) : 64;   // tuning: K pixels per staged tile, up mode
+  constexpr int up_pix = 64;   // K pixels per staged tile, up mode (128 / 192 measured slower except at 16^2: the four gradient planes cost LDS)
   a.TH = ((up && !by_plane) ? up_pix : 128) / tw;
   if (a.TH > 16) a.TH = 16;
   if (a.TH < 1) a.TH = 1;
@@ -734,7 +722,7 @@ static int launch_wgrad2(Wg2Args& a, hipStream_t st, const char* what) {
     hipLaunchKernelGGL((k_wgrad2_pf<MB, NB>), grid, dim3(256), smem, st, a);
   } else {
     const int PA = a.NPA * a.TH * (a.TW / 4), PB = a.BH * a.QB;
-    if (PA <= 256 && PB <= 256 && getenv("CAGC_WGRAD_NOAFF") == nullptr) {
+    if (PA <= 256 && PB <= 256) {
       static bool attr_af[64] = {};
       if (dev >= 0 && dev < 64 && !attr_af[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad2<MB, NB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -810,7 +798,7 @@ extern "C" int64_t cagc_modconv_wgrad_workspace(int B, int Cin, int Cout, int H,
   int64_t n = (int64_t)a.nsplit * a.ntaps * a.Mp32 * a.Np32;
   if (ksize == 3 && W % 4 == 0) {   // the caller's pointers decide v1/v2 at launch: size for the larger
     Wg2Args b;
-    wgrad2_geometry(b, wg2_plan(Cout, Cin, up), B, Cin, Cout, H, W, ksize, up, (up && wgrad_up_by_planes()) ? 0 : -1);
+    wgrad2_geometry(b, wg2_plan(Cout, Cin, up), B, Cin, Cout, H, W, ksize, up);
     const int64_t n2 = (int64_t)b.nsplit * b.ntaps * b.Mp * b.Np;
     if (n2 > n) n = n2;
   }
@@ -854,10 +842,9 @@ extern "C" int cagc_modconv_wgrad_demod(float* gweight, float* workspace, const 
     Wg2Args b;
     int rc2 = 0;
     const int key = pl.mb * 10 + pl.nb;
-    const bool planes = up && wgrad_up_by_planes();
-    for (int plane = planes ? 0 : -1; plane < (planes ? 4 : 0) && !rc2; ++plane) {
-      wgrad2_geometry(b, pl, B, Cin, Cout, H, W, ksize, up, plane);
-      b.ga = g + (plane > 0 ? (int64_t)plane * b.AHg * b.APitch : 0);     // plane p of [B][Cout][4][Hk][pitch]
+    {
+      wgrad2_geometry(b, pl, B, Cin, Cout, H, W, ksize, up);
+      b.ga = g;
       b.x = x; b.s = s; b.ws = workspace;
       if (key == 11) rc2 = launch_wgrad2<1, 1>(b, st2, what);
       else if (key == 22) rc2 = launch_wgrad2<2, 2>(b, st2, what);

@@ -242,7 +242,6 @@ bool wgrad_rd_plan(WgrPlan& P, int B, int Cin, int Cout, int H, int W, int ksize
     P.mb = 1;
     P.nb = (nblk % 4 == 0 && nblk >= 8) ? 4 : (nblk == 1 ? 1 : 2);
   }
-  { static const char* e = getenv("CAGC_WGRAD_RD_PLAN"); if (e && e[0] && e[1] == ',' && e[2]) { P.mb = e[0] - '0'; P.nb = e[2] - '0'; } }
   if (ksize == 1) { if (!((P.mb == 1 || P.mb == 2 || P.mb == 4) && (P.nb == 1 || P.nb == 2 || P.nb == 4))) return false; }
   else if (P.mb < 1 || P.mb > 4 || P.nb < 1 || P.nb > 4 || P.nb == 3 || P.mb * P.nb > 8 || (P.mb == 4 && P.nb == 2) || (!up && P.nb == 4)) return false;
   P.ntaps = ntaps;

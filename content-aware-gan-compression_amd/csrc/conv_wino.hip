@@ -467,7 +467,6 @@ __global__ __launch_bounds__(256) void k_wino_pack(float* __restrict__ up, const
 // CUs idle (small per-GPU batch / 32x32 layers: 8 pixel tiles x 8 channel tiles = 64 workgroups).  Fewer blocks per
 // workgroup = more workgroups; each repeats the input transform, which otherwise idle CUs do for free.
 static int wino_run_mb(int pmb, int M, int nblocks) {
-  if (getenv("CAGC_WINO_NO_SPLIT")) return pmb;
   auto wgs = [&](int b) { return (int64_t)nblocks * cdiv(M, b * 16); };
   int mb = pmb;
   if (pmb == 4 && wgs(4) < 200) mb = 2;
@@ -489,7 +488,7 @@ static int launch_wino_nh(WinoArgs& a, hipStream_t st, const char* what) {
     attr[dev] = true;
   }
   a.mtiles = cdiv(a.Cout, NH == 3 ? 2 * MT : MT);
-  { static const int wm = getenv("CAGC_WINO_MAP") ? atoi(getenv("CAGC_WINO_MAP")) : 1; a.wg_map = wm; }
+  a.wg_map = 1;        // XCD-contiguous channel tiles (round 2: -17 % HBM / MALL traffic against the linear order)
   CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
   hipLaunchKernelGGL((k_wino<MB, GATED, SUB, NH>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(wino_threads(NH)), smem, st, a);
   return check_launch(what);

@@ -122,11 +122,7 @@ inline bool wino_f4_enabled() {
   static const int v = getenv("CAGC_WINO_F4") ? atoi(getenv("CAGC_WINO_F4")) : 1;
   return v != 0;
 }
-inline bool wino_f4_ragged() {      // CAGC_WINO_F4_RAGGED=0: only layers whose M is a multiple of 128 (A/B switch)
-  static const int v = getenv("CAGC_WINO_F4_RAGGED") ? atoi(getenv("CAGC_WINO_F4_RAGGED")) : 1;
-  return v != 0;
-}
-inline bool wino_use_f4(int K, int M) { return wino_f4_enabled() && M >= 128 && K >= 128 && (M % 128 == 0 || wino_f4_ragged()); }
+inline bool wino_use_f4(int K, int M) { return wino_f4_enabled() && M >= 128 && K >= 128; }
 inline int wino4_kp(int K) { return round_up(K, 16); }     // two chunks of 8 per main-loop iteration
 inline int64_t wino4_packed_elems(int K, int M) { return (int64_t)cdiv(M, 64) * 36 * wino4_kp(K) * 64; }   // 64-channel tiles, zero-padded
 // An F(4x4)-eligible layer carries BOTH packings back to back, [F(4x4) | F(2x2)]: the kernel is chosen per LAUNCH (run-time batch

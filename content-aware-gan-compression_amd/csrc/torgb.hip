@@ -253,7 +253,7 @@ extern "C" int cagc_torgb_fwd(float* out, const float* x, const float* w, const 
   CAGC_REQUIRE(3 * C * sizeof(float) <= 48 * 1024, "%s: C too large", what);
   const int64_t HW = (int64_t)H * W;
   const int nstrip = cdiv(HW, RGB_PIX);
-  if (HW % 4 == 0 && (int64_t)B * nstrip < 512 && ((uintptr_t)x % 16) == 0 && getenv("CAGC_TORGB_NOSPLIT") == nullptr) {
+  if (HW % 4 == 0 && (int64_t)B * nstrip < 512 && ((uintptr_t)x % 16) == 0) {
     // under-filled: 256-pixel workgroups, channels split over wavefronts (and spare lanes for images under 256 pixels)
     const int quads = (int)(HW / 4 < 64 ? HW / 4 : 64);
     int NQ = 1;
