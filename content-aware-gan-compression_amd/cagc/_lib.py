@@ -70,7 +70,7 @@ _PROTOS = {
     "cagc_modconv_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "cagc_modconv_wgrad_demod": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "cagc_styled_bwd_finish": [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
-    "cagc_torgb_bwd_finish": [_p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "cagc_torgb_bwd_finish": [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "cagc_wino_eligible": [_i, _i],
     "cagc_wino_plan": [_i, _i, _i, _i, _i],
     "cagc_wino_packed_elems": [_i, _i],
@@ -79,6 +79,7 @@ _PROTOS = {
     "cagc_wino_conv3x3_act_dgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p],
     "cagc_fir4x4_pitched": [_p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "cagc_conv3x3s2_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "cagc_conv3x3s2_act_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p],
     "cagc_conv3x3s2_dgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "cagc_torgb_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "cagc_torgb_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],

@@ -718,13 +718,12 @@ class _ResBlockFrozen(Function):
             ho, wo = (hb - 3) // 2 + 1, (wb - 3) // 2 + 1
             tmp = torch.empty(B, C, hb, pitch, dtype=x.dtype, device=dev)
             _lib.call("cagc_fir4x4_pitched", _lib.ptr(tmp), _lib.ptr(y1), _lib.ptr(fir2), B * C, H, W, W, hb, wb, pitch, pad2[0], pad2[0])
-            y2 = torch.empty(B, cout, ho, wo, dtype=x.dtype, device=dev)
-            _lib.call("cagc_conv3x3s2_fwd", _lib.ptr(y2), _lib.ptr(tmp), _lib.ptr(wp2_fwd), B, C, cout, hb, wb, pitch)
+            y2a = torch.empty(B, cout, ho, wo, dtype=x.dtype, device=dev)
+            # bias + LeakyReLU in the stride-2 conv's MFMA epilogue (same-box A/B at batch 16: 3.51 ms per step either way — the
+            # epilogue's extra work equals the saved streaming pass; kept for the four fewer launches and one fewer tensor)
+            _lib.call("cagc_conv3x3s2_act_fwd", _lib.ptr(y2a), _lib.ptr(tmp), _lib.ptr(wp2_fwd), _lib.ptr(b2.detach().contiguous()), B, C, cout,
+                      hb, wb, pitch, 0.2, SQRT2)
             del tmp
-            y2a = torch.empty_like(y2)
-            _lib.call("cagc_fused_bias_act_fwd", _lib.ptr(y2a), _lib.ptr(y2), _lib.ptr(b2.detach().contiguous()), B, cout, ho * wo,
-                      0.2, SQRT2)
-            del y2
             ys = _launch(x, firsk, (1, 1), (2, 2), (padsk[0], padsk[1], padsk[0], padsk[1]), (ho, wo))
             # skip 1x1 conv + residual merge as ONE per-image GEMM with an (alpha, beta) epilogue (csrc/conv1x1.hip):
             #   out[b] = (1/sqrt2) * (W_skip @ ys[b]) + (1/sqrt2) * y2a[b]          (wpsk_fwd = packed scale * W_skip)
@@ -991,15 +990,14 @@ class _ToRGB(Function):
         g = gout.contiguous()
         scale = 1.0 / math.sqrt(C)
         gx = torch.empty_like(x)
-        gws = torch.empty(B, 3, C, dtype=x.dtype, device=x.device)
+        gws = torch.empty(B * 3 * (C + 1), dtype=x.dtype, device=x.device)     # [B,3,C] weight sums + [B,3] sums of g (bias gradient)
+        gweight = torch.empty(1, 3, C, 1, 1, dtype=x.dtype, device=x.device)
+        gs = torch.empty(B, C, dtype=x.dtype, device=x.device)
+        gbias = torch.empty(1, 3, 1, 1, dtype=x.dtype, device=x.device)
         with _lib.on_device(x):
             _lib.call("cagc_torgb_bwd", _lib.ptr(gx), _lib.ptr(gws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(w2), _lib.ptr(s), B, C,
                       H, W, scale)
-        gweight = torch.empty(1, 3, C, 1, 1, dtype=x.dtype, device=x.device)
-        gs = torch.empty(B, C, dtype=x.dtype, device=x.device)
-        with _lib.on_device(x):
-            _lib.call("cagc_torgb_bwd_finish", _lib.ptr(gweight), _lib.ptr(gs), _lib.ptr(gws), _lib.ptr(s), _lib.ptr(w2), B, C, scale)
-        gbias = g.sum([0, 2, 3]).reshape(1, 3, 1, 1)
+            _lib.call("cagc_torgb_bwd_finish", _lib.ptr(gweight), _lib.ptr(gs), _lib.ptr(gbias), _lib.ptr(gws), _lib.ptr(s), _lib.ptr(w2), B, C, scale)
         gskip = None
         if ctx.has_skip:
             # adjoint of upfirdn2d(up=2, pad=(2,1)): flipped FIR, down=2, pad=(1,1)  (reference op/upfirdn2d.py:111-116)

@@ -900,9 +900,8 @@ extern "C" int cagc_modconv_up_dgrad(float* gx, float* gs, const float* gt, cons
 // produces it), out [B,Cout,Ho,Wo].  The data gradient is the stride-2 transposed conv evaluated by output
 // parity (same decomposition as cagc_modconv_up_fwd) and written straight into the strided positions of gx.
 // -------------------------------------------------------------------------------------------------
-extern "C" int cagc_conv3x3s2_fwd(float* out, const float* x, const float* wp, int B, int Cin, int Cout, int Hin, int Win,
-                                  int in_pitch, cagc_stream_t stream) {
-  const char* what = "cagc_conv3x3s2_fwd";
+static int conv3x3s2_fwd_impl(float* out, const float* x, const float* wp, const float* bias, int B, int Cin, int Cout, int Hin, int Win,
+                             int in_pitch, float alpha, float act_scale, cagc_stream_t stream, const char* what) {
   CAGC_REQUIRE(out && x && wp, "%s: null tensor", what);
   CAGC_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin >= 3 && Win >= 3 && (Hin & 1) && (Win & 1) && in_pitch >= Win,
                "%s: bad shape", what);
@@ -916,7 +915,17 @@ extern "C" int cagc_conv3x3s2_fwd(float* out, const float* x, const float* wp, i
   for (int ky = 0; ky < 3; ++ky)
     for (int kx = 0; kx < 3; ++kx) taps[n++] = RawTap{0, ky, kx, ky * 3 + kx};
   RawItem it{n, taps, 0, 0, 0, Ho, Wo};
+  if (bias) { a.epi = CAGC_EPI_STYLED; a.bias = bias; a.alpha = alpha; a.act_scale = act_scale; }   // + bias, LeakyReLU in the MFMA epilogue
   return run_conv(a, &it, 1, as_stream(stream), what);
+}
+extern "C" int cagc_conv3x3s2_fwd(float* out, const float* x, const float* wp, int B, int Cin, int Cout, int Hin, int Win,
+                                  int in_pitch, cagc_stream_t stream) {
+  return conv3x3s2_fwd_impl(out, x, wp, nullptr, B, Cin, Cout, Hin, Win, in_pitch, 0.2f, 1.f, stream, "cagc_conv3x3s2_fwd");
+}
+extern "C" int cagc_conv3x3s2_act_fwd(float* out, const float* x, const float* wp, const float* bias, int B, int Cin, int Cout, int Hin,
+                                      int Win, int in_pitch, float alpha, float act_scale, cagc_stream_t stream) {
+  CAGC_REQUIRE(bias, "cagc_conv3x3s2_act_fwd: null bias");
+  return conv3x3s2_fwd_impl(out, x, wp, bias, B, Cin, Cout, Hin, Win, in_pitch, alpha, act_scale, stream, "cagc_conv3x3s2_act_fwd");
 }
 
 extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_bwd, int B, int Cin, int Cout, int Hin,

@@ -578,10 +578,15 @@ __global__ __launch_bounds__(256) void k_styled_bwd_finish(float* __restrict__ g
   }
 }
 // ToRGB backward tail: gws [B,3,C] (cagc_torgb_bwd) -> gw[o,c] = scale sum_b s[b,c] gws[b,o,c];  gs[b,c] = scale sum_o w[o,c] gws[b,o,c]
-__global__ __launch_bounds__(256) void k_torgb_bwd_finish(float* __restrict__ gw, float* __restrict__ gs, const float* __restrict__ gws,
-                                                          const float* __restrict__ s, const float* __restrict__ w, int B, int C,
-                                                          float scale) {
+__global__ __launch_bounds__(256) void k_torgb_bwd_finish(float* __restrict__ gw, float* __restrict__ gs, float* __restrict__ gbias,
+                                                          const float* __restrict__ gws, const float* __restrict__ s,
+                                                          const float* __restrict__ w, int B, int C, float scale) {
   const int tid = threadIdx.x;
+  if (gbias && tid < 3) {      // bias gradient: sum over images of the per-image sums of g that cagc_torgb_bwd left behind gws [B,3,C]
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += gws[(int64_t)B * 3 * C + b * 3 + tid];
+    gbias[tid] = a;
+  }
   for (int idx = tid; idx < 3 * C; idx += 256) {
     const int o = idx / C, c = idx - o * C;
     float a = 0.f;
@@ -605,9 +610,9 @@ extern "C" int cagc_styled_bwd_finish(float* gbias, float* gnw, float* gd, float
                      red, bias, noise_w, d, B, C, has_noise);
   return cagc::check_launch("cagc_styled_bwd_finish");
 }
-extern "C" int cagc_torgb_bwd_finish(float* gw, float* gs, const float* gws, const float* s, const float* w, int B, int C,
+extern "C" int cagc_torgb_bwd_finish(float* gw, float* gs, float* gbias, const float* gws, const float* s, const float* w, int B, int C,
                                      float scale, cagc_stream_t stream) {
   CAGC_REQUIRE(gw && gs && gws && s && w && B > 0 && C > 0, "cagc_torgb_bwd_finish: bad argument");
-  hipLaunchKernelGGL(cagc::k_torgb_bwd_finish, dim3(1), dim3(256), 0, cagc::as_stream(stream), gw, gs, gws, s, w, B, C, scale);
+  hipLaunchKernelGGL(cagc::k_torgb_bwd_finish, dim3(1), dim3(256), 0, cagc::as_stream(stream), gw, gs, gbias, gws, s, w, B, C, scale);
   return cagc::check_launch("cagc_torgb_bwd_finish");
 }

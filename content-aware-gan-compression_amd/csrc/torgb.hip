@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void k_torgb_bwd(float* __restrict__ gx, float
                                                    const float* __restrict__ w, const float* __restrict__ s, int C,
                                                    int64_t HW, int nchunk, int nsplit, float scale, const DetSink det) {
   __shared__ float red[4][3 * RGB_CCH];
+  __shared__ float redg[4][3];
   int bid = blockIdx.x;
   const int sp = bid % nsplit; bid /= nsplit;
   const int ch = bid % nchunk;
@@ -206,8 +207,10 @@ __global__ __launch_bounds__(256) void k_torgb_bwd(float* __restrict__ gx, float
 #pragma unroll
   for (int k = 0; k < RGB_CCH; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
   const float* gb = g + (int64_t)b * 3 * HW;
+  float sg0 = 0.f, sg1 = 0.f, sg2 = 0.f;       // sum of g over this block's pixels: the bias gradient (first channel chunk only)
   for (int64_t p = (int64_t)sp * 256 + threadIdx.x; p < HW; p += (int64_t)nsplit * 256) {
     const float g0 = gb[p], g1 = gb[HW + p], g2 = gb[2 * HW + p];
+    if (ch == 0) { sg0 += g0; sg1 += g1; sg2 += g2; }
 #pragma unroll
     for (int k = 0; k < RGB_CCH; ++k) {
       const int c = c0 + k;
@@ -227,7 +230,17 @@ __global__ __launch_bounds__(256) void k_torgb_bwd(float* __restrict__ gx, float
       const float v = wave_sum(acc[k][o]);
       if (lane == 0) red[wave][k * 3 + o] = v;
     }
+  if (ch == 0) {
+    sg0 = wave_sum(sg0); sg1 = wave_sum(sg1); sg2 = wave_sum(sg2);
+    if (lane == 0) { redg[wave][0] = sg0; redg[wave][1] = sg1; redg[wave][2] = sg2; }
+  }
   __syncthreads();
+  if (ch == 0 && threadIdx.x < 3) {       // gws[B*3*C + b*3 + o]: per-image sums of g, finished into gbias by cagc_torgb_bwd_finish
+    const float v = (redg[0][threadIdx.x] + redg[1][threadIdx.x]) + (redg[2][threadIdx.x] + redg[3][threadIdx.x]);
+    float* dst = gws + (int64_t)gridDim.x / (nchunk * nsplit) * 3 * C + b * 3 + threadIdx.x;
+    if (nsplit == 1) *dst = v;
+    else sink_add(det, dst, v);
+  }
   if (threadIdx.x < 3 * RGB_CCH) {
     const int k = threadIdx.x / 3, o = threadIdx.x % 3;
     const int c = c0 + k;
@@ -283,13 +296,14 @@ extern "C" int cagc_torgb_bwd(float* gx, float* gws, const float* g, const float
   const int maxsplit = cdiv(HW, 1024);
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
-  if (nsplit > 1) { int zrc = zero_fill(gws, sizeof(float) * (size_t)B * 3 * C, st); if (zrc) return zrc; }
+  const int64_t ngws = (int64_t)B * 3 * (C + 1);      // [B,3,C] weight sums + [B,3] sums of g (bias gradient)
+  if (nsplit > 1) { int zrc = zero_fill(gws, sizeof(float) * (size_t)ngws, st); if (zrc) return zrc; }
   DetSink det;
-  { const int drc = det_begin(det, nsplit > 1 ? gws : nullptr, (int64_t)B * 3 * C, st, what); if (drc) return drc; }
+  { const int drc = det_begin(det, nsplit > 1 ? gws : nullptr, ngws, st, what); if (drc) return drc; }
   hipLaunchKernelGGL(k_torgb_bwd, dim3((unsigned)(B * nchunk * nsplit)), dim3(256), 0, st, gx, gws, g, x, w, s, C, HW,
                      nchunk, nsplit, scale, det);
   { const int drc = check_launch(what); if (drc) return drc; }
-  return det_end(det, gws, (int64_t)B * 3 * C, st, what);
+  return det_end(det, gws, ngws, st, what);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

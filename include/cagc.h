@@ -268,8 +268,9 @@ int cagc_modconv_wgrad_demod(float* gweight, float* workspace, const float* g, c
 int cagc_styled_bwd_finish(float* gbias, float* gnw, float* gd, float* zero_ptr, int zero_n, const float* red,
                            const float* bias, const float* noise_w, const float* d, int B, int C, int has_noise,
                            cagc_stream_t stream);
-/* Tail of ToRGB's backward from gws [B,3,C] (cagc_torgb_bwd): gw [3,C] = scale sum_b s*gws, gs [B,C] = scale sum_o w*gws. */
-int cagc_torgb_bwd_finish(float* gw, float* gs, const float* gws, const float* s, const float* w, int B, int C,
+/* Tail of ToRGB's backward from gws [B,3,C] + [B,3] (cagc_torgb_bwd): gw [3,C] = scale sum_b s*gws, gs [B,C] = scale sum_o w*gws,
+ * gbias [3] = sum_b (per-image sums of g) [nullable]. */
+int cagc_torgb_bwd_finish(float* gw, float* gs, float* gbias, const float* gws, const float* s, const float* w, int B, int C,
                           float scale, cagc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -382,6 +383,10 @@ int cagc_fir4x4_pitched(float* out, const float* x, const float* kernel, int64_t
                         cagc_stream_t stream);
 int cagc_conv3x3s2_fwd(float* out, const float* x, const float* wp, int B, int Cin, int Cout, int Hin, int Win,
                        int in_pitch, cagc_stream_t stream);
+/* The same with the ConvLayer's FusedLeakyReLU (model.py:707-716) in the MFMA epilogue: out = lrelu(conv + bias[o], alpha) * act_scale —
+ * the discriminator's `Blur -> 3x3 stride 2 -> FusedLeakyReLU` without the separate bias / activation pass. */
+int cagc_conv3x3s2_act_fwd(float* out, const float* x, const float* wp, const float* bias, int B, int Cin, int Cout, int Hin, int Win,
+                           int in_pitch, float alpha, float act_scale, cagc_stream_t stream);
 int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_bwd, int B, int Cin, int Cout, int Hin,
                          int Win, int out_pitch, cagc_stream_t stream);
 
@@ -390,9 +395,9 @@ int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_bwd, int B, 
  *                                   Upsample(skip) = upfirdn2d(up=2, pad=(2,1), 4x4 FIR x4)).
  * x [B,C,H,W], w [3,C] (= conv.weight[0,:,:,0,0]), s [B,C], bias [3], skip [B,3,H/2,W/2] [nullable],
  * fir [4,4] [nullable iff skip null] -> out [B,3,H,W].  HBM-bound: x is read exactly once.
- * backward: gx [B,C,H,W] = s[b,c]*scale*sum_o w[o,c] g[b,o];   gws [B,3,C] = sum_p g[b,o,p] x[b,c,p]
- *           (from which gw = scale*sum_b s*gws, gs = scale*sum_o w*gws);  the skip gradient is
- *           cagc_upfirdn2d(down=2) on g, the bias gradient a plain sum — both on the caller's side.
+ * backward: gx [B,C,H,W] = s[b,c]*scale*sum_o w[o,c] g[b,o];   gws = [B,3,C] sums sum_p g[b,o,p] x[b,c,p] followed by [B,3] sums
+ *           sum_p g[b,o,p] — B*3*(C+1) floats — from which cagc_torgb_bwd_finish makes gw = scale*sum_b s*gws, gs = scale*sum_o w*gws
+ *           and the bias gradient;  the skip gradient is cagc_upfirdn2d(down=2) on g, on the caller's side.
  * ---------------------------------------------------------------------------------------------- */
 int cagc_torgb_fwd(float* out, const float* x, const float* w, const float* s, const float* bias,
                    const float* skip, const float* fir, int B, int C, int H, int W, float scale,

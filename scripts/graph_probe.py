@@ -36,7 +36,9 @@ def timed_replay(g, n=30):
     return host, e0.elapsed_time(e1) / n * 1e3
 
 
-def synthetic(N, numel, period=0, nside=1):
+def synthetic(N, numel, period=0, nside=1, deferred=False):
+    """deferred: the side stream is forked from ONCE-per-period events of the main stream (side.wait_event) but joins the main
+    stream only ONCE at the end — the shape 'all weight gradients as one side chain, one join before the optimiser' would give."""
     x = torch.zeros(numel, device=dev)
     ys = [torch.zeros(numel, device=dev) for _ in range(nside)]
     sides = [torch.cuda.Stream() for _ in range(nside)]
@@ -55,10 +57,14 @@ def synthetic(N, numel, period=0, nside=1):
                     with torch.cuda.stream(s):
                         y.add_(1.0)
                 x.add_(1.0)
-                for s in sides:
-                    main.wait_stream(s)
+                if not deferred:
+                    for s in sides:
+                        main.wait_stream(s)
             else:
                 x.add_(1.0)
+        if deferred:
+            for s in sides:
+                main.wait_stream(s)
     return timed_replay(g)
 
 
@@ -70,6 +76,10 @@ def main():
             h, d = synthetic(N, numel, period, nside)
             forks = (N // period) if period else 0
             print(f"| chain of add_({numel}) period {period} sides {nside} | {N + forks * nside} | {h:.0f} | {d:.0f} | {d / (N + forks * nside):.2f} |")
+        for N, period in ((500, 10), (500, 4)):
+            h, d = synthetic(N, numel, period, 1, deferred=True)
+            forks = N // period
+            print(f"| chain of add_({numel}) period {period}, side chain joined ONCE at the end | {N + forks} | {h:.0f} | {d:.0f} | {d / (N + forks):.2f} |")
     from cagc import kd
     from cagc.op import modconv as mc
     for bs in (2, 4):
