@@ -335,13 +335,43 @@ class GraphedKDStep(KDStep):
         else:
             self.s_noise = self.t_noise = None
         self._params = [p for p in self.student.parameters()]
-        self.flat_grad = torch.zeros(sum(p.numel() for p in self._params), device=dev)
+        n_flat = sum(p.numel() for p in self._params)
+        self.flat_grad = torch.zeros(n_flat, device=dev)
         self._grad_views, off = [], 0
         for p in self._params:
             self._grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self._flatten_optimizer(n_flat, dev)
         self.losses = None
         self._capture()
+
+    def _flatten_optimizer(self, n_flat, dev):
+        """ONE Adam launch instead of four: the student's parameters become views of one flat buffer (`p.data` re-pointed, values
+        kept), and the captured optimiser is `torch.optim.Adam` (fused, capturable — the same elementwise arithmetic) over that
+        single flat parameter with the flat gradient: multi_tensor_apply over 135 small tensors took 0.21 ms per step at every batch
+        size, the flat one ~0.04.  `self.optim` — the per-parameter optimiser every caller and the checkpoint format
+        (`optim.state_dict()`, train.py:443-452) know — stays, as a VIEW: its state tensors are slices of the flat moments and the one
+        shared step counter, so `state_dict()` / `load_optim_state` read and write what the captured graph updates."""
+        with torch.no_grad():
+            flat_p = torch.cat([p.detach().reshape(-1) for p in self._params]).contiguous()
+            off = 0
+            for p in self._params:
+                p.data = flat_p[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        M.invalidate_caches(self.student)
+        self._flat_param = torch.nn.Parameter(flat_p)
+        self._flat_param.grad = self.flat_grad
+        g0 = self.optim.param_groups[0]
+        self._flat_optim = torch.optim.Adam([self._flat_param], lr=g0["lr"], betas=tuple(g0["betas"]), eps=g0["eps"],
+                                            weight_decay=g0["weight_decay"], fused=True, capturable=True)
+        flat_m, flat_v = torch.zeros(n_flat, device=dev), torch.zeros(n_flat, device=dev)
+        step = torch.zeros((), dtype=torch.float32, device=dev)
+        self._flat_optim.state[self._flat_param] = {"step": step, "exp_avg": flat_m, "exp_avg_sq": flat_v}
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            self.optim.state[p] = {"step": step, "exp_avg": flat_m[off:off + n].view_as(p), "exp_avg_sq": flat_v[off:off + n].view_as(p)}
+            off += n
 
     def _fwd_bwd(self):
         if self.random_noise:
@@ -371,7 +401,7 @@ class GraphedKDStep(KDStep):
         with torch.cuda.stream(side):
             for _ in range(3):
                 self._fwd_bwd()
-                self.optim.step()
+                self._flat_optim.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with torch.no_grad():
@@ -391,7 +421,7 @@ class GraphedKDStep(KDStep):
             self.losses = self._fwd_bwd()
         self.graph_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_opt):
-            self.optim.step()
+            self._flat_optim.step()
 
     def replay(self, inject_index=None):
         """One step on whatever the static buffers hold.  inject_index: int in 1..n_latent-1, or None = no mixing."""
