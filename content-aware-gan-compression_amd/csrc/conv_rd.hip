@@ -413,12 +413,13 @@ static int launch_rd(const RdArgs& a, bool pad, dim3 grid, hipStream_t st, const
 // Launch-shape tunables of the register-direct kernel: defaults, overridden by the environment (read once) or by
 // cagc_set_tuning() — a test / tuning hook, not part of the data path's contract (process-wide, not synchronised).
 struct RdTuning {
-  int mode, min_wgs, force_mb, force_kw, split_on, atomic_below, split_target;
+  int mode, min_wgs, force_mb, force_kw, split_on, atomic_below, split_target, min_wgs_long;
 };
 static int env_or(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static RdTuning& rd_tuning() {
   static RdTuning t = {env_or("CAGC_RD", 1), env_or("CAGC_RD_MIN_WGS", 512), env_or("CAGC_RD_MB", 0), env_or("CAGC_RD_KW", 0),
-                       env_or("CAGC_RD_SPLIT", 1), env_or("CAGC_RD_ATOMIC_BELOW", 160), env_or("CAGC_RD_SPLIT_WGS", 320)};
+                       env_or("CAGC_RD_SPLIT", 1), env_or("CAGC_RD_ATOMIC_BELOW", 160), env_or("CAGC_RD_SPLIT_WGS", 512),
+                       env_or("CAGC_RD_MIN_WGS_LONG", 768)};
   return t;
 }
 
@@ -499,7 +500,13 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
   //   kw  waves of a workgroup that split K (workgroup tile 256 / kw pixels; partial sums meet in LDS)
   //   mb  channel blocks per workgroup: the packed tile, or a half / quarter of a power-of-two tile
   //   ks  K split ACROSS workgroups (fp32 atomics on a pre-zeroed output): only when the two above do not suffice
-  const int min_wgs = tune.min_wgs, force_mb = tune.force_mb, force_kw = tune.force_kw, split_on = tune.split_on;
+  // workgroups below which a launch takes finer tiles: 512 (two per CU) for K split over waves AND channel sub-tiles; launches with a
+  // long contraction (>= 256 channels: teacher / discriminator layers) keep splitting K over waves — never the channel tile — up to
+  // 768 workgroups (round 4 sweeps, gpurun_out/r4_sweep*.log: per-GPU batch 2 / 4 -2 % / -1 %; halving the channel tile as well cost
+  // the batch-16 step 0.9 %: twice the B-operand traffic per MFMA)
+  const int min_wgs = tune.min_wgs;
+  const int min_wgs_kw = (a.Kp >= 256 && tune.min_wgs_long > tune.min_wgs) ? tune.min_wgs_long : tune.min_wgs;
+  const int force_mb = tune.force_mb, force_kw = tune.force_kw, split_on = tune.split_on;
   auto tiles_for = [&](int kw) {
     int64_t t = 0;
     for (int p = 0; p < nitems; ++p)
@@ -521,6 +528,7 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
     else if (pow2_tile && mb > 2) mb /= 2;
     else break;
   }
+  while (wgs() < min_wgs_kw && kw < 4 && kw_ok(kw * 2) && mb <= 5) kw *= 2;
   if (force_mb && pow2_tile && T.rb % force_mb == 0) mb = force_mb;
   if (force_kw && kw_ok(force_kw) && (mb <= 5 || force_kw == 1)) kw = force_kw;
   if (mb < 3 && mb < nblk && !pow2_tile) return CAGC_RD_DECLINED;
@@ -541,7 +549,7 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
     int64_t groups = 0;
     for (int p = 0; p < nitems; ++p) groups += (int64_t)r.items[p].block_end * raw[p].ntaps * r.KQ;
     groups *= mtiles;
-    const int target = tune.split_target > 0 ? tune.split_target : 320;
+    const int target = tune.split_target > 0 ? tune.split_target : 512;
     int64_t per = groups / target;                        // groups per workgroup
     if (per < 16 * kw) per = 16 * kw;
     for (int p = 0; p < nitems; ++p) {
@@ -586,7 +594,8 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   CAGC_REQUIRE(key, "cagc_set_tuning: null key");
   cagc::RdTuning& t = cagc::rd_tuning();
   if (!strcmp(key, "rd")) t.mode = value;
-  else if (!strcmp(key, "rd_min_wgs")) t.min_wgs = value;
+  else if (!strcmp(key, "rd_min_wgs")) { t.min_wgs = value; t.min_wgs_long = value > 768 ? value : (value < 512 ? value : 768); }
+  else if (!strcmp(key, "rd_min_wgs_long")) t.min_wgs_long = value;
   else if (!strcmp(key, "rd_mb")) t.force_mb = value;
   else if (!strcmp(key, "rd_kw")) t.force_kw = value;
   else if (!strcmp(key, "rd_split")) t.split_on = value;
@@ -608,6 +617,7 @@ extern "C" int cagc_get_tuning(const char* key, int* value) {
   cagc::wgrad_rd_get_tuning(&wm, &wt);
   if (!strcmp(key, "rd")) *value = t.mode;
   else if (!strcmp(key, "rd_min_wgs")) *value = t.min_wgs;
+  else if (!strcmp(key, "rd_min_wgs_long")) *value = t.min_wgs_long;
   else if (!strcmp(key, "rd_mb")) *value = t.force_mb;
   else if (!strcmp(key, "rd_kw")) *value = t.force_kw;
   else if (!strcmp(key, "rd_split")) *value = t.split_on;

@@ -216,7 +216,7 @@ static int pick_blocks(int blocks, const int* cands, int nc) {
 
 // tunables (environment at first use, or cagc_set_tuning "wgrad_rd" / "wgrad_rd_wgs"): kernel on / off, target workgroup count
 static int& wgr_mode() { static int v = getenv("CAGC_WGRAD_RD") ? atoi(getenv("CAGC_WGRAD_RD")) : 1; return v; }
-static int& wgr_target() { static int v = getenv("CAGC_WGRAD_RD_WGS") ? atoi(getenv("CAGC_WGRAD_RD_WGS")) : 768; return v; }
+static int& wgr_target() { static int v = getenv("CAGC_WGRAD_RD_WGS") ? atoi(getenv("CAGC_WGRAD_RD_WGS")) : 384; return v; }   // 768 -> 384 in round 4 (sweep: -0.4 .. -0.8 % at every per-GPU batch)
 void wgrad_rd_set_tuning(int mode, int target_wgs) {
   if (mode >= 0) wgr_mode() = mode;
   if (target_wgs > 0) wgr_target() = target_wgs;

@@ -30,7 +30,7 @@ CONFIGS = {
     "kw1_atomics": {"rd_min_wgs": 1, "rd_kw": 1, "rd_atomic_below": 1 << 20, "rd_split_wgs": 512},
     "mb4": {"rd_min_wgs": 1, "rd_mb": 4, "rd_atomic_below": 0},
 }
-DEFAULTS = {"rd": 1, "rd_min_wgs": 512, "rd_mb": 0, "rd_kw": 0, "rd_split": 1, "rd_atomic_below": 160, "rd_split_wgs": 320}
+DEFAULTS = {"rd": 1, "rd_min_wgs": 512, "rd_mb": 0, "rd_kw": 0, "rd_split": 1, "rd_atomic_below": 160, "rd_split_wgs": 512}
 
 
 @pytest.fixture(params=list(CONFIGS))
@@ -167,7 +167,7 @@ def test_set_tuning_rejects_unknown_keys():
 # register-direct weight gradient (csrc/conv_wgrad_rd.hip)
 # ---------------------------------------------------------------------------------------------------
 WG_CONFIGS = {"default": {}, "lds_kernels": {"wgrad_rd": 0}, "few_splits": {"wgrad_rd_wgs": 8}, "many_splits": {"wgrad_rd_wgs": 100000}}
-WG_DEFAULTS = {"wgrad_rd": 1, "wgrad_rd_wgs": 768}
+WG_DEFAULTS = {"wgrad_rd": 1, "wgrad_rd_wgs": 384}
 
 
 @pytest.fixture(params=list(WG_CONFIGS))
