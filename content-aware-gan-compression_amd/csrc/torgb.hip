@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_torgb_fwd_split(float* __restrict__ out
   const int CG = 64 / NQ;                       // channel groups inside a wavefront
   const int quad = lane % NQ, cg = lane / NQ;
   const int nsub = 4 * CG, sub = wave * CG + cg;   // this lane's channel subset: sub, sub + nsub, ...
-  const int64_t p0 = (int64_t)strip * 256 + quad * 4;
+  const int64_t p0 = (int64_t)strip * (4 * NQ) + quad * 4;      // a workgroup covers 4 * NQ pixels (256, or fewer for under-filled grids)
   float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
   if (p0 < HW) {
     const float* xb = x + (int64_t)b * C * HW + p0;
@@ -267,12 +267,18 @@ extern "C" int cagc_torgb_fwd(float* out, const float* x, const float* w, const 
   const int64_t HW = (int64_t)H * W;
   const int nstrip = cdiv(HW, RGB_PIX);
   if (HW % 4 == 0 && (int64_t)B * nstrip < 512 && ((uintptr_t)x % 16) == 0) {
-    // under-filled: 256-pixel workgroups, channels split over wavefronts (and spare lanes for images under 256 pixels)
-    const int quads = (int)(HW / 4 < 64 ? HW / 4 : 64);
+    // under-filled: workgroups of 4 * NQ pixels, channels split over wavefronts and over the 64 / NQ lane groups of a wave.  NQ = 64
+    // (256 pixels) unless that leaves fewer than ~256 workgroups (teacher 512 ch @64^2 at per-GPU batch 2: 32 workgroups, each wave a
+    // serial chain of 128 channels = 16 batches of loads, 24 us) — then narrower strips down to 32 pixels, i.e. more lanes per pixel
     int NQ = 1;
-    while (NQ * 2 <= quads) NQ *= 2;            // power of two <= 64 (quads is one for every size the generator produces)
-    if (NQ == quads) {
-      const int ns = cdiv(HW, 256);
+    {
+      const int quads = (int)(HW / 4 < 64 ? HW / 4 : 64);
+      while (NQ * 2 <= quads) NQ *= 2;            // power of two <= 64
+      if (NQ != quads) NQ = 0;                    // (quads is a power of two for every size the generator produces)
+      while (NQ > 8 && (int64_t)B * cdiv(HW, 4 * NQ) < 256) NQ /= 2;
+    }
+    if (NQ) {
+      const int ns = cdiv(HW, 4 * NQ);
       const size_t smem = (3 * (size_t)C + 256 * 12) * sizeof(float);
       hipLaunchKernelGGL(k_torgb_fwd_split, dim3((unsigned)(B * ns)), dim3(256), smem, as_stream(stream), out, x, w, s, bias,
                          skip, fir, C, H, W, ns, NQ, scale);
