@@ -266,6 +266,8 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
     for (int i = 0; i < 4; ++i) acc[p][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- pipeline --------------------------------------------------------------------------------------------------------------
+  // (issuing the A ring's first loads in front of the raw tile's, so that their L2 latency runs under the first prefetch / commit /
+  // transform, was measured in round 4: +-0.5 % on all four discriminator shapes — the prologue is not load-latency bound)
   prefetch(0);
   commit(raw);
   prefetch(1);
