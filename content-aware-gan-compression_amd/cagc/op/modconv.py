@@ -101,10 +101,16 @@ def _side_stream_small(numel):
     return _SIDE_LIMIT > 0 and numel <= _SIDE_LIMIT
 
 
+_side_lock = threading.Lock()
+
+
 def _side_stream(dev):
     st = _side_streams.get(dev)
     if st is None:
-        st = _side_streams[dev] = torch.cuda.Stream(device=dev)
+        with _side_lock:      # DataParallel replicas call this from one worker thread per device
+            st = _side_streams.get(dev)
+            if st is None:
+                st = _side_streams[dev] = torch.cuda.Stream(device=dev)
     return st
 
 
@@ -303,17 +309,22 @@ class _ModConv(Function):
             # nothing else in this node depends on — then runs on a side stream next to the data gradient (fork / join become
             # graph dependencies under HIP-graph capture)
             side = None
+            if need_w:
+                # workspace and result are allocated on the MAIN stream, BEFORE the fork (the caching allocator pools memory per
+                # stream: blocks allocated under the side stream could never be reused by main-stream allocations — the slab
+                # workspace reaches GBs at 1024 px — and a block recycled from the main stream is only safe to touch behind the
+                # fork event) and handed to the side stream with record_stream
+                up = 1 if upsample else 0
+                n_ws = _lib.query("cagc_modconv_wgrad_workspace", B, cin, cout, H, W, k, up)
+                ws = torch.empty(n_ws, dtype=x.dtype, device=dev)
+                gweight = torch.empty(1, cout, cin, k, k, dtype=x.dtype, device=dev)
+                wc = weight.detach().contiguous() if gwsq is not None else None
             if need_w and (need_x or need_s) and _side_stream_small(B * max(cin, cout) * Ho * Wo):
                 main = torch.cuda.current_stream()
                 side = _side_stream(dev)
                 side.wait_stream(main)
             if need_w:
                 with (torch.cuda.stream(side) if side is not None else _nullctx()):
-                    up = 1 if upsample else 0
-                    n_ws = _lib.query("cagc_modconv_wgrad_workspace", B, cin, cout, H, W, k, up)
-                    ws = torch.empty(n_ws, dtype=x.dtype, device=dev)
-                    gweight = torch.empty(1, cout, cin, k, k, dtype=x.dtype, device=dev)
-                    wc = weight.detach().contiguous() if gwsq is not None else None
                     _lib.call("cagc_modconv_wgrad_demod", _lib.ptr(gweight), _lib.ptr(ws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(s),
                               _lib.ptr(gwsq), _lib.ptr(wc), B, cin, cout, H, W, k, up, 1.0 / math.sqrt(cin * k * k))
             if need_x or need_s:
@@ -332,8 +343,7 @@ class _ModConv(Function):
                               _lib.ptr(x), B, cin, cout, H, W, k)
             if side is not None:
                 main.wait_stream(side)
-                gweight.record_stream(main)                     # allocated on the side stream, consumed on the main one
-                for t_ in (wc, gwsq, g, x, s):                  # allocated on the main stream, read on the side stream
+                for t_ in (ws, gweight, wc, gwsq, g, x, s):     # allocated on the main stream, used on the side stream
                     if t_ is not None:
                         t_.record_stream(side)
         g_noise = None
@@ -753,12 +763,12 @@ class _ResBlockFrozen(Function):
             # side stream next to the conv branch (its workgroups fill the tails of that chain's launches) and joins in front
             # of the adjoint FIR that adds it onto gx
             side = None
+            gy = torch.empty(B, C, ho, wo, dtype=g.dtype, device=dev)      # on the main stream, before the fork (see _ModConv.backward)
             if _SIDE_LIMIT > 0 and SIDE_SKIP_GEMM:
                 main = torch.cuda.current_stream()
                 side = _side_stream(dev)
                 side.wait_stream(main)
             with (torch.cuda.stream(side) if side is not None else _nullctx()):
-                gy = torch.empty(B, C, ho, wo, dtype=g.dtype, device=dev)
                 _lib.call("cagc_gemm1x1", _lib.ptr(gy), _lib.ptr(g), _lib.ptr(wpsk_bwd), None, B, cout, C, ho * wo, 1.0, 0.0)
             # conv branch: activation backward carrying the 1/sqrt2, stride-2 data gradient, adjoint blur
             gz2 = torch.empty_like(g)
@@ -780,9 +790,8 @@ class _ResBlockFrozen(Function):
             # MFMA-bound kernel's un-overlapped epilogue for the 0.36 ms pass it saved — bench_r2_i.)
             if side is not None:
                 main.wait_stream(side)
-                gy.record_stream(main)       # allocated on the side stream, consumed on the main one
-                g.record_stream(side)
-                wpsk_bwd.record_stream(side)
+                for t_ in (gy, g, wpsk_bwd):  # allocated on the main stream, used on the side stream
+                    t_.record_stream(side)
             gp = (4 - padsk[0] - 1, W - 2 * wo + padsk[0], 4 - padsk[0] - 1, H - 2 * ho + padsk[0])
             if gp == (2, 1, 2, 1) and W % 4 == 0:
                 _lib.call("cagc_fir4x4_up2_acc", _lib.ptr(gx), _lib.ptr(gy), _lib.ptr(_flipped_scaled(firsk, scale)), _lib.ptr(gx),

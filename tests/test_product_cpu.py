@@ -129,3 +129,28 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/cagc.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     assert _lib.load().cagc_arch() == b"gfx950"
+
+
+def test_tuning_getters_and_wino_plan_are_host_side():
+    """cagc_get_tuning / cagc_set_tuning round-trip and the library's own per-launch Winograd decision (cagc_wino_plan) need no GPU:
+    bench.py attributes executed FLOPs with the latter instead of re-deriving the policy (advisor r3)."""
+    from cagc import _lib
+    lib = _lib.load()
+    for key in ("rd", "rd_min_wgs", "rd_min_wgs_long", "rd_mb", "rd_kw", "rd_split", "rd_atomic_below", "rd_split_wgs", "deterministic", "wgrad_rd",
+                "wgrad_rd_wgs", "wino4_hv", "wino4_min_wgs"):
+        v = _lib.get_tuning(key)
+        assert _lib.set_tuning(key, v) == v and _lib.get_tuning(key) == v
+    import ctypes
+    out = ctypes.c_int(0)
+    assert lib.cagc_get_tuning(b"no_such_knob", ctypes.byref(out)) != 0 and b"unknown key" in lib.cagc_last_error()
+    with _lib.tuning(wino4_min_wgs=256):
+        f4 = _lib.query("cagc_wino_plan", 16, 512, 512, 64, 64)
+        assert f4 in (2, 4)                                     # 2 under CAGC_WINO_F4=0
+        assert _lib.query("cagc_wino_plan", 16, 512, 512, 60, 64) == 0            # H % 8 != 0: not Winograd-sized
+        assert _lib.query("cagc_wino_plan", 16, 77, 77, 128, 128) == 2            # K, M < 128: F(2x2)
+        if f4 == 4:
+            assert _lib.query("cagc_wino_plan", 2, 512, 512, 32, 32) == 2         # 2 * 4 * 1 * 8 = 64 workgroups < 256: the layer's F(2x2) packing
+            with _lib.tuning(wino4_min_wgs=0):
+                assert _lib.query("cagc_wino_plan", 2, 512, 512, 32, 32) == 4
+    assert _lib.get_tuning("wino4_min_wgs") in (256, int(__import__("os").environ.get("CAGC_WINO4_MIN_WGS", "256")))
+
