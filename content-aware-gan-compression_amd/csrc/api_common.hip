@@ -99,4 +99,31 @@ int det_end(const DetSink& k, float* base, int64_t n, hipStream_t st, const char
   return check_launch(what);
 }
 }  // namespace cagc
+namespace cagc {
+namespace {
+struct KsBuf { float* p = nullptr; size_t cap = 0; };
+std::map<std::pair<int, hipStream_t>, KsBuf> g_ks;
+}  // namespace
+float* ksplit_scratch(size_t bytes, hipStream_t st, const char* what) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_det_mu);
+  KsBuf& b = g_ks[std::make_pair(dev, st)];
+  if (b.cap < bytes) {
+    const size_t cap = bytes < (size_t)(4u << 20) ? (size_t)(4u << 20) : bytes + bytes / 4;
+    float* fresh = nullptr;
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&fresh), cap);
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("%s: K-split scratch allocation of %zu bytes failed: %s", what, cap, hipGetErrorString(e));
+      return nullptr;
+    }
+    b.p = fresh; b.cap = cap;
+  }
+  return b.p;
+}
+}  // namespace cagc
 extern "C" const char* cagc_arch(void) { return "gfx950"; }

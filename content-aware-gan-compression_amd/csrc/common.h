@@ -60,6 +60,10 @@ __device__ __forceinline__ void sink_add(const DetSink& k, float* dst, float v) 
 int det_begin(DetSink& k, const float* base, int64_t n, hipStream_t st, const char* what);
 int det_end(const DetSink& k, float* base, int64_t n, hipStream_t st, const char* what);
 
+// library-owned scratch of the deterministic forward K split (api_common.hip): one buffer per (device, stream), grown by allocating a
+// new block and never freed (earlier launches / captured graphs may reference the old one); nullptr + error set on failure
+float* ksplit_scratch(size_t bytes, hipStream_t st, const char* what);
+
 inline hipStream_t as_stream(cagc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

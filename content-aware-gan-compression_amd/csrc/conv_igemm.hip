@@ -778,6 +778,7 @@ extern "C" int cagc_modconv_fwd(float* out, const float* x, const float* wp, con
   a.noise_bstride_on = (noise_batch == B) ? 1 : 0;
   a.epi = epi; a.alpha = alpha; a.act_scale = act_scale;
   a.Hin = H; a.Win = W; a.Wpitch = W; a.Hout = H; a.Wout = W; a.Wopitch = W;
+  a.fwd_slabs = 1;
   RawTap taps[9];
   int n = 0;
   const int r = ksize / 2;
@@ -797,6 +798,7 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   a.in_scale = s;
   a.Hin = H; a.Win = W; a.Wpitch = W;
   a.Hout = H + 1; a.Wout = W + 1; a.Wopitch = cagc_phase_pitch(W); a.NPout = 4;
+  a.fwd_slabs = 1;
   // convT[o, 2y+ky, 2x+kx] += Wsc[o,i,ky,kx] * xs[i,y,x]   (model.py:259-267)
   // phase (py,px), virtual (m,n): ky = py + 2jy, input row = m - jy
   RawTap taps[4][4];
@@ -910,6 +912,7 @@ static int conv3x3s2_fwd_impl(float* out, const float* x, const float* wp, const
   base_args(a, out, x, wp, B, Cin, Cout, 9);
   a.isy = 2; a.isx = 2;
   a.Hin = Hin; a.Win = Win; a.Wpitch = in_pitch; a.Hout = Ho; a.Wout = Wo; a.Wopitch = Wo;
+  a.fwd_slabs = 1;
   RawTap taps[9];
   int n = 0;
   for (int ky = 0; ky < 3; ++ky)

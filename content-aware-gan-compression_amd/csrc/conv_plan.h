@@ -50,6 +50,8 @@ struct ConvArgs {
   int osy, osx;                // output stride (2 for the data gradient of a stride-2 conv, else 1)
   int min_dy, min_dx;
   int nitems, ksplit, vec;     // vec: 16-byte staging loads are legal (Wpitch % 4 == 0)
+  int fwd_slabs;               // forward launch: a K split across workgroups goes through per-slice slabs + an ordered reduce (bit-reproducible
+                               // activations in every mode) instead of fp32 atomics; data-gradient launches keep the atomics
   int dbuf, a_sz, b_sz;        // dbuf: two LDS buffers of a_sz + b_sz floats, ONE barrier per K chunk (launches with <= 4 taps)
   int nblocks, mtiles;         // pixel-tile workgroups (incl. K splits) and channel tiles; grid = nblocks * mtiles
   int epi, noise_bstride_on;

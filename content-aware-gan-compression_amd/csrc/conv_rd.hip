@@ -52,6 +52,8 @@ struct RdArgs {
   const float* noise_w;
   const float* bias;
   const float* aux_x;            // dgrad: x at the output positions, for the gs reduction
+  float* slab;                   // forward K split: slice ksi of a tile writes its partial sums to slab + ksi * slab_stride (no atomics)
+  int64_t slab_stride;
   float* gs;                     // [B, Cout-of-this-GEMM], accumulated (one atomic per workgroup and channel)
   DetSink det_gs;                // deterministic mode: through the order-independent sink (common.h)
   int B, Cin, KQ, Cout, MBLK;    // KQ = Kp/4 K-steps (even), MBLK = Mp/16 channel blocks
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
   // ---- epilogue: lane holds channels m0 + i*16 + 4g + r (r = 0..3) of pixel n (same contract as k_conv_igemm) ----
   const int HWo = A.Hout * A.Wopitch;
   const bool atomic_out = ks > 1;
+  float* const slab_out = A.slab ? A.slab + (int64_t)ksi * A.slab_stride : nullptr;
   const bool styled = (A.epi == CAGC_EPI_STYLED) && !atomic_out;    // split K: the non-linear epilogue runs as a separate pass
   const bool scaled = A.out_scale && !(A.epi == CAGC_EPI_STYLED && atomic_out);
   const float nw = (styled && A.noise) ? A.noise_w[0] : 0.f;
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
             v += nz + A.bias[m];
             v = (v > 0.f ? v : v * A.alpha) * A.act_scale;
           }
-          if (atomic_out) atomicAdd(A.out + oidx, v);
+          if (atomic_out) { if (slab_out) slab_out[oidx] = v; else atomicAdd(A.out + oidx, v); }
           else if (!RD_ABL(1) || v == 12345.678f) A.out[oidx] = v;
         }
       }
@@ -378,6 +381,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
       sink_add(A.det_gs, A.gs + (int64_t)b0 * A.Cout + m0 + tid, p);
     }
   }
+}
+
+// Ordered reduce of the forward K split: out[i] = sum_k slab[k][i] (k ascending: bit-reproducible), then the epilogue the split launch
+// deferred — styled: lrelu(v * d + nw * noise + bias) * act_scale — and zeros in the pitch padding of pitched outputs.
+__global__ __launch_bounds__(256) void k_ksplit_reduce(float* __restrict__ out, const float* __restrict__ slab, int ks, int64_t stride,
+                                                       int64_t total, int Wout, int Wopitch, int styled, const float* __restrict__ d,
+                                                       const float* __restrict__ noise, int noise_bstride_on,
+                                                       const float* __restrict__ noise_w, const float* __restrict__ bias, int C, int HW,
+                                                       float alpha, float act_scale) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  if (Wopitch != Wout && (int)(idx % Wopitch) >= Wout) { out[idx] = 0.f; return; }
+  float v = slab[idx];
+  for (int k = 1; k < ks; ++k) v += slab[(int64_t)k * stride + idx];
+  if (styled) {      // un-pitched [B, C, HW]
+    const int p = (int)(idx % HW);
+    const int64_t plane = idx / HW;
+    const int c = (int)(plane % C);
+    const int b = (int)(plane / C);
+    v = v * (d ? d[plane] : 1.f) + bias[c];
+    if (noise) v += noise_w[0] * noise[(noise_bstride_on ? (int64_t)b * HW : 0) + p];
+    v = (v > 0.f ? v : v * alpha) * act_scale;
+  }
+  out[idx] = v;
 }
 
 template <int MB, bool PAD, bool SCALE, bool GS>
@@ -542,7 +569,12 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
     blocks += r.items[p].block_end;
   }
   int ks_max = 1;
-  const int atomic_below = deterministic_mode() ? 0 : tune.atomic_below;
+  // K split across workgroups for launches that cannot fill the chip otherwise.  FORWARD launches (a.fwd_slabs): every K slice writes its
+  // partial tile to its own slab of a library scratch and an ordered reduce finishes it — activations are bit-reproducible in every
+  // mode, so LeakyReLU gates (and with them gradients at the parity bar) repeat run to run.  Data-gradient launches: fp32 atomics on the
+  // pre-zeroed output (default mode; their noise is linear in the gradient, 1e-7) or no split at all (deterministic mode).
+  const bool slabs = a.fwd_slabs != 0 && !a.gs;
+  const int atomic_below = (deterministic_mode() && !slabs) ? 0 : tune.atomic_below;
   if ((int64_t)blocks * mtiles < atomic_below) {
     if (!split_on) return CAGC_RD_DECLINED;
     // every workgroup gets about the same number of (K-step, tap) groups: an item's split is proportional to its taps
@@ -562,12 +594,22 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
       ks_max = k > ks_max ? k : ks_max;
     }
   }
+  const int64_t out_elems = (int64_t)a.B * a.Cout * a.NPout * a.Hout * a.Wopitch;
+  if (slabs && ks_max > 1 && (int64_t)ks_max * out_elems * 4 > (256ll << 20)) {
+    // (only a forced split of a large layer gets here — tests, cagc_set_tuning: launches that need a split are small) no 256 MB+ scratch:
+    // atomics in the default mode, no split in deterministic mode
+    if (deterministic_mode()) { ks_max = 1; for (int p = 0; p < nitems; ++p) r.items[p].ks = 1; }
+  } else if (slabs && ks_max > 1) {
+    for (int p = 0; p < nitems; ++p) r.items[p].ks = ks_max;       // one slab count for the whole output: the reduce is a plain sum over slabs
+    r.slab = ksplit_scratch(sizeof(float) * (size_t)ks_max * out_elems, st, what);
+    if (!r.slab) return CAGC_ERR_LAUNCH;
+    r.slab_stride = out_elems;
+  }
   blocks = 0;
   for (int p = 0; p < nitems; ++p) { blocks += r.items[p].block_end * r.items[p].ks; r.items[p].block_end = blocks; }
   a.ksplit = ks_max;
-  if (ks_max > 1) {
-    const size_t bytes = sizeof(float) * (size_t)a.B * a.Cout * a.NPout * a.Hout * a.Wopitch;
-    const int zrc = zero_fill(a.out, bytes, st);
+  if (ks_max > 1 && !r.slab) {
+    const int zrc = zero_fill(a.out, sizeof(float) * (size_t)out_elems, st);
     if (zrc) return zrc;
   }
   r.nblocks = blocks; r.mtiles = mtiles;
@@ -578,13 +620,24 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
     if (dbg) fprintf(stderr, "[cagc] %s: RD items %d taps %d mb %d kw %d ks %d pad %d scale %d gs %d lin %d grid %d K %d M %d\n", what, nitems, raw[0].ntaps, mb,
                      kw, ks_max, (int)pad, (int)(a.in_scale != nullptr), (int)(a.gs != nullptr), r.items[0].lin, blocks * mtiles, a.Kp, a.Mp);
   }
+  int rc;
   switch (mb) {
-    case 1: return launch_rd<1>(r, pad, grid, st, what);
-    case 2: return launch_rd<2>(r, pad, grid, st, what);
-    case 3: return launch_rd<3>(r, pad, grid, st, what);
-    case 4: return launch_rd<4>(r, pad, grid, st, what);
-    case 5: return launch_rd<5>(r, pad, grid, st, what);
-    default: return launch_rd<8>(r, pad, grid, st, what);
+    case 1: rc = launch_rd<1>(r, pad, grid, st, what); break;
+    case 2: rc = launch_rd<2>(r, pad, grid, st, what); break;
+    case 3: rc = launch_rd<3>(r, pad, grid, st, what); break;
+    case 4: rc = launch_rd<4>(r, pad, grid, st, what); break;
+    case 5: rc = launch_rd<5>(r, pad, grid, st, what); break;
+    default: rc = launch_rd<8>(r, pad, grid, st, what); break;
+  }
+  if (rc || !r.slab) return rc;
+  {   // ordered reduce + the deferred epilogue; the caller sees a finished output (ksplit = 1: no separate epilogue pass)
+    const int styled = a.epi == CAGC_EPI_STYLED ? 1 : 0;
+    if (styled && (a.NPout != 1 || a.Wopitch != a.Wout)) { set_error("%s: styled epilogue on a pitched / planar output", what); return CAGC_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(k_ksplit_reduce, dim3((unsigned)cdiv(out_elems, 256)), dim3(256), 0, st, a.out, r.slab, ks_max, out_elems, out_elems, a.Wout,
+                       a.Wopitch, styled, styled ? a.out_scale : nullptr, a.noise, a.noise_bstride_on, a.noise_w, a.bias, a.Cout, a.Hout * a.Wout, a.alpha,
+                       a.act_scale);
+    a.ksplit = 1;
+    return check_launch(what);
   }
 }
 

@@ -15,12 +15,16 @@
  *   - all tensors are fp32, contiguous, NCHW unless stated ("planes" = N*C flattened); the two reference operators also
  *     exist in an any-dtype form (fp32 / fp16 / fp64: cagc_fused_bias_act_any, cagc_upfirdn2d_any).
  *   - OWNERSHIP: the caller allocates every output and workspace (PyTorch caching allocator) and
- *     passes data_ptr(); the library never frees or retains a caller's pointer.  ONE exception to "never
- *     allocates": in deterministic mode (cagc_set_tuning("deterministic", 1) / CAGC_DETERMINISTIC=1) the
- *     order-independent reduction sink keeps a library-owned scratch per (device, stream) — 16 bytes per reduced
- *     element, < 1 MB on this path — obtained with hipMalloc on first use (also under stream capture, relaxed mode),
- *     grown by allocating a new block and never freed before process exit (earlier launches / captured graphs may
- *     still reference the old one); the table of scratches is mutex-guarded.  Default mode allocates nothing.
+ *     passes data_ptr(); the library never frees or retains a caller's pointer.  TWO exceptions to "never
+ *     allocates", both library-owned scratches kept per (device, stream), obtained with hipMalloc on first use (also
+ *     under stream capture, relaxed mode), grown by allocating a new block and never freed before process exit
+ *     (earlier launches / captured graphs may still reference the old one), in a mutex-guarded table:
+ *       (a) every mode: the K-split slabs of FORWARD convolution launches — a small layer whose reduction is cut across
+ *           workgroups writes one partial-sum slab per slice and an ordered reduce adds them (bit-reproducible
+ *           activations; no fp32 atomics in any forward pass); >= 4 MB, the largest split output x its slices
+ *           (< 32 MB on this path; a launch that would need > 256 MB falls back to not splitting);
+ *       (b) deterministic mode (cagc_set_tuning("deterministic", 1) / CAGC_DETERMINISTIC=1): the order-independent
+ *           reduction sink of the backward pass — 16 bytes per reduced element, < 1 MB on this path.
  *   - ERRORS: every function returns CAGC_OK (0) or a negative code; the message is available from
  *     cagc_last_error() (thread-local).  Nothing throws across the ABI.
  *   - THREADING: the data path is re-entrant — entry points may be called concurrently from several host threads
@@ -29,7 +33,7 @@
  *     table behind cagc_set_tuning / cagc_get_tuning (plain ints, initialised from CAGC_* environment variables at
  *     first use, NOT synchronised: set them before worker threads start or while no launch is in flight), the
  *     per-device "LDS limit already raised" flags of the large-LDS kernels (idempotent: a race costs one redundant
- *     hipFuncSetAttribute call), and the deterministic-mode scratch table above (mutex).  The device is the caller's
+ *     hipFuncSetAttribute call), and the two scratch tables above (mutex).  The device is the caller's
  *     current HIP device; kernels are enqueued on `stream` and not synchronised.
  *   - nullable pointers are marked [nullable].
  */
@@ -64,10 +68,11 @@ const char* cagc_last_error(void);
  * "rd_split", "rd_atomic_below", "rd_split_wgs", "rd_min_wgs_long" — see csrc/conv_rd.hip; "wgrad_rd" (0 = LDS-staged weight-gradient kernels
  * only), "wgrad_rd_wgs" — csrc/conv_wgrad_rd.hip; "wino4_hv" (0 per launch, 1 / 2: 64- / 128-channel workgroup shape of the F(4x4) kernel),
  * "wino4_min_wgs" (64-channel workgroups below which a launch takes the layer's F(2x2) packing; default 256) — csrc/conv_wino4.hip;
- * "deterministic" (also CAGC_DETERMINISTIC=1): no fp32-atomic K split in the
- * convolution kernels, and the backward reductions (grad-bias / styled-epilogue / style / ToRGB weight sums, L1 loss) through an
- * order-independent fixed-point sink on a library-owned per-stream scratch — forward passes AND gradients become
- * bit-reproducible run to run (slower at small per-GPU batch).  The same knobs are read from CAGC_RD* at first use. */
+ * "deterministic" (also CAGC_DETERMINISTIC=1): forward passes are bit-reproducible run to run in EVERY mode (K splits through
+ * ordered slabs); this key additionally removes the fp32-atomic K split from the data-gradient launches and routes the backward
+ * reductions (grad-bias / styled-epilogue / style / ToRGB weight sums, L1 loss) through an order-independent fixed-point sink on a
+ * library-owned per-stream scratch — gradients become bit-reproducible too (default mode: they repeat to ~1e-6 of their scale,
+ * fp32 summation order only; deterministic costs ~1 % at batch 16, ~7 % at per-GPU batch 2).  The same knobs are read from CAGC_RD* at first use. */
 int cagc_set_tuning(const char* key, int value);
 /* Current value of a tuning key (same keys); CAGC_ERR_INVALID for an unknown key. */
 int cagc_get_tuning(const char* key, int* value);
