@@ -655,7 +655,7 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "rd_atomic_below")) t.atomic_below = value;
   else if (!strcmp(key, "rd_split_wgs")) t.split_target = value;
   else if (!strcmp(key, "deterministic")) cagc::deterministic_mode() = value;
-  else if (!strcmp(key, "wgrad_rd")) cagc::wgrad_rd_set_tuning(value, 0);
+  else if (!strcmp(key, "wgrad_rd")) cagc::wgrad_rd_set_tuning(value, -1);
   else if (!strcmp(key, "wgrad_rd_wgs")) cagc::wgrad_rd_set_tuning(-1, value);
   else if (!strcmp(key, "wino4_hv")) cagc::wino4_hv_tuning() = value;
   else if (!strcmp(key, "wino4_min_wgs")) cagc::wino4_min_wgs() = value;

@@ -21,7 +21,7 @@ bool wgrad_rd_plan(WgrPlan& P, int B, int Cin, int Cout, int H, int W, int ksize
 int run_wgrad_rd(const WgrPlan& P, float* ws, const float* g, const float* x, const float* s, int B, int Cin, int Cout, int H,
                  int W, int up, hipStream_t st);
 
-// mode < 0 / target_wgs <= 0: leave unchanged
+// mode < 0 / target_wgs < 0: leave unchanged; target_wgs 0: the plan picks the K split by its cost model
 void wgrad_rd_set_tuning(int mode, int target_wgs);
 void wgrad_rd_get_tuning(int* mode, int* target_wgs);
 

@@ -17,11 +17,15 @@
 //     the accumulators when the partial slab is written — never to the staged operand.
 // Wave tile = (MB*16 output channels) x (NB*16 input channels) x 9 taps = 9*MB*NB accumulator tiles, one wave per SIMD
 // (up to 512 registers); the next row's operands are in flight while the current row's 36*MB*NB MFMAs run.
-// K is split over workgroups (image, column group, row chunk); each writes a partial slab [9][Mp][Np], k_wgrad_reduce
-// (conv_wgrad.hip) sums them in a fixed order — deterministic, no atomics.
+// K is split over waves: a workgroup is FOUR K slices of one wave tile — 4 x upw consecutive units (column group, row chunk) of
+// one image — whose accumulators are summed through LDS in a fixed order before ONE partial slab [9][Mp][Np] is written
+// (a quarter of the slab traffic of a slab per wave, and no idle SIMD whatever mt x nt is); k_wgrad_reduce (conv_wgrad.hip)
+// sums the slabs in a fixed order — deterministic, no atomics.
 #include "common.h"
 #include "conv_wgrad_rd.h"
 #include <stdlib.h>
+#include <math.h>
+#include <algorithm>
 #include <string.h>
 #include <type_traits>
 
@@ -37,7 +41,8 @@ struct WgrArgs {
   int B, Cin, Cout, H, W;
   int a_pitch, a_plane, a_chan;   // A: row pitch, plane stride, channel stride (floats)
   int CG, RC, chunks;             // column groups per row, rows per chunk, chunks per image
-  int upw, nsplit;                // units per workgroup; number of slabs
+  int upw, nsplit;                // units per WAVE; number of slabs (= workgroups per wave tile)
+  int gpi, per_image;             // slabs per image; units per image (CG * chunks)
   int Mp, Np, mt, nt;             // padded dims of a slab; wave tiles along M / N
   int wm, gm, gn;                 // waves of a workgroup along M (1, 2, 4); workgroup tiles along M / N
 };
@@ -52,12 +57,10 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_rd(const WgrArgs A) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lm = lane & 15, g = lane >> 4;
-  // wave tiles are dealt to the waves linearly (N fastest: the 4 waves of a workgroup share their A rows through L1), so at
-  // most 3 wave slots idle per split however mt x nt factors
-  const int wg = blockIdx.x;
-  const int split = wg / A.gm;                       // gm = workgroups per split = ceil(mt * nt / 4)
-  const int tile = (wg - split * A.gm) * 4 + wave;
-  if (tile >= A.mt * A.nt) return;                   // no barriers in this kernel: idle waves just leave
+  // workgroup = (slab, wave tile), tile fastest: the tiles of one slab read the same pixels (L2)
+  const int T = A.mt * A.nt;
+  const int split = blockIdx.x / T;
+  const int tile = blockIdx.x - split * T;
   const int mtile = tile / A.nt, ntile = tile - mtile * A.nt;
   const int m0 = mtile * MB * 16, n0 = ntile * NB * 16;
   const int HW = A.H * A.W;
@@ -76,12 +79,12 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_rd(const WgrArgs A) {
   typedef typename std::conditional<UP, RowU, RowP>::type Row;
 
   const __amdgpu_buffer_rsrc_t rnull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.x), 0, 0, 0x00020000);
-  int b_last = 0;
-  for (int u = split * A.upw; u < (split + 1) * A.upw; ++u) {
+  const int b = split / A.gpi;                                        // a slab stays inside one image (its modulation is applied once)
+  const int u_first = ((split - b * A.gpi) * 4 + wave) * A.upw;        // this wave's K slice: upw units of image b
+  const int u_end = min(u_first + A.upw, A.per_image);                // (a short image leaves the last waves without units)
+  for (int u = u_first; u < u_end; ++u) {
     const int cg = u % A.CG;
-    const int rc = (u / A.CG) % A.chunks;
-    const int b = u / (A.CG * A.chunks);
-    b_last = b;
+    const int rc = u / A.CG;
     const int col = cg * 16 + 4 * g;
     const bool colok = col < A.W;
     const int y_lo = rc * A.RC, y_hi = y_lo + A.RC;
@@ -183,24 +186,46 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_rd(const WgrArgs A) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // ---- partial slab [9][Mp][Np] of this split; the image's modulation s[b, n] applied here (lane holds column n = lm) ----
+  // ---- the four K slices summed through LDS in a fixed order (wave 0 + 1 + 2 + 3), tap by tap; then the partial slab
+  //      [9][Mp][Np] of this split, the image's modulation s[b, n] applied here (lane holds column n = lm) ----
+  constexpr int NBUF = NT == 1 ? 1 : 2;
+  __shared__ float red[NBUF][3][MB * NB * 4][64];
   float sv[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int n = n0 + j * 16 + lm;
-    sv[j] = (A.s && n < A.Cin) ? A.s[(int64_t)b_last * A.Cin + n] : 1.f;
+    sv[j] = (A.s && n < A.Cin) ? A.s[(int64_t)b * A.Cin + n] : 1.f;
   }
   float* slab = A.ws + (int64_t)split * NT * A.Mp * A.Np;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
+    const int buf = t % NBUF;
+    if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < MB; ++i)
+      for (int i = 0; i < MB; ++i)
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const f32x4 v = acc[t][i][j];
-        float* p = slab + ((int64_t)t * A.Mp + m0 + i * 16 + 4 * g) * A.Np + n0 + j * 16 + lm;
-        p[0] = v[0] * sv[j]; p[A.Np] = v[1] * sv[j]; p[2 * A.Np] = v[2] * sv[j]; p[3 * A.Np] = v[3] * sv[j];
-      }
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[buf][wave - 1][(i * NB + j) * 4 + r][lane] = acc[t][i][j][r];
+    }
+    __syncthreads();          // two buffers: the writes of tap t + 2 are behind the barrier of tap t + 1, which wave 0 passes after its reads of tap t
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = (i * NB + j) * 4 + r;
+            v[r] = ((acc[t][i][j][r] + red[buf][0][e][lane]) + red[buf][1][e][lane]) + red[buf][2][e][lane];
+          }
+          float* p = slab + ((int64_t)t * A.Mp + m0 + i * 16 + 4 * g) * A.Np + n0 + j * 16 + lm;
+          p[0] = v[0] * sv[j]; p[A.Np] = v[1] * sv[j]; p[2 * A.Np] = v[2] * sv[j]; p[3 * A.Np] = v[3] * sv[j];
+        }
+    }
+    if constexpr (NBUF == 1) __syncthreads();
+  }
 }
 
 static int pick_blocks(int blocks, const int* cands, int nc) {
@@ -216,10 +241,10 @@ static int pick_blocks(int blocks, const int* cands, int nc) {
 
 // tunables (environment at first use, or cagc_set_tuning "wgrad_rd" / "wgrad_rd_wgs"): kernel on / off, target workgroup count
 static int& wgr_mode() { static int v = getenv("CAGC_WGRAD_RD") ? atoi(getenv("CAGC_WGRAD_RD")) : 1; return v; }
-static int& wgr_target() { static int v = getenv("CAGC_WGRAD_RD_WGS") ? atoi(getenv("CAGC_WGRAD_RD_WGS")) : 384; return v; }   // 768 -> 384 in round 4 (sweep: -0.4 .. -0.8 % at every per-GPU batch)
+static int& wgr_target() { static int v = getenv("CAGC_WGRAD_RD_WGS") ? atoi(getenv("CAGC_WGRAD_RD_WGS")) : 0; return v; }   // 0: the plan's cost model picks the K split
 void wgrad_rd_set_tuning(int mode, int target_wgs) {
   if (mode >= 0) wgr_mode() = mode;
-  if (target_wgs > 0) wgr_target() = target_wgs;
+  if (target_wgs >= 0) wgr_target() = target_wgs;
 }
 void wgrad_rd_get_tuning(int* mode, int* target_wgs) { *mode = wgr_mode(); *target_wgs = wgr_target(); }
 static bool wgr_tuning_on() { return wgr_mode() != 0; }
@@ -228,42 +253,63 @@ bool wgrad_rd_plan(WgrPlan& P, int B, int Cin, int Cout, int H, int W, int ksize
   if (!wgr_tuning_on() || (ksize != 3 && !(ksize == 1 && !up))) return false;
   const int ntaps = ksize * ksize;
   if (W % 16 != 0 || W < 16 || H % 2 != 0 || H < 2) return false;
-  // wave tile (measured, scripts/sweep_wgrad_plan.py): the operand that differs per tap wants ONE channel block per wave —
-  // B in the plain geometry (3 loads per block and row offset), A in the transposed one (9 loads per block) — and the shared
-  // operand several: plain (2|3|4, 1), transposed (1, 2|4)
+  // wave tile (measured, scripts/time_wgrad.py): the operand that differs per tap wants ONE channel block per wave — B in the plain
+  // geometry (3 loads per block and row offset), A in the transposed one (9 loads per block) — and the shared operand several:
+  // plain (2|3|4|5, 1), transposed (1, 2|4|5).  The student's 77 / 154 channels are 5 / 10 blocks: a 5-block tile pads nothing
+  // (2- or 3-block tiles pad 80 -> 96) and is taken whenever the launch model below prices it lower (long K; always for 5 blocks).
   const int mblk = cdiv(Cout, 16), nblk = cdiv(Cin, 16);
+  int cand[2][2], ncand = 1;
   if (ksize == 1) {     // one tap: 16 accumulator tiles at most — square wave tiles
-    P.mb = (mblk % 4 == 0) ? 4 : (mblk % 2 == 0 ? 2 : (mblk == 1 ? 1 : 2));
-    P.nb = (nblk % 4 == 0) ? 4 : (nblk % 2 == 0 ? 2 : (nblk == 1 ? 1 : 2));
+    cand[0][0] = (mblk % 4 == 0) ? 4 : (mblk % 2 == 0 ? 2 : (mblk == 1 ? 1 : 2));
+    cand[0][1] = (nblk % 4 == 0) ? 4 : (nblk % 2 == 0 ? 2 : (nblk == 1 ? 1 : 2));
   } else if (!up) {
-    P.nb = 1;
-    P.mb = (mblk % 4 == 0 && mblk >= 8) ? 4 : (mblk % 3 == 0 ? 3 : (mblk % 2 == 0 ? 2 : (mblk == 1 ? 1 : 3)));
+    cand[0][1] = 1;
+    cand[0][0] = (mblk % 4 == 0 && mblk >= 8) ? 4 : (mblk % 3 == 0 ? 3 : (mblk % 2 == 0 ? 2 : (mblk == 1 ? 1 : 3)));
+    if (mblk % 5 == 0 && cand[0][0] < 4) { cand[1][0] = 5; cand[1][1] = 1; ncand = 2; }
   } else {
-    P.mb = 1;
-    P.nb = (nblk % 4 == 0 && nblk >= 8) ? 4 : (nblk == 1 ? 1 : 2);
+    cand[0][0] = 1;
+    cand[0][1] = (nblk % 4 == 0 && nblk >= 8) ? 4 : (nblk == 1 ? 1 : 2);
+    if (nblk % 5 == 0 && cand[0][1] < 4) { cand[1][0] = 1; cand[1][1] = 5; ncand = 2; }
   }
-  if (ksize == 1) { if (!((P.mb == 1 || P.mb == 2 || P.mb == 4) && (P.nb == 1 || P.nb == 2 || P.nb == 4))) return false; }
-  else if (P.mb < 1 || P.mb > 4 || P.nb < 1 || P.nb > 4 || P.nb == 3 || P.mb * P.nb > 8 || (P.mb == 4 && P.nb == 2) || (!up && P.nb == 4)) return false;
   P.ntaps = ntaps;
-  P.mt = cdiv(Cout, 16 * P.mb); P.nt = cdiv(Cin, 16 * P.nb);
-  P.Mp = P.mt * 16 * P.mb; P.Np = P.nt * 16 * P.nb;
-  P.wm = 1;
-  P.gm = cdiv(P.mt * P.nt, 4); P.gn = 1;             // workgroups per split: wave tiles dealt linearly, 4 per workgroup
-  // K split: units = (image, column group, row chunk); a workgroup takes `upw` consecutive units (inside one image when the
-  // layer is modulated).  Aim at ~3 workgroups per CU; the slab workspace grows with the split count.
+  P.wm = 1; P.gn = 1;
   P.CG = W / 16;
-  int want = cdiv(wgr_target(), P.gm * P.gn);
-  if (want < 1) want = 1;
-  if (want > 512) want = 512;
-  P.chunks = 1;
-  while ((int64_t)B * P.CG * P.chunks < want && (H / P.chunks) % 4 == 0 && H / P.chunks >= 8) P.chunks *= 2;
+  // K split: units = (column group, row chunk) of one image; a wave takes `upw` consecutive units, a workgroup 4 waves, a slab is
+  // one workgroup's sum.  Candidates (chunks, upw) are powers of two; the pick minimises a model of the launch —
+  //   MFMA time of the busiest CU: ceil(workgroups / 256) x (rows per wave x MFMAs per row + 1 us per unit: its first row's loads
+  //     are exposed).  The kernel is MFMA-bound and a CU runs its workgroups' waves one per SIMD, so a 1.5-workgroups-per-CU grid
+  //     costs what 2 do: the 39-channel layer's 512 x 3 waves used to run at 0.63 with every other SIMD idle half of the time;
+  //   slab traffic: every slab is written once and read once by the reduction (~3 TB/s effective);
+  // unless cagc_set_tuning("wgrad_rd_wgs") / CAGC_WGRAD_RD_WGS names a workgroup count to aim at (tests, sweeps).
+  double best = -1;
+  for (int c = 0; c < ncand; ++c) {
+    const int mb = cand[c][0], nb = cand[c][1];
+    const int mt = cdiv(Cout, 16 * mb), nt = cdiv(Cin, 16 * nb), T = mt * nt;
+    const double us_row = 4.0 * ntaps * mb * nb * 32.0 / 2400.0;         // one wave, one row of 16 pixels: 4 K-steps per tap and block pair
+    const double slab_bytes = 4.0 * ntaps * (mt * 16 * mb) * (nt * 16 * nb);
+    for (int chunks = 1; chunks <= H; chunks *= 2) {
+      if (chunks > 1 && !((H / (chunks / 2)) % 4 == 0 && H / (chunks / 2) >= 8)) break;   // rows per chunk stay even and >= 4
+      const int per_image = P.CG * chunks;
+      for (int upw = 1; upw <= per_image; upw *= 2) {
+        if (upw > 1 && per_image % (4 * upw) != 0) break;
+        const int64_t nsplit = (int64_t)B * cdiv(per_image, 4 * upw), wgs = nsplit * T;
+        if (nsplit > 4096 || wgs >= (1 << 30)) continue;
+        double cost;
+        if (wgr_target() > 0) cost = fabs(log((double)wgs / wgr_target())) + 1e-3 * c;
+        else cost = (double)cdiv((int)wgs, 256) * upw * ((H / chunks) * us_row + 1.0) + (double)nsplit * slab_bytes * 2.0 / 3.0e6;
+        if (best < 0 || cost < best - 1e-9) {
+          best = cost;
+          P.mb = mb; P.nb = nb; P.mt = mt; P.nt = nt; P.chunks = chunks; P.upw = upw; P.nsplit = (int)nsplit;
+        }
+      }
+    }
+  }
+  if (best < 0) return false;
+  if (ksize == 1) { if (!((P.mb == 1 || P.mb == 2 || P.mb == 4) && (P.nb == 1 || P.nb == 2 || P.nb == 4))) return false; }
+  else if (!((P.nb == 1 && P.mb >= 1 && P.mb <= 5) || (P.mb == 1 && (P.nb == 2 || ((P.nb == 4 || P.nb == 5) && up))))) return false;
+  P.Mp = P.mt * 16 * P.mb; P.Np = P.nt * 16 * P.nb;
+  P.gm = P.mt * P.nt;                                // wave tiles = workgroups per slab
   P.RC = H / P.chunks;
-  const int per_image = P.CG * P.chunks;
-  const int64_t total = (int64_t)B * per_image;
-  int upw = 1;
-  while (total / (upw * 2) >= want && total % (upw * 2) == 0 && (!modulated || per_image % (upw * 2) == 0)) upw *= 2;
-  P.upw = upw;
-  P.nsplit = (int)(total / upw);
   P.workspace = (int64_t)P.nsplit * ntaps * P.Mp * P.Np;
   if (P.workspace * 4 > (int64_t)3 << 30) return false;          // > 3 GB of slabs: leave it to the LDS kernel
   // 32-bit lane offsets: one channel-block tile of one image
@@ -288,8 +334,9 @@ int run_wgrad_rd(const WgrPlan& P, float* ws, const float* g, const float* x, co
   if (up) { a.a_pitch = (W + 1 + 3) & ~3; a.a_plane = (H + 1) * a.a_pitch; a.a_chan = 4 * a.a_plane; }
   else { a.a_pitch = W; a.a_plane = 0; a.a_chan = H * W; }
   a.CG = P.CG; a.RC = P.RC; a.chunks = P.chunks; a.upw = P.upw; a.nsplit = P.nsplit;
+  a.per_image = P.CG * P.chunks; a.gpi = P.nsplit / B;
   a.Mp = P.Mp; a.Np = P.Np; a.mt = P.mt; a.nt = P.nt; a.wm = P.wm; a.gm = P.gm; a.gn = P.gn;
-  const int64_t wgs = (int64_t)P.gm * P.gn * P.nsplit;
+  const int64_t wgs = (int64_t)P.gm * P.nsplit;
   if (wgs >= (1ll << 31)) { set_error("cagc_modconv_wgrad: grid too large"); return CAGC_ERR_INVALID; }
   {
     static const bool dbg = getenv("CAGC_CONV_DEBUG") != nullptr;
@@ -311,12 +358,11 @@ int run_wgrad_rd(const WgrPlan& P, float* ws, const float* g, const float* x, co
     case 11: return launch_wgr<1, 1>(a, up, grid, st);
     case 12: return launch_wgr<1, 2>(a, up, grid, st);
     case 21: return launch_wgr<2, 1>(a, up, grid, st);
-    case 22: return launch_wgr<2, 2>(a, up, grid, st);
     case 31: return launch_wgr<3, 1>(a, up, grid, st);
-    case 32: return launch_wgr<3, 2>(a, up, grid, st);
     case 41: return launch_wgr<4, 1>(a, up, grid, st);
+    case 51: return launch_wgr<5, 1>(a, up, grid, st);
+    case 15: hipLaunchKernelGGL((k_wgrad_rd<1, 5, true>), grid, dim3(256), 0, st, a); return check_launch("cagc_modconv_wgrad(register-direct)");
     case 14: hipLaunchKernelGGL((k_wgrad_rd<1, 4, true>), grid, dim3(256), 0, st, a); return check_launch("cagc_modconv_wgrad(register-direct)");
-    case 24: hipLaunchKernelGGL((k_wgrad_rd<2, 4, true>), grid, dim3(256), 0, st, a); return check_launch("cagc_modconv_wgrad(register-direct)");
     default: set_error("cagc_modconv_wgrad: no register-direct kernel for tile (%d,%d)", P.mb, P.nb); return CAGC_ERR_UNSUPPORTED;
   }
 }

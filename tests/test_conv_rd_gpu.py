@@ -167,7 +167,7 @@ def test_set_tuning_rejects_unknown_keys():
 # register-direct weight gradient (csrc/conv_wgrad_rd.hip)
 # ---------------------------------------------------------------------------------------------------
 WG_CONFIGS = {"default": {}, "lds_kernels": {"wgrad_rd": 0}, "few_splits": {"wgrad_rd_wgs": 8}, "many_splits": {"wgrad_rd_wgs": 100000}}
-WG_DEFAULTS = {"wgrad_rd": 1, "wgrad_rd_wgs": 384}
+WG_DEFAULTS = {"wgrad_rd": 1, "wgrad_rd_wgs": 0}
 
 
 @pytest.fixture(params=list(WG_CONFIGS))
