@@ -383,6 +383,128 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
   }
 }
 
+// ---- stride-2 3x3 forward, vector-operand form (the discriminator's `Blur -> 3x3 stride 2` on its big layers) -----------------
+// The general kernel above feeds every MFMA's B operand with its own 4-byte load: 12 loads per (K-step, input row) for the 3 taps x 4
+// pixel blocks of a wave.  Here a lane owns FOUR CONSECUTIVE output pixels ox0 .. ox0+3 of one row — pixel block j of the wave is
+// "pixel ox0 + j of every lane" (interleaved blocks: the mapping is free on the MFMA side, a block is any 16 pixels) — and the nine input
+// columns 2*ox0 .. 2*ox0+8 those pixels read in input row 2*oy + dy are two aligned 16-byte loads and one 4-byte load:
+//     dx = 0: (C0.x, C0.z, C1.x, C1.z)    dx = 1: (C0.y, C0.w, C1.y, C1.w)    dx = 2: (C0.z, C1.x, C1.z, R)
+// — register names, no VALU.  3 B loads + 6 A loads per 96 MFMAs instead of 12 + 6, and the epilogue stores 16 bytes per lane.
+// Same packed weights, same descriptors-as-padding idea, same XCD-aware workgroup map; launches the plan routes here: one 9-tap item,
+// MB = 8, no K split, no padding taps, Wout % 4 == 0, 16-byte aligned rows.
+__global__ __launch_bounds__(256, 2) void k_conv_s2v(const RdArgs A) {
+  constexpr int MB = 8;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lm = lane & 15, g = lane >> 4;
+  int pix_id, mtile;
+  {
+    const int w = blockIdx.x, nx = A.nblocks, mt = A.mtiles;
+    const int full = (nx / 8) * 8;
+    const int s = w / 8, xcd = w - s * 8;
+    const int p = (s / mt) * 8 + xcd;
+    if (w < full * mt && p < full) { pix_id = p; mtile = s % mt; }
+    else { const int r = w - full * mt; pix_id = full + r / mt; mtile = r % mt; }
+  }
+  const int region = A.Hout * A.Wout;
+  const int cs = A.Hin * A.Wpitch;
+  const int b0 = (pix_id * CONV_NT) / region;                 // image of the tile's first pixel (uniform)
+  const int p0 = pix_id * CONV_NT + wave * 64 + 4 * lm;       // this lane's first output pixel in the linearised (image, oy, ox) space
+  const int pb = p0 / region;
+  const int rem = p0 - pb * region;
+  const int oy = rem / A.Wout, ox0 = rem - oy * A.Wout;       // Wout % 4 == 0: the four pixels share a row
+  const bool pok = pb < A.B;
+  const unsigned voff = pok ? 4u * (unsigned)(((pb - b0) * A.Cin + g) * cs + 2 * oy * A.Wpitch + 2 * ox0) : RD_OOR;
+  const int row_bytes = A.Wpitch * 4;
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.wp), 0, (int)A.wp_bytes, 0x00020000);
+  const unsigned a_lane = (unsigned)(lane * A.a_lane_bytes);
+  const int a_tile = mtile * A.a_tile_bytes;
+  const int64_t img_elems = (int64_t)A.Cin * cs;
+  auto in_rsrc = [&](int kq) {   // descriptor of K-step kq: base = channel 4*kq of image b0, ends with the tensor
+    const int64_t left = ((int64_t)(A.B - b0) * A.Cin - 4 * kq) * cs * 4;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.in) + (int64_t)b0 * img_elems + (int64_t)4 * kq * cs, 0,
+                                             left > 0x7fffffff ? 0x7fffffff : (left > 0 ? (int)left : 0), 0x00020000);
+  };
+  f32x4 acc[MB][4];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // one stage = (K-step, input row dy): 3 taps x 32 MFMAs; operands of the next stage are in flight while this one computes
+  float4 c0[2], c1[2], av[2][3][2];
+  float cr[2];
+  auto issue = [&](const int slot, const __amdgpu_buffer_rsrc_t ri, const int kq, const int dy) {
+    const int so = dy * row_bytes;
+    c0[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ri, voff, so, 0));
+    c1[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ri, voff + 16u, so, 0));
+    cr[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, voff + 32u, so, 0));
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ao = (dy * 3 + dx) * A.a_tap_bytes + a_tile + kq * A.a_kq_bytes;
+      av[slot][dx][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, a_lane, ao, 0));
+      av[slot][dx][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, a_lane + 16u, ao, 0));
+    }
+  };
+  auto compute = [&](const int slot) {
+    const float4 C0 = c0[slot], C1 = c1[slot];
+    const float R = cr[slot];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      float bb[4];
+      if (dx == 0) { bb[0] = C0.x; bb[1] = C0.z; bb[2] = C1.x; bb[3] = C1.z; }
+      else if (dx == 1) { bb[0] = C0.y; bb[1] = C0.w; bb[2] = C1.y; bb[3] = C1.w; }
+      else { bb[0] = C0.z; bb[1] = C1.x; bb[2] = C1.z; bb[3] = R; }
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const float4 a4 = av[slot][dx][i >> 2];
+        const float ai = (i & 3) == 0 ? a4.x : ((i & 3) == 1 ? a4.y : ((i & 3) == 2 ? a4.z : a4.w));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, bb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  __amdgpu_buffer_rsrc_t r0 = in_rsrc(0);
+  issue(0, r0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kq = 0; kq < A.KQ; kq += 2) {           // KQ is even: 6 stages per iteration -> static slots
+    const __amdgpu_buffer_rsrc_t r1 = in_rsrc(kq + 1);
+    const int kqn = (kq + 2 < A.KQ) ? kq + 2 : kq;  // last iteration: re-read valid operands instead of branching
+    const __amdgpu_buffer_rsrc_t r2 = in_rsrc(kqn);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      if (s < 5) issue((s + 1) & 1, (s + 1) / 3 ? r1 : r0, kq + (s + 1) / 3, (s + 1) % 3);
+      else issue(0, r2, kqn, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(s & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    r0 = r2;
+  }
+  // ---- epilogue: lane holds channels m0 + i*16 + 4g + r of its four pixels -> one 16-byte store per (i, r) ----
+  if (!pok) return;
+  const bool styled = A.epi == CAGC_EPI_STYLED;
+  const int m0 = mtile * MB * 16;
+  float* const orow = A.out + (int64_t)pb * A.Cout * region + (int64_t)oy * A.Wout + ox0;
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + i * 16 + 4 * g + r;
+      if (m < A.Cout) {
+        float4 v = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+        if (styled) {
+          const float bs = A.bias[m];
+          v.x += bs; v.y += bs; v.z += bs; v.w += bs;
+          v.x = (v.x > 0.f ? v.x : v.x * A.alpha) * A.act_scale; v.y = (v.y > 0.f ? v.y : v.y * A.alpha) * A.act_scale;
+          v.z = (v.z > 0.f ? v.z : v.z * A.alpha) * A.act_scale; v.w = (v.w > 0.f ? v.w : v.w * A.alpha) * A.act_scale;
+        }
+        *reinterpret_cast<float4*>(orow + (int64_t)m * region) = v;
+      }
+    }
+}
+
 // Ordered reduce of the forward K split: out[i] = sum_k slab[k][i] (k ascending: bit-reproducible), then the epilogue the split launch
 // deferred — styled: lrelu(v * d + nw * noise + bias) * act_scale — and zeros in the pitch padding of pitched outputs.
 __global__ __launch_bounds__(256) void k_ksplit_reduce(float* __restrict__ out, const float* __restrict__ slab, int ks, int64_t stride,
@@ -440,13 +562,13 @@ static int launch_rd(const RdArgs& a, bool pad, dim3 grid, hipStream_t st, const
 // Launch-shape tunables of the register-direct kernel: defaults, overridden by the environment (read once) or by
 // cagc_set_tuning() — a test / tuning hook, not part of the data path's contract (process-wide, not synchronised).
 struct RdTuning {
-  int mode, min_wgs, force_mb, force_kw, split_on, atomic_below, split_target, min_wgs_long;
+  int mode, min_wgs, force_mb, force_kw, split_on, atomic_below, split_target, min_wgs_long, s2v;
 };
 static int env_or(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static RdTuning& rd_tuning() {
   static RdTuning t = {env_or("CAGC_RD", 1), env_or("CAGC_RD_MIN_WGS", 512), env_or("CAGC_RD_MB", 0), env_or("CAGC_RD_KW", 0),
                        env_or("CAGC_RD_SPLIT", 1), env_or("CAGC_RD_ATOMIC_BELOW", 160), env_or("CAGC_RD_SPLIT_WGS", 512),
-                       env_or("CAGC_RD_MIN_WGS_LONG", 768)};
+                       env_or("CAGC_RD_MIN_WGS_LONG", 768), env_or("CAGC_RD_S2V", 1)};
   return t;
 }
 
@@ -621,6 +743,19 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
                      kw, ks_max, (int)pad, (int)(a.in_scale != nullptr), (int)(a.gs != nullptr), r.items[0].lin, blocks * mtiles, a.Kp, a.Mp);
   }
   int rc;
+  {   // the stride-2 3x3 forward on its big layers: vector-operand kernel (k_conv_s2v)
+    bool s2v = tune.s2v != 0 && mb == 8 && T.rb == 8 && kw == 1 && ks_max == 1 && nitems == 1 && raw[0].ntaps == 9 && !pad && !a.in_scale && !a.out_scale && !a.gs &&
+               !a.noise && a.isx == 2 && a.isy == 2 && a.osx == 1 && a.osy == 1 && a.NPin == 1 && a.NPout == 1 && a.Wout % 4 == 0 &&
+               a.Wopitch == a.Wout && a.Wpitch % 4 == 0 && ((uintptr_t)a.in % 16 == 0) && ((uintptr_t)a.out % 16 == 0) && raw[0].vy_base == 0 &&
+               raw[0].vx_base == 0 && raw[0].Hv == a.Hout && raw[0].Wv == a.Wout && raw[0].out_plane == 0 && raw[0].ooy == 0 && raw[0].oox == 0 &&
+               (a.epi == CAGC_EPI_LINEAR || (a.epi == CAGC_EPI_STYLED && a.bias)) && a.Win >= 2 * a.Wout + 1 && r.KQ % 2 == 0;
+    for (int t = 0; s2v && t < 9; ++t) s2v = raw[0].taps[t].plane == 0 && raw[0].taps[t].dy == t / 3 && raw[0].taps[t].dx == t % 3 && raw[0].taps[t].widx == t;
+    if (s2v) {
+      r.nblocks = (int)cdiv((int64_t)a.B * a.Hout * a.Wout, CONV_NT); r.mtiles = mtiles;
+      hipLaunchKernelGGL(k_conv_s2v, dim3((unsigned)(r.nblocks * mtiles)), dim3(256), 0, st, r);
+      return check_launch(what);
+    }
+  }
   switch (mb) {
     case 1: rc = launch_rd<1>(r, pad, grid, st, what); break;
     case 2: rc = launch_rd<2>(r, pad, grid, st, what); break;
@@ -654,6 +789,7 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "rd_split")) t.split_on = value;
   else if (!strcmp(key, "rd_atomic_below")) t.atomic_below = value;
   else if (!strcmp(key, "rd_split_wgs")) t.split_target = value;
+  else if (!strcmp(key, "rd_s2v")) t.s2v = value;
   else if (!strcmp(key, "deterministic")) cagc::deterministic_mode() = value;
   else if (!strcmp(key, "wgrad_rd")) cagc::wgrad_rd_set_tuning(value, -1);
   else if (!strcmp(key, "wgrad_rd_wgs")) cagc::wgrad_rd_set_tuning(-1, value);
@@ -676,6 +812,7 @@ extern "C" int cagc_get_tuning(const char* key, int* value) {
   else if (!strcmp(key, "rd_split")) *value = t.split_on;
   else if (!strcmp(key, "rd_atomic_below")) *value = t.atomic_below;
   else if (!strcmp(key, "rd_split_wgs")) *value = t.split_target;
+  else if (!strcmp(key, "rd_s2v")) *value = t.s2v;
   else if (!strcmp(key, "deterministic")) *value = cagc::deterministic_mode();
   else if (!strcmp(key, "wgrad_rd")) *value = wm;
   else if (!strcmp(key, "wgrad_rd_wgs")) *value = wt;

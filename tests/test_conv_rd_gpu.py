@@ -86,6 +86,40 @@ def test_stride2_conv_forward_and_data_gradient(shape, tuning):
     assert rel(gx[..., :hb], gref) <= TOL, ("dgrad", tuning, shape, rel(gx[..., :hb], gref))
 
 
+# launches big enough (>= 512 workgroups of 128 channels x 256 pixels) for the vector-operand stride-2 kernel (k_conv_s2v): full tiles;
+# a ragged last tile + ragged channel count; rows shorter than a wave's 64 pixels (a wave spans 4 rows, a tile 2 images)
+S2V_SHAPES = [(4, 16, 256, 256), (5, 24, 250, 200), (256, 8, 256, 32)]
+
+
+@pytest.mark.parametrize("act", [False, True])
+@pytest.mark.parametrize("shape", S2V_SHAPES)
+def test_stride2_forward_vector_operand_kernel(shape, act):
+    B, cin, cout, H = shape
+    torch.manual_seed(13)
+    hb = H + 1
+    pitch = (hb + 3) // 4 * 4
+    ho = (hb - 3) // 2 + 1
+    w = torch.randn(cout, cin, 3, 3, device=DEV)
+    bias = torch.randn(cout, device=DEV)
+    scale = 1.0 / math.sqrt(cin * 9)
+    wp_fwd, _ = mc.pack_plain_weights(w, scale, True)
+    x = torch.randn(B, cin, hb, pitch, device=DEV)
+    ref = F.conv2d(x[..., :hb].double(), w.double() * scale, stride=2)
+    if act:
+        ref = F.leaky_relu(ref + bias.double().view(1, -1, 1, 1), 0.2) * math.sqrt(2.0)
+    outs = {}
+    for s2v in (1, 0):     # the general register-direct kernel computes the same launch: both against float64, and against each other
+        out = torch.full((B, cout, ho, ho), float("nan"), device=DEV)
+        with _lib.tuning(rd_s2v=s2v):
+            if act:
+                _lib.call("cagc_conv3x3s2_act_fwd", _lib.ptr(out), _lib.ptr(x), _lib.ptr(wp_fwd), _lib.ptr(bias), B, cin, cout, hb, hb, pitch, 0.2, math.sqrt(2.0))
+            else:
+                _lib.call("cagc_conv3x3s2_fwd", _lib.ptr(out), _lib.ptr(x), _lib.ptr(wp_fwd), B, cin, cout, hb, hb, pitch)
+        assert rel(out, ref) <= TOL, (s2v, shape, act, rel(out, ref))
+        outs[s2v] = out
+    assert torch.equal(outs[0], outs[1]), "same fp32 FMA chain per output (K order: channels, then taps row-major)"
+
+
 # (B, cin, cout, H): modulated transposed conv (phase-planar output) and its data gradient with the fused gs reduction
 UP_SHAPES = [(3, 20, 36, 5), (2, 77, 39, 16), (16, 154, 154, 4), (4, 154, 77, 8), (2, 512, 256, 32), (1, 256, 128, 64)]
 

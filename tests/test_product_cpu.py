@@ -136,7 +136,7 @@ def test_tuning_getters_and_wino_plan_are_host_side():
     bench.py attributes executed FLOPs with the latter instead of re-deriving the policy (advisor r3)."""
     from cagc import _lib
     lib = _lib.load()
-    for key in ("rd", "rd_min_wgs", "rd_min_wgs_long", "rd_mb", "rd_kw", "rd_split", "rd_atomic_below", "rd_split_wgs", "deterministic", "wgrad_rd",
+    for key in ("rd", "rd_min_wgs", "rd_min_wgs_long", "rd_mb", "rd_kw", "rd_split", "rd_atomic_below", "rd_split_wgs", "rd_s2v", "deterministic", "wgrad_rd",
                 "wgrad_rd_wgs", "wino4_hv", "wino4_min_wgs"):
         v = _lib.get_tuning(key)
         assert _lib.set_tuning(key, v) == v and _lib.get_tuning(key) == v
