@@ -166,7 +166,7 @@ class KernelTimer:
             elif name in ("cagc_wino_conv3x3", "cagc_wino_conv3x3_act_dgrad"):   # one record family per device kernel, so the
                 gated = name.endswith("act_dgrad")                              # average launch duration is comparable with the
                 nblk = -(-(args[6]) // 16)                                      # rocprofv3 per-symbol summary (conv_wino.hip wino_mb)
-                mb = nblk if nblk <= 3 else (3 if (nblk % 4 != 0 and nblk % 3 == 0) else 4)
+                mb = nblk if nblk <= 3 else (3 if -(-nblk // 3) * 3 < -(-nblk // 4) * 4 else 4)
                 # 4-wave (NH 1) or 8-wave (NH 2) workgroups: conv_wino.hip wino_nh()
                 Bq, K, Hq, Wq = (args[5], args[7], args[8], args[9]) if gated else (args[4], args[5], args[7], args[8])
                 wgs2 = Bq * (Wq // 32) * (Hq // 8) * -(-args[6] // (mb * 16))

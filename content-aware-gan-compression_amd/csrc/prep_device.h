@@ -171,8 +171,7 @@ __device__ __forceinline__ void wino4_pack_elem(float* __restrict__ up, const fl
 inline int wino_mb(int M) {
   const int nblk = cdiv(M, 16);
   if (nblk <= 3) return nblk;
-  if (nblk % 4 != 0 && nblk % 3 == 0) return 3;
-  return 4;
+  return cdiv(nblk, 3) * 3 < cdiv(nblk, 4) * 4 ? 3 : 4;     // e.g. 77 channels = 5 blocks: 3 + 2 (one zero block) instead of 4 + 1 (three)
 }
 inline int64_t wino2_packed_elems(int K, int M) { return (int64_t)cdiv(M, wino_mb(M) * 16) * 16 * wino_kp(K) * 64; }
 inline int64_t wino_packed_total(int K, int M) {

@@ -326,6 +326,124 @@ __global__ __launch_bounds__(256) void k_fir4_vec(float* __restrict__ out, const
   }
 }
 
+// Row-streaming form of the 4x4 FIR for the large blurs (no LDS, no barrier): a thread owns 4 adjacent output columns of a strip of R
+// output rows and walks down it; every input row is three aligned 16-byte buffer loads (columns ox-4 .. ox+7: the 7-column window of
+// its outputs for any pad_x0 in [0, 4]; the neighbours' loads hit the same lines in L1) whose out-of-image rows / columns are
+// out-of-range offsets (the descriptor returns the padding zero).  The next four rows' loads are in flight while the current four
+// output rows are computed from a register window: the tiled kernel above holds ~40 KB in flight per CU between its barriers, this one
+// several times the ~60 KB that HBM latency x bandwidth asks for.
+template <int PX>
+__global__ __launch_bounds__(256) void k_fir4_rows(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ kern,
+                                                   int64_t planes, int in_h, int in_w, int in_pitch, int out_h, int out_w,
+                                                   int out_pitch, int pad_y0, int ncg, int chunks, int R) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cg = (int)(gid % ncg);
+  const int64_t rest = gid / ncg;
+  const int chunk = (int)(rest % chunks);
+  const int64_t p = rest / chunks;
+  if (p >= planes) return;
+  float kf[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) kf[t] = kern[(3 - t / 4) * 4 + (3 - t % 4)];     // uniform address: scalar loads
+  const int ox = 4 * cg;
+  const int y0 = chunk * R, y1 = min(y0 + R, out_h);
+  const int64_t plane_elems = (int64_t)in_h * in_pitch;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(planes * plane_elems * 4), 0x00020000);
+  constexpr unsigned OOR = 0x80000000u;
+  // per-thread column offsets of the three float4 (bytes inside a row), or out of range
+  unsigned cb[3];
+  int nval[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int c = ox - 4 + 4 * q;
+    const bool ok = c >= 0 && c < in_w;             // c + 3 < in_pitch: pitch % 4 == 0
+    cb[q] = ok ? (unsigned)c * 4u : OOR;
+    nval[q] = in_w - c;                             // components below this index are image columns (pitch padding is not trusted)
+  }
+  const unsigned pbase = (unsigned)(p * plane_elems * 4);
+  struct Row { float v[12]; };
+  auto load_row = [&](Row& Rw, const int iy) {
+    const bool rok = iy >= 0 && iy < in_h;
+    const unsigned rb = pbase + (unsigned)iy * (unsigned)in_pitch * 4u;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const unsigned off = (rok && cb[q] != OOR) ? rb + cb[q] : OOR;
+      const float4 f = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+      Rw.v[4 * q] = f.x; Rw.v[4 * q + 1] = f.y; Rw.v[4 * q + 2] = f.z; Rw.v[4 * q + 3] = f.w;
+    }
+  };
+  const bool ragged = (in_w & 3) != 0;              // uniform
+  auto mask_row = [&](Row& Rw) {
+    if (ragged) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (nval[q] < 4) {
+          if (nval[q] < 2) Rw.v[4 * q + 1] = 0.f;
+          if (nval[q] < 3) Rw.v[4 * q + 2] = 0.f;
+          Rw.v[4 * q + 3] = 0.f;
+        }
+      }
+    }
+  };
+  auto emit = [&](const Row& a, const Row& b, const Row& c, const Row& d, const int oy) {
+    if (oy >= y1) return;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    const Row* rows[4] = {&a, &b, &c, &d};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float k = kf[i * 4 + j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += rows[i]->v[4 - PX + j + e] * k;
+      }
+    const float4 ov = make_float4(ox < out_w ? o[0] : 0.f, ox + 1 < out_w ? o[1] : 0.f, ox + 2 < out_w ? o[2] : 0.f, ox + 3 < out_w ? o[3] : 0.f);
+    *reinterpret_cast<float4*>(out + (p * out_h + oy) * (int64_t)out_pitch + ox) = ov;      // pitch padding written as zero
+  };
+  Row r0, r1, r2, n0, n1, n2, n3, m0, m1, m2, m3;
+  const int iy0 = y0 - pad_y0;
+  load_row(r0, iy0); load_row(r1, iy0 + 1); load_row(r2, iy0 + 2);
+  load_row(n0, iy0 + 3); load_row(n1, iy0 + 4); load_row(n2, iy0 + 5); load_row(n3, iy0 + 6);
+  mask_row(r0); mask_row(r1); mask_row(r2);
+  for (int oy = y0; oy < y1; oy += 4) {
+    const int iyn = oy - pad_y0 + 7;
+    load_row(m0, iyn); load_row(m1, iyn + 1); load_row(m2, iyn + 2); load_row(m3, iyn + 3);     // next group's rows in flight
+    mask_row(n0); mask_row(n1); mask_row(n2); mask_row(n3);
+    emit(r0, r1, r2, n0, oy);
+    emit(r1, r2, n0, n1, oy + 1);
+    emit(r2, n0, n1, n2, oy + 2);
+    emit(n0, n1, n2, n3, oy + 3);
+    r0 = n1; r1 = n2; r2 = n3;
+    n0 = m0; n1 = m1; n2 = m2; n3 = m3;
+  }
+}
+
+// rows per thread strip of k_fir4_rows: ~32, a multiple of 4, strips of near-equal height
+static bool fir4_rows_plan(int64_t planes, int in_h, int in_pitch, int out_h, int out_w, int out_pitch, int pad_x0, const void* x, const void* out,
+                           int* chunks, int* R) {
+  if (!(in_pitch % 4 == 0 && out_pitch % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0)) return false;
+  if (out_h < 32 || out_w < 32) return false;
+  if (planes * (int64_t)in_h * in_pitch * 4 > 0x7fffffffll) return false;       // one descriptor over the whole input
+  int c = (out_h + 16) / 32;
+  if (c < 1) c = 1;
+  *chunks = c;
+  *R = (cdiv(out_h, c) + 3) & ~3;
+  *chunks = cdiv(out_h, *R);
+  return true;
+}
+static int launch_fir4_rows(float* out, const float* x, const float* kernel, int64_t planes, int in_h, int in_w, int in_pitch, int out_h,
+                            int out_w, int out_pitch, int pad_x0, int pad_y0, int chunks, int R, hipStream_t st) {
+  const int ncg = out_pitch / 4;
+  const int64_t threads = planes * chunks * ncg;
+  const int64_t nb = (threads + 255) / 256;
+  if (nb >= (1ll << 31)) return -1;
+#define CAGC_FIR_ROWS(P_) case P_: hipLaunchKernelGGL(k_fir4_rows<P_>, dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, planes, in_h, in_w, in_pitch, out_h, out_w, out_pitch, pad_y0, ncg, chunks, R); break;
+  switch (pad_x0) { CAGC_FIR_ROWS(0) CAGC_FIR_ROWS(1) CAGC_FIR_ROWS(2) CAGC_FIR_ROWS(3) CAGC_FIR_ROWS(4) default: return -1; }
+#undef CAGC_FIR_ROWS
+  return 0;
+}
+static int fir_rows_on() { static const int v = getenv("CAGC_FIR_ROWS") ? atoi(getenv("CAGC_FIR_ROWS")) : 1; return v; }
+
 // ---------------------------------------------------------------------------------------------------
 // blur after the transposed conv, phase-planar input.  T_full[Y,X] = t[plane 2*(Y&1)+(X&1)][Y>>1][X>>1].
 // out[Y,X] = sum_{a,b} kf[a][b] * T_full[Y-1+a, X-1+b],  Y in [0,2H), kf = flipped fir.
@@ -683,7 +801,11 @@ extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, i
     const int tx = cdiv(out_w, FT), ty = cdiv(out_h, FT);
     const int64_t nb = planes * tx * ty;
     CAGC_REQUIRE(nb < (1ll << 31), "cagc_upfirdn2d: too large");
-    if (in_w % 4 == 0 && out_w % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0) {
+    int chunks, R;
+    if (in_w % 4 == 0 && out_w % 4 == 0 && fir_rows_on() && fir4_rows_plan(planes, in_h, in_w, out_h, out_w, out_w, pad_x0, x, out, &chunks, &R) &&
+        launch_fir4_rows(out, x, kernel, planes, in_h, in_w, in_w, out_h, out_w, out_w, pad_x0, pad_y0, chunks, R, st) == 0) {
+      // row-streaming kernel
+    } else if (in_w % 4 == 0 && out_w % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0) {
       const int ty2 = cdiv(out_h, 2 * FT);
       if (fir_w64() == 2 && out_w >= 64) {   // measured neutral-to-worse (1.134 vs 1.119 ms/step): opt-in only (CAGC_BLUR_W64=2)
         const int tx64 = cdiv(out_w, 64);
@@ -773,6 +895,12 @@ extern "C" int cagc_fir4x4_pitched(float* out, const float* x, const float* kern
   const int tx = cdiv(out_pitch, FT), ty = cdiv(out_h, FT);
   const int64_t nb = planes * tx * ty;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_fir4x4_pitched: too large");
+  {
+    int chunks, R;
+    if (fir_rows_on() && fir4_rows_plan(planes, in_h, in_pitch, out_h, out_w, out_pitch, pad_x0, x, out, &chunks, &R) &&
+        launch_fir4_rows(out, x, kernel, planes, in_h, in_w, in_pitch, out_h, out_w, out_pitch, pad_x0, pad_y0, chunks, R, as_stream(stream)) == 0)
+      return check_launch("cagc_fir4x4_pitched");
+  }
   if (in_pitch % 4 == 0 && out_pitch % 4 == 0 && pad_x0 >= 0 && pad_x0 <= 4 && ((uintptr_t)x | (uintptr_t)out) % 16 == 0) {
     const int ty2 = cdiv(out_h, 2 * FT);
     if (fir_w64() == 2 && out_pitch >= 64) {
