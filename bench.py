@@ -111,7 +111,7 @@ KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false, false", "c
              "cagc_wino_conv3x3[k_wino4<false>]": "k_wino4<false,", "cagc_wino_conv3x3_act_dgrad[k_wino4<true>]": "k_wino4<true,",   # both SCALE variants
              "cagc_modconv_fwd": "k_conv_rd<4, true, true, false>",
              "cagc_modconv_up_fwd": "k_conv_rd<8, true, true, false>",
-             "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_act_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_dgrad": "k_conv_rd<8, true, false, false>",
+             "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_act_fwd": "k_conv_s2v", "cagc_conv3x3s2_dgrad": "k_conv_rd<8, true, false, false>",
              "cagc_modconv_dgrad": "k_conv_rd<5, true, false, true>",
              "cagc_modconv_up_dgrad": "k_conv_rd<5, true, false, true>", "cagc_modconv_wgrad": "k_wgrad_rd<4, 1, false, 9>",
              "cagc_modconv_wgrad_demod": "k_wgrad_rd<3, 1, false, 9>"}

@@ -1,4 +1,6 @@
-"""Timing of the 4x4 FIR passes of the discriminator (cagc_fir4x4_pitched) at the bench shapes; A/B: CAGC_FIR_ROWS=0 (tiled LDS kernel)."""
+"""Timing of the 4x4 FIR passes of the discriminator (cagc_fir4x4_pitched) and of the blur behind the transposed conv (cagc_blur_up_fwd) at
+the bench shapes; A/B for the former: CAGC_FIR_ROWS=0 (tiled LDS kernel).  A row-streaming cagc_blur_up_fwd was measured with the second
+half of this script and not kept (0.776 vs 0.741 ms over these shapes)."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "content-aware-gan-compression_amd")]
@@ -19,4 +21,16 @@ for (planes, ih, iw, ip, oh, ow, op, pad) in [(2048, 256, 256, 256, 257, 257, 26
     by = 4.0 * planes * (ih * iw + oh * ow)
     tot += t
     print(f"planes {planes} {ih}x{iw}/{ip} -> {oh}x{ow}/{op}: {t*1e6:7.1f} us  {by/t/1e12:5.2f} TB/s")
+print(f"sum {tot*1e3:.3f} ms")
+print("cagc_blur_up_fwd (styled epilogue: d, per-image noise, bias, lrelu)")
+tot = 0.0
+fir = k.flatten().contiguous()
+for (B, C, H) in [(16, 128, 128), (16, 256, 64), (16, 39, 128), (16, 512, 32), (16, 77, 64), (16, 154, 32), (2, 128, 128), (2, 512, 32)]:
+    W = H; P = (W + 1 + 3) & ~3
+    t_ = torch.randn(B, C, 4, H + 1, P, device="cuda"); out = torch.empty(B, C, 2 * H, 2 * W, device="cuda")
+    d = torch.rand(B, C, device="cuda"); nz = torch.randn(B, 1, 2 * H, 2 * W, device="cuda"); nw = torch.ones(1, device="cuda"); bias = torch.randn(C, device="cuda")
+    tm = timeit(lambda: _lib.call("cagc_blur_up_fwd", _lib.ptr(out), _lib.ptr(t_), _lib.ptr(fir), _lib.ptr(d), _lib.ptr(nz), B, _lib.ptr(nw), _lib.ptr(bias), B, C, H, W, 0.2, 1.4142135))
+    by = 4.0 * B * C * (4 * (H + 1) * (W + 1) + 4 * H * W)
+    tot += tm
+    print(f"B {B} C {C} H {H}: {tm*1e6:7.1f} us  {by/tm/1e12:5.2f} TB/s")
 print(f"sum {tot*1e3:.3f} ms")
