@@ -34,3 +34,6 @@ for (name, key), (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     if ms / N * 1e3 < thr: continue
     tf = f"{fl / (ms * 1e-3) / 1e12:6.1f} TF" if fl > 0 else "        "
     print(f"{name:26s} {str(key):44s} x{cnt // N:2d}  {us:8.1f} us each  {ms / N:7.3f} ms/step  {tf}")
+if os.environ.get("DUMP"):      # machine-readable: {"entry point (shape)": [launches per step, ms per step, flops per step]}
+    import json
+    json.dump({f"{name} {key}": [cnt / N, ms / N, fl / N] for (name, key), (cnt, ms, fl) in agg.items()}, open(os.environ["DUMP"], "w"))
