@@ -694,8 +694,9 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
   // K split across workgroups for launches that cannot fill the chip otherwise.  FORWARD launches (a.fwd_slabs): every K slice writes its
   // partial tile to its own slab of a library scratch and an ordered reduce finishes it — activations are bit-reproducible in every
   // mode, so LeakyReLU gates (and with them gradients at the parity bar) repeat run to run.  Data-gradient launches: fp32 atomics on the
-  // pre-zeroed output (default mode; their noise is linear in the gradient, 1e-7) or no split at all (deterministic mode).
-  const bool slabs = a.fwd_slabs != 0 && !a.gs;
+  // pre-zeroed output in the default mode (their noise is linear in the gradient, 1e-7); in deterministic mode slabs as well — the fused
+  // style-gradient sums (gs) of the slices are linear in the partial sums and go through the order-independent sink either way.
+  const bool slabs = (a.fwd_slabs != 0 && !a.gs) || deterministic_mode();
   const int atomic_below = (deterministic_mode() && !slabs) ? 0 : tune.atomic_below;
   if ((int64_t)blocks * mtiles < atomic_below) {
     if (!split_on) return CAGC_RD_DECLINED;

@@ -19,7 +19,7 @@
  *     allocates", both library-owned scratches kept per (device, stream), obtained with hipMalloc on first use (also
  *     under stream capture, relaxed mode), grown by allocating a new block and never freed before process exit
  *     (earlier launches / captured graphs may still reference the old one), in a mutex-guarded table:
- *       (a) every mode: the K-split slabs of FORWARD convolution launches — a small layer whose reduction is cut across
+ *       (a) every mode: the K-split slabs of FORWARD convolution launches (deterministic mode: of the data-gradient launches too) — a small layer whose reduction is cut across
  *           workgroups writes one partial-sum slab per slice and an ordered reduce adds them (bit-reproducible
  *           activations; no fp32 atomics in any forward pass); >= 4 MB, the largest split output x its slices
  *           (< 32 MB on this path; a launch that would need > 256 MB falls back to not splitting);
@@ -69,10 +69,10 @@ const char* cagc_last_error(void);
  * only), "wgrad_rd_wgs" (workgroups a weight-gradient launch aims at; 0 = its launch model picks the K split, the default) — csrc/conv_wgrad_rd.hip; "wino4_hv" (0 per launch, 1 / 2: 64- / 128-channel workgroup shape of the F(4x4) kernel),
  * "wino4_min_wgs" (64-channel workgroups below which a launch takes the layer's F(2x2) packing; default 256) — csrc/conv_wino4.hip;
  * "deterministic" (also CAGC_DETERMINISTIC=1): forward passes are bit-reproducible run to run in EVERY mode (K splits through
- * ordered slabs); this key additionally removes the fp32-atomic K split from the data-gradient launches and routes the backward
+ * ordered slabs); this key additionally moves the data-gradient launches' K split from fp32 atomics to the same slabs and routes the backward
  * reductions (grad-bias / styled-epilogue / style / ToRGB weight sums, L1 loss) through an order-independent fixed-point sink on a
  * library-owned per-stream scratch — gradients become bit-reproducible too (default mode: they repeat to ~1e-6 of their scale,
- * fp32 summation order only; deterministic costs ~1 % at batch 16, ~7 % at per-GPU batch 2).  The same knobs are read from CAGC_RD* at first use. */
+ * fp32 summation order only; deterministic costs ~1 % at batch 16, ~2 % at per-GPU batch 2).  The same knobs are read from CAGC_RD* at first use. */
 int cagc_set_tuning(const char* key, int value);
 /* Current value of a tuning key (same keys); CAGC_ERR_INVALID for an unknown key. */
 int cagc_get_tuning(const char* key, int* value);
