@@ -7,8 +7,10 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KNOBS = {"CAGC_RD_MIN_WGS": [256, 512, 768, 1024], "CAGC_RD_ATOMIC_BELOW": [0, 160, 320], "CAGC_RD_SPLIT_WGS": [192, 320, 512],
-         "CAGC_WINO4_MIN_WGS": [128, 256, 512], "CAGC_WGRAD_RD_WGS": [384, 768, 1536]}
+KNOBS = {"CAGC_RD_MIN_WGS": [256, 512, 768, 1024], "CAGC_RD_ATOMIC_BELOW": [0, 96, 160, 320], "CAGC_RD_SPLIT_WGS": [256, 512, 768],
+         "CAGC_WINO4_MIN_WGS": [128, 256, 512], "CAGC_WGRAD_RD_WGS": [256, 384, 768]}       # WGRAD_RD_WGS default 0 = the launch model
+if os.environ.get("SWEEP_KNOBS"):      # e.g. SWEEP_KNOBS=CAGC_RD_ATOMIC_BELOW,CAGC_RD_SPLIT_WGS
+    KNOBS = {k: v for k, v in KNOBS.items() if k in os.environ["SWEEP_KNOBS"].split(",")}
 
 
 def run(env_extra, bs):
