@@ -133,12 +133,16 @@ inline bool wino4_for_launch(int K, int M, int B, int H, int W) {
   return wino_use_f4(K, M) && (int64_t)B * (H / 8) * (W / 32) * cdiv(M, 64) >= wino4_min_wgs();
 }
 
+// Storage slot of Winograd position (i, j): row-major over i, and inside a row the columns in the order 1 2 3 4 0 5 — the input
+// transform's packed results (V[i][1], V[i][2]), (V[i][3], V[i][4]), (V[i][0], V[i][5]) are then three aligned 8-byte LDS writes
+// (conv_wino4.hip).  The same order indexes the packed weights and the kernel's accumulators.
+__host__ __device__ constexpr int wino4_slot(int i, int j) { return 6 * i + (j == 0 ? 4 : (j == 5 ? 5 : j - 1)); }
+
 // U[pos=(i,j)][k][m] = scale * (G g G^T)[i][j], G the 6x3 matrix of F(4,3) (interpolation points 0, +-1, +-2, inf); stored in
-// MFMA A-operand order  up[tile of 64 channels][pos 36][K/4][lane = (k%4, m%16)][4 channel blocks];  idx over [tiles][Kp/4][64][4]
+// MFMA A-operand order  up[tile of 64 channels][channel block 4][slot group 9][K/4][lane = (k%4, m%16)][4 slots]: the wave that
+// owns a channel block feeds one 16-byte load to four MFMAs (four positions of one K-step);  idx over [tiles][Kp/4][64][4 blocks]
 __device__ __forceinline__ void wino4_pack_elem(float* __restrict__ up, const float* __restrict__ w, int64_t idx, int Cout, int Cin,
                                                 int Kp, float scale, int dgrad) {
-  // per (tile, pos, K/4 group): [lane 64][4 blocks] — the 4 blocks of a lane that ONE wave feeds to the MFMAs are 16 contiguous
-  // bytes and a wave's 64 lanes read one contiguous KB
   const int b4 = (int)(idx & 3), ln = (int)((idx >> 2) & 63);
   const int kq = (int)((idx >> 8) % (Kp / 4)), mt = (int)((idx >> 8) / (Kp / 4));
   const int k = 4 * kq + (ln >> 4), m = mt * 64 + b4 * 16 + (ln & 15);
@@ -159,12 +163,15 @@ __device__ __forceinline__ void wino4_pack_elem(float* __restrict__ up, const fl
   for (int i = 0; i < 6; ++i)
 #pragma unroll
     for (int bb = 0; bb < 3; ++bb) t[i][bb] = G[i][0] * gk[0][bb] + G[i][1] * gk[1][bb] + G[i][2] * gk[2][bb];
-  const int64_t ps = (int64_t)(Kp / 4) * 256;                                   // stride between positions
-  float* dst = up + ((int64_t)mt * 36 * (Kp / 4) + kq) * 256 + ln * 4 + b4;
+  const int64_t gs = (int64_t)(Kp / 4) * 256;                                   // stride between slot groups
+  float* dst = up + ((int64_t)(mt * 4 + b4) * 9 * (Kp / 4) + kq) * 256 + ln * 4;
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * ps] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+    for (int j = 0; j < 6; ++j) {
+      const int n = wino4_slot(i, j);
+      dst[(n >> 2) * gs + (n & 3)] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+    }
 }
 
 // channel blocks (of 16) per Winograd workgroup tile for M output channels: 4, or fewer when that wastes less of the last tile

@@ -7,6 +7,7 @@ if len(sys.argv) > 1:
 from cagc.op import modconv as mc
 B, C, H = int(os.environ.get("B", 16)), int(os.environ.get("C", 512)), int(os.environ.get("H", 64))
 x = torch.randn(B, C, H, H, device="cuda"); w = torch.randn(C, C, 3, 3, device="cuda")
+if os.environ.get("ZERO") == "1": x.zero_(); w.zero_()     # same instruction stream on zero operands: what the matrix pipe's power limit costs
 up = mc.pack_wino(w, 0.01, False); out = torch.empty_like(x)
 def run():
     _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(x), _lib.ptr(up), None, B, C, C, H, H, 0, None, None, 0, None, None, 0.2, 1.0)
@@ -15,4 +16,8 @@ torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(10): run()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
 fl = 2.0 * B * C * C * 9 * H * H
+if os.environ.get("CLK") == "1":      # -DCAGC_W4_CLK builds: per-workgroup shader clock in out[0 .. workgroups)
+    nwg = B * (H // 8) * (H // 32) * (C // 128)
+    c = out.flatten()[:nwg].float().cpu()
+    print(f"shader clock MHz under this kernel: median {c.median():.0f} min {c.min():.0f} max {c.max():.0f} over {nwg} workgroups")
 print(sys.argv[1:] or "default", (B, C, H), f"{dt*1e3:.3f} ms  direct-equiv {fl/dt/1e12:.1f} TF  mfma {fl*4/9/dt/1e12:.1f} TF")

@@ -1,0 +1,18 @@
+"""Run ON THE GPU BOX: python scripts/time_wino_libs.py lib1.so lib2.so ... — one process per (library, shape) of scripts/time_wino.py,
+interleaved so that every library sees the same clocks; prints a table (ms)."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+shapes = [(16, 512, 64), (16, 256, 128), (16, 128, 256), (16, 512, 32)] if not os.environ.get("SHAPES") else \
+    [tuple(int(v) for v in s.split(",")) for s in os.environ["SHAPES"].split(";")]
+res = {}
+for rep in range(int(os.environ.get("REPS", 2))):
+    for (B, C, H) in shapes:
+        for lib in sys.argv[1:]:
+            env = dict(os.environ, B=str(B), C=str(C), H=str(H))
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_wino.py"), lib], env=env, capture_output=True, text=True).stdout
+            ms = float(out.split(") ")[-1].split(" ms")[0]) if " ms" in out else float("nan")
+            res.setdefault((lib, (B, C, H)), []).append(ms)
+print("| library | " + " | ".join(f"B{B} C{C} H{H}" for (B, C, H) in shapes) + " |")
+print("|---|" + "---|" * len(shapes))
+for lib in sys.argv[1:]:
+    print(f"| {lib} | " + " | ".join(f"{min(res[(lib, s)]):.3f}" for s in shapes) + " |")
