@@ -22,6 +22,7 @@ struct WinoArgs {
   int epi, noise_bstride_on;
   int wg_map;              // workgroup -> tile mapping, see k_wino
   float alpha, act_scale;
+  float* clk;              // F(4x4) only: cagc_set_clock_probe accumulator or null
 };
 
 // F(4x4,3x3) kernel (conv_wino4.hip): H % 8 == 0, W % 32 == 0; `up` packed by wino4_pack_elem (64-channel tiles)

@@ -357,6 +357,12 @@ int cagc_wino_eligible(int H, int W);
  * swaps the layer's Cin / Cout) takes under the current tuning: 0 = not eligible, 2 = F(2x2,3x3), 4 = F(4x4,3x3).  Benchmarks
  * use it to attribute executed FLOPs to the kernel that really ran. */
 int cagc_wino_plan(int B, int K, int M, int H, int W);
+/* Diagnostic (benchmarks): while `acc` is non-null, workgroup 0 of every F(4x4) Winograd launch adds the shader clock it
+ * measured over its own lifetime (MHz: s_memtime ticks per 100 MHz s_memrealtime tick) to acc[0] and 1 to acc[1] — two device
+ * floats the caller owns and zeroes.  Process-wide, not synchronised with launches in flight; pass NULL to stop.  The fp32
+ * matrix pipe's 157.3 TFLOP/s is quoted at 2.4 GHz; under real operands this kernel holds ~2.0 GHz at the board's power limit
+ * (2.35 GHz on all-zero operands, same instruction stream), so its ceiling is ~132 TFLOP/s — DESIGN.md §5. */
+int cagc_set_clock_probe(float* acc);
 int64_t cagc_wino_packed_elems(int K, int M);
 int cagc_wino_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad, cagc_stream_t stream);
 int cagc_wino_conv3x3(float* out, const float* x, const float* up, const float* s, int B, int Cin, int Cout, int H,

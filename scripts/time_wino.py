@@ -16,8 +16,9 @@ torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(10): run()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
 fl = 2.0 * B * C * C * 9 * H * H
-if os.environ.get("CLK") == "1":      # -DCAGC_W4_CLK builds: per-workgroup shader clock in out[0 .. workgroups)
-    nwg = B * (H // 8) * (H // 32) * (C // 128)
-    c = out.flatten()[:nwg].float().cpu()
-    print(f"shader clock MHz under this kernel: median {c.median():.0f} min {c.min():.0f} max {c.max():.0f} over {nwg} workgroups")
+clk = torch.zeros(2, device="cuda")
+_lib.load().cagc_set_clock_probe(ctypes.c_void_p(clk.data_ptr()))
+for _ in range(5): run()
+torch.cuda.synchronize(); _lib.load().cagc_set_clock_probe(None)
+print(f"shader clock under this kernel: {float(clk[0] / clk[1].clamp(min=1)):.0f} MHz")
 print(sys.argv[1:] or "default", (B, C, H), f"{dt*1e3:.3f} ms  direct-equiv {fl/dt/1e12:.1f} TF  mfma {fl*4/9/dt/1e12:.1f} TF")

@@ -11,8 +11,9 @@ for rep in range(int(os.environ.get("REPS", 2))):
             env = dict(os.environ, B=str(B), C=str(C), H=str(H))
             out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_wino.py"), lib], env=env, capture_output=True, text=True).stdout
             ms = float(out.split(") ")[-1].split(" ms")[0]) if " ms" in out else float("nan")
-            res.setdefault((lib, (B, C, H)), []).append(ms)
+            mhz = int(out.split("this kernel: ")[1].split(" MHz")[0]) if "this kernel: " in out else 0
+            res.setdefault((lib, (B, C, H)), []).append((ms, mhz))
 print("| library | " + " | ".join(f"B{B} C{C} H{H}" for (B, C, H) in shapes) + " |")
 print("|---|" + "---|" * len(shapes))
 for lib in sys.argv[1:]:
-    print(f"| {lib} | " + " | ".join(f"{min(res[(lib, s)]):.3f}" for s in shapes) + " |")
+    print(f"| {lib} | " + " | ".join("%.3f @%d MHz" % min(res[(lib, s)]) for s in shapes) + " |")

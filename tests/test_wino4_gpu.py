@@ -83,3 +83,31 @@ def test_wino4_gated_data_gradient(shape, hv):
     assert rel(gx, ref) <= BAR, ("gated dgrad", shape, rel(gx, ref))
     _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(gg), _lib.ptr(ag), _lib.ptr(upb), _lib.ptr(rg), B, cin, cout, H, W, 0.2, 2 ** 0.5)
     assert rel(gx, ref + res.double()) <= BAR, ("gated dgrad + residual", shape)
+
+
+def test_clock_probe_reports_the_shader_clock_and_leaves_results_alone():
+    """include/cagc.h cagc_set_clock_probe (bench.py roofline.shader_clock_mhz_in_k_wino4): workgroup 0 of every F(4x4) launch adds
+    its measured shader clock to a caller-owned accumulator; the output is bit-identical with and without the probe."""
+    import ctypes
+    B, C, H, W = 2, 128, 32, 64
+    torch.manual_seed(7)
+    x, w = torch.randn(B, C, H, W, device=DEV), torch.randn(C, C, 3, 3, device=DEV)
+    up = mc.pack_wino(w, 0.03, False)
+    out0, out1 = torch.empty_like(x), torch.empty_like(x)
+    run = lambda o: _lib.call("cagc_wino_conv3x3", _lib.ptr(o), _lib.ptr(x), _lib.ptr(up), None, B, C, C, H, W, 0, None, None, 0, None, None, 0.2, 1.0)
+    with _lib.tuning(wino4_min_wgs=0):
+        run(out0)
+        acc = torch.zeros(2, device=DEV)
+        lib = _lib.load()
+        assert lib.cagc_set_clock_probe(ctypes.c_void_p(acc.data_ptr())) == 0
+        try:
+            for _ in range(3):
+                run(out1)
+            torch.cuda.synchronize()
+        finally:
+            assert lib.cagc_set_clock_probe(None) == 0
+        run(out1)                                    # probe off again: the accumulator no longer moves
+        torch.cuda.synchronize()
+    n, mhz = float(acc[1]), float(acc[0] / acc[1])
+    assert n == 3.0 and 500.0 < mhz < 3000.0, (n, mhz)
+    assert torch.equal(out0, out1)
