@@ -359,9 +359,11 @@ int cagc_wino_eligible(int H, int W);
 int cagc_wino_plan(int B, int K, int M, int H, int W);
 /* Diagnostic (benchmarks): while `acc` is non-null, workgroup 0 of every F(4x4) Winograd launch adds the shader clock it
  * measured over its own lifetime (MHz: s_memtime ticks per 100 MHz s_memrealtime tick) to acc[0] and 1 to acc[1] — two device
- * floats the caller owns and zeroes.  Process-wide, not synchronised with launches in flight; pass NULL to stop.  The fp32
- * matrix pipe's 157.3 TFLOP/s is quoted at 2.4 GHz; under real operands this kernel holds ~2.0 GHz at the board's power limit
- * (2.35 GHz on all-zero operands, same instruction stream), so its ceiling is ~132 TFLOP/s — DESIGN.md §5. */
+ * floats the caller owns and zeroes.  Process-wide, not synchronised with launches in flight; pass NULL to stop.  Workgroup 0 is
+ * the START of a launch: the figure is the clock the launch was given, before the power controller reacts to it.  Measured
+ * (DESIGN.md §5): the fp32 matrix pipe's 157.3 TFLOP/s is quoted at 2.4 GHz; launched back to back on real operands this kernel
+ * settles at 2.00-2.07 GHz at the board's power limit (2.35 GHz on all-zero operands, same instruction stream); between the
+ * other kernels of an eagerly launched KD step its launches start at ~2.30 GHz. */
 int cagc_set_clock_probe(float* acc);
 int64_t cagc_wino_packed_elems(int K, int M);
 int cagc_wino_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad, cagc_stream_t stream);
