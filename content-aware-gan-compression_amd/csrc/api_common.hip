@@ -127,3 +127,13 @@ float* ksplit_scratch(size_t bytes, hipStream_t st, const char* what) {
 }
 }  // namespace cagc
 extern "C" const char* cagc_arch(void) { return "gfx950"; }
+
+namespace cagc {
+static float* g_clock_probe = nullptr;     // diagnostic; process-wide (include/cagc.h cagc_set_clock_probe)
+float* clock_probe_ptr() { return g_clock_probe; }
+}  // namespace cagc
+
+extern "C" int cagc_set_clock_probe(float* acc) {
+  cagc::g_clock_probe = acc;
+  return CAGC_OK;
+}

@@ -81,4 +81,17 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
+// cagc_set_clock_probe (include/cagc.h): the caller's two-float accumulator or null; kernels that carry the probe add the shader
+// clock their workgroup 0 measured over its lifetime (MHz) to [0] and 1 to [1]
+float* clock_probe_ptr();
+__device__ __forceinline__ void clock_probe_begin(const float* acc, long long& c0, long long& w0) {
+  if (acc != nullptr && blockIdx.x == 0) { c0 = clock64(); w0 = wall_clock64(); }
+}
+__device__ __forceinline__ void clock_probe_end(float* acc, const long long c0, const long long w0) {
+  if (acc != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long dc = clock64() - c0, dw = wall_clock64() - w0;       // shader-clock ticks / 100 MHz ticks
+    if (dw > 0) { atomicAdd(acc, (float)dc / (float)dw * 100.f); atomicAdd(acc + 1, 1.f); }
+  }
+}
+
 }  // namespace cagc

@@ -68,6 +68,7 @@ struct RdArgs {
   int epi, noise_bstride_on;
   unsigned wp_bytes;
   float alpha, act_scale;
+  float* clk;                    // cagc_set_clock_probe accumulator or null
   RdItem items[MAX_ITEMS];
 };
 
@@ -184,7 +185,7 @@ __device__ __forceinline__ void rd_main(const RdArgs& A, const RdItem& I, f32x4 
 }
 
 template <int MB, bool PAD, bool SCALE, bool GS>
-__global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
+__device__ __forceinline__ void conv_rd_body(const RdArgs& A) {
   constexpr int MT = MB * 16;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -383,6 +384,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
   }
 }
 
+template <int MB, bool PAD, bool SCALE, bool GS>
+__global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
+  long long c0 = 0, w0 = 0;
+  clock_probe_begin(A.clk, c0, w0);
+  conv_rd_body<MB, PAD, SCALE, GS>(A);       // (its early returns — K-split paths — come back here)
+  clock_probe_end(A.clk, c0, w0);
+}
+
 // ---- stride-2 3x3 forward, vector-operand form (the discriminator's `Blur -> 3x3 stride 2` on its big layers) -----------------
 // The general kernel above feeds every MFMA's B operand with its own 4-byte load: 12 loads per (K-step, input row) for the 3 taps x 4
 // pixel blocks of a wave.  Here a lane owns FOUR CONSECUTIVE output pixels ox0 .. ox0+3 of one row — pixel block j of the wave is
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
 // — register names, no VALU.  3 B loads + 6 A loads per 96 MFMAs instead of 12 + 6, and the epilogue stores 16 bytes per lane.
 // Same packed weights, same descriptors-as-padding idea, same XCD-aware workgroup map; launches the plan routes here: one 9-tap item,
 // MB = 8, no K split, no padding taps, Wout % 4 == 0, 16-byte aligned rows.
-__global__ __launch_bounds__(256, 2) void k_conv_s2v(const RdArgs A) {
+__device__ __forceinline__ void conv_s2v_body(const RdArgs& A) {
   constexpr int MB = 8;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -505,6 +514,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_s2v(const RdArgs A) {
     }
 }
 
+__global__ __launch_bounds__(256, 2) void k_conv_s2v(const RdArgs A) {
+  long long c0 = 0, w0 = 0;
+  clock_probe_begin(A.clk, c0, w0);
+  conv_s2v_body(A);
+  clock_probe_end(A.clk, c0, w0);
+}
+
 // Ordered reduce of the forward K split: out[i] = sum_k slab[k][i] (k ascending: bit-reproducible), then the epilogue the split launch
 // deferred — styled: lrelu(v * d + nw * noise + bias) * act_scale — and zeros in the pitch padding of pitched outputs.
 __global__ __launch_bounds__(256) void k_ksplit_reduce(float* __restrict__ out, const float* __restrict__ slab, int ks, int64_t stride,
@@ -597,6 +613,7 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
   r.NPin = a.NPin; r.Hin = a.Hin; r.Win = a.Win; r.Wpitch = a.Wpitch; r.isy = a.isy; r.isx = a.isx;
   r.NPout = a.NPout; r.Hout = a.Hout; r.Wout = a.Wout; r.Wopitch = a.Wopitch; r.osy = a.osy; r.osx = a.osx;
   r.nitems = nitems; r.epi = a.epi; r.noise_bstride_on = a.noise_bstride_on; r.alpha = a.alpha; r.act_scale = a.act_scale;
+  r.clk = clock_probe_ptr();
   // register-direct weight layout: behind the LDS kernel's layout in the same packed buffer (prep_device.h)
   const RdTile T = rd_tile(nblk);
   const int ntile_p = cdiv(nblk, T.rb);

@@ -95,9 +95,8 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
   float* v_lds = smem;                    // [2][CK][16 tiles][36 slots]
   float* raw = v_lds + 2 * W4_VSZ;        // [2][CK][RPS]
 
-  const bool probe = A.clk != nullptr && blockIdx.x == 0;      // cagc_set_clock_probe: shader clock seen by the first workgroup
   long long clk_c0 = 0, clk_w0 = 0;
-  if (probe) { clk_c0 = clock64(); clk_w0 = wall_clock64(); }
+  clock_probe_begin(A.clk, clk_c0, clk_w0);      // cagc_set_clock_probe: shader clock seen by the first workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hb = HV == 2 ? wave >> 2 : 0, blk = wave & 3;
@@ -391,10 +390,7 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
       }
     }
   }
-  if (probe && tid == 0) {
-    const long long dc = clock64() - clk_c0, dw = wall_clock64() - clk_w0;       // shader-clock ticks / 100 MHz ticks
-    if (dw > 0) { atomicAdd(A.clk, (float)dc / (float)dw * 100.f); atomicAdd(A.clk + 1, 1.f); }
-  }
+  clock_probe_end(A.clk, clk_c0, clk_w0);
 }
 
 __global__ __launch_bounds__(256) void k_wino4_pack(float* __restrict__ up, const float* __restrict__ w, int Cout, int Cin, int Kp,
@@ -440,10 +436,8 @@ static int launch_wino4(const WinoArgs& a, size_t smem, hipStream_t st, const ch
   return check_launch(what);
 }
 
-static float* g_clock_probe = nullptr;     // cagc_set_clock_probe (diagnostic; process-wide)
-
 int run_wino4(WinoArgs& a, bool gated, hipStream_t st, const char* what) {
-  a.clk = g_clock_probe;
+  a.clk = clock_probe_ptr();
   CAGC_REQUIRE(a.H % 8 == 0 && a.W % 32 == 0, "%s: F(4x4) needs H %% 8 == 0, W %% 32 == 0", what);
   a.Kp = round_up(a.Cin, 16);
   a.tiles_x = a.W / 32; a.tiles_y = a.H / 8; a.nblocks = a.B * a.tiles_x * a.tiles_y;
@@ -473,8 +467,3 @@ int run_wino4(WinoArgs& a, bool gated, hipStream_t st, const char* what) {
 }
 
 }  // namespace cagc
-
-extern "C" int cagc_set_clock_probe(float* acc) {
-  cagc::g_clock_probe = acc;
-  return CAGC_OK;
-}
