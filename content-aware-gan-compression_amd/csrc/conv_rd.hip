@@ -386,10 +386,27 @@ __device__ __forceinline__ void conv_rd_body(const RdArgs& A) {
 
 template <int MB, bool PAD, bool SCALE, bool GS>
 __global__ __launch_bounds__(256, 2) void k_conv_rd(const RdArgs A) {
+#ifdef CAGC_RD_TRACE     // debug builds only (scripts/trace_rd.py, profiles/r04_conv_rd_trace.md): the probe pointer is a trace buffer,
+                         // 4 x int64 per workgroup — [0] start, [1] end in 100 MHz ticks, [2] = item * 16 + taps, [3] = XCC id
+  const long long t0 = wall_clock64();
+  conv_rd_body<MB, PAD, SCALE, GS>(A);
+  __syncthreads();
+  if (A.clk != nullptr && threadIdx.x == 0) {
+    long long* tr = reinterpret_cast<long long*>(A.clk) + 4ll * blockIdx.x;
+    int item = 0, pix_id;
+    { const int w = blockIdx.x, nx = A.nblocks, mt = A.mtiles; const int full = (nx / 8) * 8; const int s = w / 8, xcd = w - s * 8;
+      const int p = (s / mt) * 8 + xcd;
+      if (w < full * mt && p < full) pix_id = p; else pix_id = full + (w - full * mt) / mt; }
+    while (item < A.nitems - 1 && pix_id >= A.items[item].block_end) ++item;
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    tr[0] = t0; tr[1] = wall_clock64(); tr[2] = item * 16 + A.items[item].ntaps; tr[3] = (long long)(xcc & 15);
+  }
+#else
   long long c0 = 0, w0 = 0;
   clock_probe_begin(A.clk, c0, w0);
   conv_rd_body<MB, PAD, SCALE, GS>(A);       // (its early returns — K-split paths — come back here)
   clock_probe_end(A.clk, c0, w0);
+#endif
 }
 
 // ---- stride-2 3x3 forward, vector-operand form (the discriminator's `Blur -> 3x3 stride 2` on its big layers) -----------------
