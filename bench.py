@@ -243,6 +243,35 @@ def _cpu_model():
     return "unknown"
 
 
+def _graph_replay_clock(kd, student, teacher, disc, bs, mask, dev, rng, gen, n=10):
+    """Shader clock (MHz) the MFMA kernels of the HIP-graph-replayed KD step see — the launch mode of the timed region at N = 1.  The probe
+    pointer is read at launch time, so it is set BEFORE the capture (include/cagc.h cagc_set_clock_probe) and every replay carries it: every
+    64th workgroup of every k_wino4 / k_conv_rd launch adds its own clock.  Runs after the timed region, on a copy of the student."""
+    import copy, ctypes
+    from cagc import _lib
+    acc = torch.zeros(2, device=dev)
+    lib = _lib.load()
+    lib.cagc_set_clock_probe(ctypes.c_void_p(acc.data_ptr()))
+    try:
+        st2 = kd.GraphedKDStep(copy.deepcopy(student), teacher, disc, bs, mask, random_noise=True, world_size=1)
+    finally:
+        lib.cagc_set_clock_probe(None)          # launches outside the captured graphs stop sampling
+    for _ in range(3):
+        st2.sample_and_step(bs, mask, rng, gen)
+    torch.cuda.synchronize()
+    acc.zero_()
+    t1 = time.perf_counter()
+    for _ in range(n):
+        st2.sample_and_step(bs, mask, rng, gen)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t1) / n * 1e3
+    out = {"mhz": round(float(acc[0] / acc[1])) if float(acc[1]) > 0 else None, "samples_per_step": int(float(acc[1]) / n),
+           "ms_per_step_with_probe": round(ms, 3),
+           "what": "mean over every 64th workgroup of every F(4x4) Winograd and register-direct conv launch of the replayed step"}
+    del st2
+    return out
+
+
 def _time_mode(kd, cd, student, teacher, disc, bs, mask, world, dev, rng, gen, mode, n=8):
     """ms/step of `n` steps of one launch mode on a COPY of the student (untimed calibration / proxy runs)."""
     import copy
@@ -438,8 +467,9 @@ def main():
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "launches_per_step": cnt // 3, "avg_launch_ms": round(tot_ms / cnt, 4),
                     "flops_per_launch_avg": flops / cnt,
-                    # `peak` is the guide's figure at 2.4 GHz; under real operands the F(4x4) kernel holds ~2.0 GHz at the board's power
-                    # limit (2.35 GHz on all-zero operands, same instruction stream: DESIGN.md §5) — the ceiling at the clock it was given:
+                    # `peak` is the guide's figure at 2.4 GHz; under real operands the F(4x4) kernel runs at the board's power limit (back to
+                    # back: 2.0 GHz; 2.35 GHz on all-zero operands, same instruction stream: DESIGN.md §5).  The probe averages every 64th
+                    # workgroup of every k_wino4 launch of these eagerly launched steps — the ceiling at the clock the kernel was given:
                     "shader_clock_mhz_in_k_wino4": None if clk_mhz is None else round(clk_mhz),
                     "frac_at_measured_clock": None if clk_mhz is None else round(ach / (PEAK_F32_MFMA_TFLOPS * clk_mhz / 2400.0), 4),
                     "achieved_direct_conv_equivalent": round(ach * (4.0 if "k_wino4" in name else (2.25 if name.startswith("cagc_wino_conv3x3") else 1.0)), 2),
@@ -464,6 +494,15 @@ def main():
                         "largest_launch_MB": round(big[k][0] / 1e6, 1),
                         "largest_launch_GBps": round(big[k][0] / (big[k][1] * 1e-3) / 1e9, 1)}
                     for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])}
+    graph_clock = None
+    if world == 1 and not args.no_roofline and mode == "graph":
+        try:
+            graph_clock = _graph_replay_clock(kd, student, teacher, disc, bs, mask, dev, rng, gen)
+        except Exception as e:  # noqa: BLE001 — a diagnostic, never a reason to lose the bench line
+            print(f"[bench] graph-replay clock probe failed ({type(e).__name__}: {e})", file=sys.stderr)
+            _lib.load().cagc_set_clock_probe(None)
+        if roof is not None:
+            roof["graph_replay_clock"] = graph_clock
     full = None
     if world == 1 and not args.no_full_iteration:
         # secondary figure: the WHOLE training iteration of train.py:371-398 — D step + G/KD step + lazy

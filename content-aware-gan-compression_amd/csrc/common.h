@@ -81,14 +81,16 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
-// cagc_set_clock_probe (include/cagc.h): the caller's two-float accumulator or null; kernels that carry the probe add the shader
-// clock their workgroup 0 measured over its lifetime (MHz) to [0] and 1 to [1]
+// cagc_set_clock_probe (include/cagc.h): the caller's two-float accumulator or null; kernels that carry the probe add the shader clock
+// that every 64th workgroup measured over its own lifetime (MHz) to [0] and 1 to [1]: samples spread over the grid are spread over the
+// launch's duration ([0] / [1] = the launch-averaged clock; sampling only workgroup 0 measured the same — there is no start-of-launch bias).
 float* clock_probe_ptr();
+__device__ __forceinline__ bool clock_probe_on(const float* acc) { return acc != nullptr && (blockIdx.x & 63) == 0; }
 __device__ __forceinline__ void clock_probe_begin(const float* acc, long long& c0, long long& w0) {
-  if (acc != nullptr && blockIdx.x == 0) { c0 = clock64(); w0 = wall_clock64(); }
+  if (clock_probe_on(acc)) { c0 = clock64(); w0 = wall_clock64(); }
 }
 __device__ __forceinline__ void clock_probe_end(float* acc, const long long c0, const long long w0) {
-  if (acc != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (clock_probe_on(acc) && threadIdx.x == 0) {
     const long long dc = clock64() - c0, dw = wall_clock64() - w0;       // shader-clock ticks / 100 MHz ticks
     if (dw > 0) { atomicAdd(acc, (float)dc / (float)dw * 100.f); atomicAdd(acc + 1, 1.f); }
   }

@@ -357,13 +357,15 @@ int cagc_wino_eligible(int H, int W);
  * swaps the layer's Cin / Cout) takes under the current tuning: 0 = not eligible, 2 = F(2x2,3x3), 4 = F(4x4,3x3).  Benchmarks
  * use it to attribute executed FLOPs to the kernel that really ran. */
 int cagc_wino_plan(int B, int K, int M, int H, int W);
-/* Diagnostic (benchmarks): while `acc` is non-null, workgroup 0 of every F(4x4) Winograd launch adds the shader clock it
- * measured over its own lifetime (MHz: s_memtime ticks per 100 MHz s_memrealtime tick) to acc[0] and 1 to acc[1] — two device
- * floats the caller owns and zeroes.  Process-wide, not synchronised with launches in flight; pass NULL to stop.  Workgroup 0 is
- * the START of a launch: the figure is the clock the launch was given, before the power controller reacts to it.  Measured
- * (DESIGN.md §5): the fp32 matrix pipe's 157.3 TFLOP/s is quoted at 2.4 GHz; launched back to back on real operands this kernel
- * settles at 2.00-2.07 GHz at the board's power limit (2.35 GHz on all-zero operands, same instruction stream); between the
- * other kernels of an eagerly launched KD step its launches start at ~2.30 GHz. */
+/* Diagnostic (benchmarks): while `acc` is non-null, every 64th workgroup of every F(4x4) Winograd and register-direct
+ * convolution launch adds the shader clock it measured over its own lifetime (MHz: s_memtime ticks per 100 MHz s_memrealtime
+ * tick) to acc[0] and 1 to acc[1] — two device floats the caller owns and zeroes; acc[0] / acc[1] is the clock averaged over
+ * the launches' duration.  Process-wide, not synchronised with launches in flight (and read at launch time: a captured HIP graph
+ * keeps what it was captured with); pass NULL to stop.  Measured: the fp32 matrix pipe's 157.3 TFLOP/s is quoted
+ * at 2.4 GHz; on real operands the F(4x4) kernel holds 2.00-2.07 GHz when launched back to back (2.35 GHz on all-zero operands,
+ * same instruction stream: the board's power limit), 2.31-2.34 GHz inside the eagerly launched KD step and 2.33 GHz in the
+ * HIP-graph-replayed one (all probed kernels; the step is not power-limited); the register-direct kernels hold 2.33-2.41 GHz
+ * back to back. */
 int cagc_set_clock_probe(float* acc);
 int64_t cagc_wino_packed_elems(int K, int M);
 int cagc_wino_prep(float* up, const float* weight, int Cout, int Cin, float scale, int dgrad, cagc_stream_t stream);

@@ -86,8 +86,8 @@ def test_wino4_gated_data_gradient(shape, hv):
 
 
 def test_clock_probe_reports_the_shader_clock_and_leaves_results_alone():
-    """include/cagc.h cagc_set_clock_probe (bench.py roofline.shader_clock_mhz_in_k_wino4): workgroup 0 of every F(4x4) launch adds
-    its measured shader clock to a caller-owned accumulator; the output is bit-identical with and without the probe."""
+    """include/cagc.h cagc_set_clock_probe (bench.py roofline.shader_clock_mhz_in_k_wino4): every 64th workgroup of every F(4x4) launch
+    adds its measured shader clock to a caller-owned accumulator; the output is bit-identical with and without the probe."""
     import ctypes
     B, C, H, W = 2, 128, 32, 64
     torch.manual_seed(7)
@@ -109,5 +109,6 @@ def test_clock_probe_reports_the_shader_clock_and_leaves_results_alone():
         run(out1)                                    # probe off again: the accumulator no longer moves
         torch.cuda.synchronize()
     n, mhz = float(acc[1]), float(acc[0] / acc[1])
-    assert n == 3.0 and 500.0 < mhz < 3000.0, (n, mhz)
+    wgs = B * (H // 8) * (W // 32) * (C // 64)       # 64-channel workgroups (a 128-channel shape would be half as many): every 64th samples
+    assert n in (3.0 * ((wgs + 63) // 64), 3.0 * ((wgs // 2 + 63) // 64)) and 500.0 < mhz < 3000.0, (n, mhz, wgs)
     assert torch.equal(out0, out1)
