@@ -9,7 +9,7 @@ python - <<PY
 import json
 d = json.load(open("gpurun_out/bench_${TAG}.json"))
 r = d["roofline"]
-print({k: d[k] for k in ("value", "ms_per_step")}, "roofline", r["kernel"][:40], r["achieved"], r["frac"], "clock", r.get("shader_clock_mhz_in_k_wino4"), r.get("frac_at_measured_clock"), "avg_launch_ms", r["avg_launch_ms"])
+print({k: d[k] for k in ("value", "ms_per_step")}, "roofline", r["kernel"][:40], r["achieved"], r["frac"], "clock", r.get("shader_clock_mhz"), r.get("frac_at_measured_clock"), "avg_launch_ms", r["avg_launch_ms"])
 print({k: v["graph_ms"] for k, v in d["strong_scaling_proxy_1gpu"].items()}, d["deterministic_mode"], d["config3_1024"], d["full_iteration"]["value"], d["saliency_sweep"]["value"], d["cpu_baseline"])
 PY
 bash scripts/profile_step.sh ${TAG} 2>&1 | tail -16

@@ -86,7 +86,7 @@ def test_wino4_gated_data_gradient(shape, hv):
 
 
 def test_clock_probe_reports_the_shader_clock_and_leaves_results_alone():
-    """include/cagc.h cagc_set_clock_probe (bench.py roofline.shader_clock_mhz_in_k_wino4): every 64th workgroup of every F(4x4) launch
+    """include/cagc.h cagc_set_clock_probe (bench.py roofline.shader_clock_mhz): every 64th workgroup of every F(4x4) launch
     adds its measured shader clock to a caller-owned accumulator; the output is bit-identical with and without the probe."""
     import ctypes
     B, C, H, W = 2, 128, 32, 64
