@@ -22,7 +22,7 @@
 //     wino4_slot — the transform's packed pairs are aligned 8-byte writes; (tile, row half) across a half-wave is conflict-free
 //     for the writes, 36-float tile rows are conflict-free for the 16-byte reads).
 // On gfx950 VALU instructions do not overlap the fp32 MFMA: per chunk a wave issues 72 MFMAs next to ~45
-// packed transform operations (every other chunk), the commit of the prefetched raw tile and 18 + 18 + 9 LDS accesses; one barrier
+// packed transform operations (the waves of channel half 0 only), the commit of the prefetched raw tile and 18 + 18 + 9 LDS accesses; one barrier
 // per chunk.  Output transform: A^T M A on the wave's own accumulators, packed over the two channel rows a lane holds per
 // register pair (100 packed operations per pair), then demodulation / noise / bias / LeakyReLU / residual, 16-byte stores.
 #include "common.h"
@@ -65,6 +65,18 @@ __device__ __forceinline__ void w4_at6(const f32x2 m0, const f32x2 m1, const f32
 #define W4_ABL(bit) false
 #endif
 
+// Timing of one workgroup (debug builds only: -DCAGC_W4_TRACE, scripts/trace_wino4.py): per wave, shader cycles summed over the chunks in
+//   [0] groups 0 .. CM_AT-1 (MFMAs + operand loads only)   [1] group CM_AT (+ raw-tile commit, next prefetch)   [2] groups CM_AT+1 .. XF_AT-1
+//   [3] group XF_AT in chunks where this wave TRANSFORMS    [8] group XF_AT in chunks where it does not           [4] groups XF_AT+1 .. 17
+//   [5] chunk barrier, chunks where this wave transformed   [9] chunk barrier, chunks where it did not
+//   [6] prologue, [7] epilogue of the workgroup.  Every stamp is an s_memtime + a full lgkmcnt wait: it perturbs the LDS pipelining a little.
+#ifdef CAGC_W4_TRACE
+__device__ long long g_w4_trace[8][12];
+#define W4_TR(k) do { const long long t_ = clock64(); tr[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define W4_TR(k)
+#endif
+
 // packed-fp32 helpers with half selection (VOP3P op_sel): the row stage of the input transform works on values paired along the
 // axis it mixes, so its operands come from different register halves.  The constant pair is a scalar-register operand.
 __device__ __forceinline__ f32x2 pk_lo_fma_lo(const f32x2 a, const f32x2 k, const f32x2 c) {     // (a.lo*k.lo + c.lo, a.lo*k.hi + c.lo)
@@ -85,7 +97,15 @@ __device__ __forceinline__ f32x2 pk_lo_pm_lo(const f32x2 a, const f32x2 b) {    
 
 // Workgroup = 4 * HV waves (2 per SIMD at HV = 2): wave = (channel half hb, block blk) owns channels 16 * (4 hb + blk) .. + 15 of the
 // tile at all 36 positions.  The two waves of a SIMD are (hb = 0, blk) and (hb = 1, blk) (waves w and w + 4 share a SIMD):
-// they take turns transforming (even / odd chunks), so every SIMD carries the same VALU work in every chunk.
+// the OLDER one (hb = 0) runs the input transform of EVERY chunk.  The SIMD issues oldest-wave-first: waves 0-3 stream their MFMAs at
+// the full pipe rate (4 MFMAs in 128 cycles) whatever waves 4-7 do, which get the rest.  When the older wave stops to transform, the
+// younger one's MFMAs fill the pipe — the overlap the design wants.  Rounds 3-4 ALTERNATED the transformer by chunk parity ("the same
+// VALU load on every SIMD in every chunk", an argument that assumes symmetric arbitration): in the chunks where the younger wave
+// transformed, the older one ran its 72 MFMAs first and then sat at the barrier for ~3400 cycles while the younger did its MFMAs AND
+// the whole transform alone — 7550 cycles against 5950 for the other kind of chunk (in-kernel phase trace, -DCAGC_W4_TRACE,
+// profiles/r04_wino4_phase_trace.md).  That exposed half was "the transform's 12 %" of the ablation builds, and why neither its VALU
+// count nor its LDS waits had mattered.  Always-the-older-wave: 6752 -> 6599 cycles per chunk, -1.0 ... -3.7 % back to back,
+// KD step 29.84 / 29.97 -> 29.60 / 29.61 ms same-box; bit-identical outputs (scripts/cmp_wino_builds.py).
 template <bool GATED, bool SCALE, int HV>
 __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoArgs A) {
   constexpr int CK = W4_CK;
@@ -97,6 +117,10 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
 
   long long clk_c0 = 0, clk_w0 = 0;
   clock_probe_begin(A.clk, clk_c0, clk_w0);      // cagc_set_clock_probe: shader clock seen by the first workgroup
+#ifdef CAGC_W4_TRACE
+  const long long t_entry = clock64();
+  long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hb = HV == 2 ? wave >> 2 : 0, blk = wave & 3;
@@ -171,7 +195,7 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
   };
 
   // ---- input transform: work item = (half h of the transformed rows, channel c, tile); 256 items per chunk -----------------
-  // done by the 256 threads of channel half hb == (chunk & 1): both waves of a SIMD alternate (HV = 1: by every thread, every chunk)
+  // done by the 256 threads of channel half 0, every chunk (see the kernel's header comment; HV = 1: by every thread, every chunk)
   // (the row half h is wave-uniform: the column stage differs between the halves.  16 tiles x 2 channels per half-wave makes the
   // 8-byte V writes 2-way bank conflicts — LDS cycles, which are spare; h across the half-wave would be conflict-free but runs
   // both column stages in every lane: VALU issue, which is MFMA time)
@@ -242,7 +266,8 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
     return ((q * KQ + 2 * chunk + s) * 256) * 4;
   };
 #ifndef W4_XF_AT
-#define W4_XF_AT 8      // group of the chunk at which the transforming waves run chunk j+1's input transform
+#define W4_XF_AT 8      // group of the chunk at which the transforming waves run chunk j+1's input transform (re-swept with the older wave as
+                        // the only transformer: 1 / 3 / 5 are +1 ... +2 %, 8 / 11 / 14 equal — gpurun_out/w4_xfat_sweep.md)
 #endif
 #ifndef W4_CM_AT
 #define W4_CM_AT 6      // (measured: 12 -> 6 is -4 % on 128 -> 128 @256^2, neutral on 512 channels) group at which the raw tile of chunk j+2 is committed to LDS and chunk j+3 is requested
@@ -294,7 +319,7 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
     const float* vbn = v_lds + (cur ^ 1) * W4_VSZ + vb_wave;
     const int vnext = 4 * (cur ^ 1) * W4_VSZ;                       // byte offsets in LDS
     const int rnext = 4 * (2 * W4_VSZ + (cur ^ 1) * W4_RSZ);        // chunk j+1, transformed during this chunk by the waves of half (j+1)&1
-    const bool xf = HV == 1 || (hb == (cur ^ 1));       // uniform per wave: (j + 1) & 1 == cur ^ 1
+    const bool xf = HV == 1 || hb == 0;                 // uniform per wave: the OLDER wave of each SIMD transforms every chunk (kernel header)
     const int jn = (j + 1 < nch) ? j + 1 : j;           // last chunk: re-read valid weights instead of branching
 #pragma unroll
     for (int gi = 0; gi < 18; ++gi) {
@@ -321,11 +346,25 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
         prefetch(j + 3);
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef CAGC_W4_TRACE
+      if (gi == W4_CM_AT - 1) W4_TR(0);
+      if (gi == W4_CM_AT) W4_TR(1);
+      if (gi == W4_XF_AT - 1) W4_TR(2);
+      if (gi == W4_XF_AT) { if (xf) W4_TR(3); else W4_TR(8); }
+      if (gi == 17) W4_TR(4);
+#endif
     }
     if (!W4_ABL(16)) __syncthreads();
+#ifdef CAGC_W4_TRACE
+    if (xf) W4_TR(5); else W4_TR(9);
+#endif
     bv_cur = b_read(vbn, 0);
     bv_nxt = b_read(vbn, 1);
   };
+#ifdef CAGC_W4_TRACE
+  tlast = clock64();
+  tr[6] = tlast - t_entry;
+#endif
   for (int j = 0; j < nch; j += 2) {     // Kp is a multiple of 16: an even number of chunks
     chunk(j, 0);
     chunk(j + 1, 1);
@@ -391,6 +430,11 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
     }
   }
   clock_probe_end(A.clk, clk_c0, clk_w0);
+#ifdef CAGC_W4_TRACE
+  tr[7] = clock64() - tlast;
+  if (blockIdx.x == gridDim.x / 2 && lane == 0)
+    for (int k = 0; k < 12; ++k) g_w4_trace[wave][k] = tr[k];
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_wino4_pack(float* __restrict__ up, const float* __restrict__ w, int Cout, int Cin, int Kp,
@@ -466,4 +510,11 @@ int run_wino4(WinoArgs& a, bool gated, hipStream_t st, const char* what) {
   return sc ? launch_wino4<false, true, 1>(a, smem, st, what) : launch_wino4<false, false, 1>(a, smem, st, what);
 }
 
+#ifdef CAGC_W4_TRACE
+}  // namespace cagc
+extern "C" int cagc_wino4_trace_dump(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cagc::g_w4_trace), sizeof(long long) * 96);
+}
+namespace cagc {
+#endif
 }  // namespace cagc
