@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--local-batch", type=int, default=0, help="per-GPU batch override (default: global batch 16 / world size; "
                                                                "--size 1024 at --gpus 1: 4)")
     ap.add_argument("--no-config3", action="store_true", help="skip the compact configs[3] (1024 px, per-GPU batch 4) leg")
+    ap.add_argument("--no-sweep-clock", action="store_true", help="do not run the shader-clock probe during the saliency-sweep leg")
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong-scaling proxy table (per-GPU batch 8/4/2 on this GPU)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed bs-16 steps of the CPU baseline (SURVEY 8-d: 3)")
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -603,6 +604,10 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()      # bs-64 fwd+bwd of the full generator: start from a released cache, whatever ran before
+        # This leg is BIMODAL PER PROCESS ON SOME BOXES (417 - 491 img/s against 522 - 554; one box 4 slow runs of 6, the next box 0 of 10,
+        # same code and flags: gpurun_out/diag_sweep3.log, diag_sweep_ab.log) — at the SAME shader clock in both modes (2285 - 2300 MHz,
+        # reported below), with or without any other leg before it, with or without the probe (interleaved A/B 544.5 vs 543.8 img/s).
+        # Not the power limit, not leg order, not the probe; cause not found.  The KD step on the same boxes is not affected.
         # BASELINE configs[4]: prune.py's content-aware saliency sweep over the FULL 256 px generator, bs 64 (forward +
         # backward incl. weight gradients of the 512-channel layers); bounded here to a few batches
         from cagc import prune
@@ -612,11 +617,17 @@ def main():
         nb = args.sweep
         prune.content_aware_scores(teacher, 64, 64, 0.05, mfn, dev)
         torch.cuda.synchronize()
+        import ctypes as _ct2
+        sw_clk = torch.zeros(2, device=dev)      # every 64th workgroup of the F(4x4) / register-direct launches adds its clock (two atomics): the
+        if not args.no_sweep_clock:
+            _lib.load().cagc_set_clock_probe(_ct2.c_void_p(sw_clk.data_ptr()))  # KD step's time is unchanged by it (30.09 vs 30.08 ms)
         t2 = time.perf_counter()
         sc = prune.content_aware_scores(teacher, 64 * nb, 64, 0.05, mfn, dev)
         torch.cuda.synchronize()
         dts = time.perf_counter() - t2
+        _lib.load().cagc_set_clock_probe(None)
         sweep = {"value": round(64 * nb / dts, 2), "unit": "images/s", "batches": nb, "batch_size": 64,
+                 "shader_clock_mhz": round(float(sw_clk[0] / sw_clk[1])) if float(sw_clk[1]) > 0 else None,
                  "what": "content-aware saliency sweep, full 256px generator fwd+bwd (271 GFLOP/img), on-device mask/noise/score",
                  "tflops": round(64 * nb / dts * 271e9 / 1e12, 1), "score_layers": len(sc)}
         teacher.eval()
@@ -635,10 +646,8 @@ def main():
                 cpu["all_cores"] = {"error": f"{type(e).__name__}: {e}", "cores": allc}
 
     if world == 1 and not args.no_roofline and mode == "graph" and roof is not None:
-        # LAST leg on purpose: it captures one more HIP graph (with the clock probe set, so that the replays carry it).  Run before the
-        # saliency sweep it left that leg slow in 2 of 3 runs (485 / 472 / 551 img/s against 535 - 552 in seven runs without it:
-        # gpurun_out/diag_sweep.log; presumably allocator layout after the extra capture — not established) — a diagnostic must not be
-        # able to influence a measured leg, so nothing runs after it.
+        # LAST leg on purpose: it captures one more HIP graph (with the clock probe set, so that the replays carry it), and a diagnostic must
+        # not be able to influence a measured leg — so nothing runs after it.
         import gc
         gc.collect()
         torch.cuda.empty_cache()
