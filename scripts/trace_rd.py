@@ -1,5 +1,8 @@
 """Workgroup-level timeline of ONE register-direct conv launch (debug build -DCAGC_RD_TRACE: every workgroup records start / end in
-100 MHz ticks, its item and its XCC).  Run ON THE GPU BOX:  LIB=libcagc_hip_rdtrace.so python scripts/trace_rd.py
+100 MHz ticks, its item and its XCC).  Build (from content-aware-gan-compression_amd/csrc, after `make`):
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DCAGC_RD_TRACE=1 -c conv_rd.hip -o build_alt/conv_rd_trace.o
+  hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v "build/conv_rd.o") build_alt/conv_rd_trace.o -o ../cagc/libcagc_hip_rdtrace.so
+Run ON THE GPU BOX:  LIB=libcagc_hip_rdtrace.so SHAPE=cin,cout,H python scripts/trace_rd.py
 Prints per item kind (taps) the count and duration, the number of busy workgroup slots over time, and what the tail costs."""
 import os, sys, ctypes, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
