@@ -87,6 +87,8 @@ _PROTOS = {
     "cagc_fromrgb_fwd": [_p, _p, _p, _p, _i, _i, _i64, _f, _f, _f, _p],
     "cagc_fromrgb_act_dgrad": [_p, _p, _p, _p, _i, _i, _i64, _f, _f, _f, _p],
     "cagc_masked_l1": [_p, _p, _p, _p, _p, _i, _i, _i64, _f, _p],
+    "cagc_gan_kd_loss_tail_ws_floats": [_i, _i, _i64],
+    "cagc_gan_kd_loss_tail": [_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i64, _f, _f, _p, _p],
     "cagc_add_scale": [_p, _p, _p, _i64, _f, _p],
     "cagc_scale_reduce": [_p, _p, _p, _p, _i, _i, _i64, _p],
     "cagc_to_phase_planar": [_p, _p, _i64, _i, _i, _i, _p],
@@ -102,6 +104,7 @@ _RESTYPES = {
     "cagc_wino_packed_elems": _i64,
     "cagc_gemm1x1_packed_elems": _i64,
     "cagc_content_mask_workspace": _i64,
+    "cagc_gan_kd_loss_tail_ws_floats": _i64,
 }
 EXPORTS = tuple(_PROTOS)
 
@@ -130,7 +133,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, _i)
-    if lib.cagc_abi_version() != 1:
+    if lib.cagc_abi_version() != 2:
         raise RuntimeError("libcagc_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -28,14 +28,27 @@ def iteration_from_filename(path):
     return int(str(path)[-9:-3])
 
 
+def optim_state_for_checkpoint(optim):
+    """`optim.state_dict()` with every state tensor cloned: no two entries share storage.  `GraphedKDStep.optim` is a VIEW of one
+    flat Adam (all `step` entries alias ONE counter, the moments are slices of one buffer); torch.save / load_state_dict preserve
+    such aliasing, and a plain Adam resumed from it would advance the shared counter once per parameter per step (wrong bias
+    correction).  Accepts an optimiser or a GraphedKDStep."""
+    if hasattr(optim, "optim_state_dict"):
+        return optim.optim_state_dict()
+    sd = optim.state_dict()
+    sd["state"] = {k: {n: (v.detach().clone() if torch.is_tensor(v) else v) for n, v in st.items()} for k, st in sd["state"].items()}
+    return sd
+
+
 def save_checkpoint(ckpt_dir, iteration, generator, discriminator, g_ema, g_optim=None, d_optim=None):
     """torch.save of the reference's dict (train.py:443-452) to `<ckpt_dir>/<iteration:06d>.pt`; returns the path.
-    DDP / DataParallel wrappers are unwrapped (the reference saves `.module`'s state dict)."""
+    DDP / DataParallel wrappers are unwrapped (the reference saves `.module`'s state dict).  g_optim may be an optimiser or a
+    GraphedKDStep; optimiser state is written de-aliased (`optim_state_for_checkpoint`)."""
     state = {"g": _unwrap(generator).state_dict(), "d": _unwrap(discriminator).state_dict(), "g_ema": _unwrap(g_ema).state_dict()}
     if g_optim is not None:
-        state["g_optim"] = g_optim.state_dict()
+        state["g_optim"] = optim_state_for_checkpoint(g_optim)
     if d_optim is not None:
-        state["d_optim"] = d_optim.state_dict()
+        state["d_optim"] = optim_state_for_checkpoint(d_optim)
     os.makedirs(ckpt_dir, exist_ok=True)
     path = os.path.join(ckpt_dir, checkpoint_name(iteration))
     torch.save(state, path)

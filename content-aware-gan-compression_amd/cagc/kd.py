@@ -87,7 +87,8 @@ class KDStep:
         if self.phase_timer is not None:
             self.phase_timer.mark(phase)
 
-    def g_losses(self, zs, inject_index, mask, student_noise=None, teacher_noise=None):
+    def _forward_all(self, zs, inject_index, mask, student_noise=None, teacher_noise=None):
+        """student, frozen D and teacher forward -> (D scores of the student image, student rgb list, teacher rgb list, mask)"""
         # The frozen teacher's forward is independent of the student / discriminator chain until the distillation loss:
         # on the GPU it runs on its own HIP stream, so its launches fill the CUs that the student's narrow (154/77/39
         # channel) and low-resolution layers leave idle, and kernel tails of one chain overlap the other.  Works eagerly
@@ -112,9 +113,8 @@ class KDStep:
                 teacher_list, mask = run_teacher()
         self._mark()
         fake_list = self.student(zs, return_rgb_list=True, inject_index=inject_index, noise=student_noise)
-        fake_img = fake_list[-1]
         self._mark("train_G_g_forward")
-        g_loss = g_nonsaturating_loss(self.disc_frozen(fake_img))
+        fake_pred = self.disc_frozen(fake_list[-1])
         if overlap:
             main.wait_stream(side)
             for t in teacher_list:
@@ -123,7 +123,10 @@ class KDStep:
                 mask.record_stream(main)
         else:
             teacher_list, mask = run_teacher()
-        teacher_img = teacher_list[-1]
+        return fake_pred, fake_list, teacher_list, mask
+
+    def _kd_term(self, fake_list, teacher_list, mask):
+        fake_img, teacher_img = fake_list[-1], teacher_list[-1]
         if self.kd_mode == "Output_Only":
             # content-aware KD off (parsing_net None, no mask supplied; reference train.py:155,516-518): plain L1
             kd_l1 = self.kd_l1_lambda * (mc.masked_l1(fake_img, teacher_img, mask) if mask is not None
@@ -143,13 +146,32 @@ class KDStep:
                 t_in = F.interpolate(t_in, size=size, mode="bilinear", align_corners=False)
             self.last_kd_lpips = self.kd_lpips_lambda * torch.mean(self.percept_loss(s_in, t_in))
             kd_l1 = kd_l1 + self.last_kd_lpips          # second return value = the whole distillation term
-        return g_loss, kd_l1, fake_img
+        return kd_l1
+
+    def g_losses(self, zs, inject_index, mask, student_noise=None, teacher_noise=None):
+        """(g_loss, kd_l1, student image) as separate differentiable terms (reference train.py:296-304)."""
+        fake_pred, fake_list, teacher_list, mask = self._forward_all(zs, inject_index, mask, student_noise, teacher_noise)
+        return g_nonsaturating_loss(fake_pred), self._kd_term(fake_list, teacher_list, mask), fake_list[-1]
+
+    def g_total(self, zs, inject_index, mask, student_noise=None, teacher_noise=None, grad_scale=1.0):
+        """(total, g_loss, kd_l1): `total` = g_loss + kd_l1 is the tensor to differentiate WITH THE IMPLICIT UNIT GRADIENT (its
+        gradients come out multiplied by grad_scale — the 1 / world_size of a data-parallel mean); the other two are detached values.
+        On the GPU in the measured configuration (Output_Only, content mask, no LPIPS) the three losses and both backward seeds are ONE
+        launch (cagc_gan_kd_loss_tail) instead of a chain of ~14 aten kernels; anything else composes the reference's terms."""
+        fake_pred, fake_list, teacher_list, mask = self._forward_all(zs, inject_index, mask, student_noise, teacher_noise)
+        if (self.kd_mode == "Output_Only" and self.percept_loss is None and mask is not None
+                and mc.gan_kd_loss_tail_ok(fake_pred, fake_list[-1], teacher_list[-1], mask)):
+            return mc.gan_kd_loss_tail(fake_pred, fake_list[-1], teacher_list[-1], mask, self.kd_l1_lambda, grad_scale, unit_seed=True)
+        g_loss, kd_l1 = g_nonsaturating_loss(fake_pred), self._kd_term(fake_list, teacher_list, mask)
+        total = g_loss + kd_l1
+        if grad_scale != 1.0:
+            total = total * grad_scale + (total.detach() * (1.0 - grad_scale))      # value unchanged, gradients scaled
+        return total, g_loss.detach(), kd_l1.detach()
 
     def g_step(self, zs, inject_index, mask, student_noise=None, teacher_noise=None):
         requires_grad(self.student, True)
         requires_grad(self.disc, False)
-        g_loss, kd_l1, _ = self.g_losses(zs, inject_index, mask, student_noise, teacher_noise)
-        total = g_loss + kd_l1
+        total, g_loss, kd_l1 = self.g_total(zs, inject_index, mask, student_noise, teacher_noise)
         self._mark("train_G_d_forward")      # as in the reference's profiler: D forward + teacher forward + the KD loss
         self.optim.zero_grad(set_to_none=True)
         total.backward()
@@ -157,8 +179,8 @@ class KDStep:
         self._mark("train_G_g_backward")
         if self.percept_loss is not None:
             lp = self.last_kd_lpips.detach()
-            return {"g": g_loss.detach(), "kd_l1_loss": kd_l1.detach() - lp, "kd_lpips_loss": lp}
-        return {"g": g_loss.detach(), "kd_l1_loss": kd_l1.detach()}
+            return {"g": g_loss, "kd_l1_loss": kd_l1 - lp, "kd_lpips_loss": lp}
+        return {"g": g_loss, "kd_l1_loss": kd_l1}
 
     def sample_and_step(self, batch, mask, rng=random, generator=None):
         dev = mask.device
@@ -304,23 +326,34 @@ class TrainIteration(KDStep):
 
 
 class GraphedKDStep(KDStep):
-    """The same step replayed from HIP graphs (torch.cuda.CUDAGraph): one graph holds latent sampling, student /
-    teacher / D forward, the losses and the whole backward; after it the (optional) gradient all-reduce runs as ONE
-    flat RCCL collective, then a second graph applies Adam.  This removes the ~1400 per-step host launches (the step
-    is launch-bound at small per-GPU batch) — the 'HIP streams and graphs instead of a tracing compiler' of the
-    design brief.  Style mixing uses a device-side index so shapes are static (Generator._synthesize).
+    """The same step replayed from a HIP graph (torch.cuda.CUDAGraph): latent sampling, student / teacher / D forward, the loss
+    tail, the whole backward, the gradient all-reduce and Adam.  This removes the ~1400 per-step host launches (the step is
+    launch-bound at small per-GPU batch) — the 'HIP streams and graphs instead of a tracing compiler' of the design brief.  Style
+    mixing uses a device-side index so shapes are static (Generator._synthesize).
 
-    Gradients live in one flat buffer (param.grad are views), which is what the all-reduce moves: 22.3 MB at 256 px."""
+    Data parallel (reference train.py:522-525 DistributedDataParallel, Miscellaneous/distributed.py:57-66): gradients live in ONE flat
+    buffer laid out in the order in which backward produces them (probed once, eagerly) and cut into `n_buckets` contiguous buckets;
+    the post-accumulate hook of a bucket's last parameter gathers the bucket into its slice and issues its RCCL all-reduce FROM INSIDE
+    the captured backward (`comm='graph'`: the collective is a graph node on RCCL's stream that depends only on that bucket — it runs
+    beside the rest of the backward, and Adam waits for all of them; the 1 / world_size of the mean is folded into the backward seed
+    by the loss tail).  If capturing a collective fails on some rank, every rank falls back to `comm='host'`: two graphs with one
+    flat all-reduce between them (the round-1..4 form).  22.3 MB of gradients at 256 px."""
 
-    def __init__(self, student, teacher, discriminator, batch, mask, random_noise=True, world_size=1, always_reduce=False, **kw):
-        """always_reduce: run the flat gradient all-reduce between the two graphs even at world size 1 (RCCL smoke test on a
-        1-GPU box: same stream ordering around the replays as a multi-GPU run)."""
+    def __init__(self, student, teacher, discriminator, batch, mask, random_noise=True, world_size=1, always_reduce=False,
+                 comm="auto", n_buckets=4, **kw):
+        """always_reduce: issue the collectives even at world size 1 (RCCL smoke test on a 1-GPU box: the same graph nodes / stream
+        ordering as a multi-GPU run).  comm: 'auto' (graph, else host), 'graph', 'host'."""
         kw.setdefault("fused_adam", True)
         super().__init__(student, teacher, discriminator, **kw)
+        assert comm in ("auto", "graph", "host")
         self.always_reduce = always_reduce
         for g in self.optim.param_groups:
             g["capturable"] = True
+        if len(self.optim.param_groups) != 1 or self.optim.param_groups[0].get("amsgrad") or self.optim.param_groups[0].get("maximize"):
+            raise ValueError("GraphedKDStep captures ONE flat Adam: a single param group without amsgrad / maximize")
         self.batch, self.world = batch, world_size
+        self._reduce = world_size > 1 or always_reduce
+        self._grad_scale = 1.0 / world_size
         dev = mask.device
         self.mask = mask.clone()
         self.z = torch.zeros(2, batch, self.latent, device=dev)
@@ -334,24 +367,108 @@ class GraphedKDStep(KDStep):
             self.t_noise = [torch.zeros(shp(i), device=dev) for i in range(base.num_layers)]
         else:
             self.s_noise = self.t_noise = None
-        self._params = [p for p in self.student.parameters()]
+        self._in_graph_comm = False
+        self._works = []
+        self._params = self._probe_grad_order([p for p in self.student.parameters()])
         n_flat = sum(p.numel() for p in self._params)
         self.flat_grad = torch.zeros(n_flat, device=dev)
         self._grad_views, off = [], 0
         for p in self._params:
             self._grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self._plan_buckets(max(1, int(n_buckets)))
         self._flatten_optimizer(n_flat, dev)
         self.losses = None
-        self._capture()
+        self.comm = None
+        modes = ["graph", "host"] if comm == "auto" else [comm]
+        if not self._reduce:
+            modes = ["graph"]                 # nothing to communicate: one graph
+        elif comm == "auto":
+            import torch.distributed as dist
+            if dist.get_backend() != "nccl":  # only RCCL collectives are stream-ordered device work that a HIP graph can hold
+                modes = ["host"]
+        err = None
+        for m in modes:
+            ok = 1.0
+            try:
+                self._capture(m)
+            except Exception as e:  # noqa: BLE001 — a collective that cannot be captured is a supported outcome
+                if m == modes[-1]:
+                    raise
+                err, ok = e, 0.0
+            if world_size > 1:                # every rank must take the same branch: the modes issue different collectives
+                import torch.distributed as dist
+                okt = torch.tensor([ok], device=dev)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                ok = float(okt.item())
+            if ok > 0:
+                self.comm = m
+                break
+            import sys
+            print(f"[cagc] GraphedKDStep: capturing the collectives inside the graph failed ({type(err).__name__ if err else 'on another rank'}: {err}); "
+                  "falling back to one flat all-reduce between two graphs", file=sys.stderr)
+        assert self.comm is not None
+
+    # ---- gradient layout ------------------------------------------------------------------------------------------------------
+    def _probe_grad_order(self, params):
+        """One eager forward / backward with post-accumulate hooks: the order in which backward finishes the parameters' gradients
+        (parameters that receive none come last).  Leaves weights, gradients and optimiser untouched."""
+        order, hooks = [], []
+        index = {id(p): i for i, p in enumerate(params)}
+        for p in params:
+            hooks.append(p.register_post_accumulate_grad_hook(lambda q: order.append(index[id(q)])))
+        requires_grad(self.student, True)
+        requires_grad(self.disc, False)
+        try:
+            z = [torch.randn_like(self.z[0]), torch.randn_like(self.z[1])]
+            total, _, _ = self.g_total(z, self.inj, self.mask, self.s_noise, self.t_noise)
+            total.backward()
+        finally:
+            for h in hooks:
+                h.remove()
+            for p in params:
+                p.grad = None
+        seen = set(order)
+        order += [i for i in range(len(params)) if i not in seen]
+        return [params[i] for i in order]
+
+    def _plan_buckets(self, n_buckets):
+        """contiguous slices of the flat buffer of ~equal size, cut at parameter boundaries: (lo, hi, first param, last param + 1)"""
+        sizes = [p.numel() for p in self._params]
+        total, target = sum(sizes), sum(sizes) / n_buckets
+        self._buckets, lo, first, acc = [], 0, 0, 0
+        for i, n in enumerate(sizes):
+            acc += n
+            if (acc - lo >= target and len(self._buckets) < n_buckets - 1) or i == len(sizes) - 1:
+                self._buckets.append((lo, acc, first, i + 1))
+                lo, first = acc, i + 1
+        assert self._buckets[-1][1] == total
+        self._closer = {id(self._params[b[3] - 1]): k for k, b in enumerate(self._buckets)}
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params if id(p) in self._closer]
+        self._armed = False
+
+    def _on_grad(self, p):
+        if self._armed:
+            self._close_bucket(self._closer[id(p)])
+
+    def _close_bucket(self, k):
+        """gather bucket k's fresh gradients into its slice of the flat buffer and, under comm='graph', launch its all-reduce"""
+        lo, hi, first, last = self._buckets[k]
+        grads = [(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1) for q in self._params[first:last]]
+        torch.cat(grads, out=self.flat_grad[lo:hi])
+        self._closed[k] = True
+        if self._in_graph_comm:
+            import torch.distributed as dist
+            self._works.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def _flatten_optimizer(self, n_flat, dev):
         """ONE Adam launch instead of four: the student's parameters become views of one flat buffer (`p.data` re-pointed, values
         kept), and the captured optimiser is `torch.optim.Adam` (fused, capturable — the same elementwise arithmetic) over that
         single flat parameter with the flat gradient: multi_tensor_apply over 135 small tensors took 0.21 ms per step at every batch
-        size, the flat one ~0.04.  `self.optim` — the per-parameter optimiser every caller and the checkpoint format
-        (`optim.state_dict()`, train.py:443-452) know — stays, as a VIEW: its state tensors are slices of the flat moments and the one
-        shared step counter, so `state_dict()` / `load_optim_state` read and write what the captured graph updates."""
+        size, the flat one ~0.04.  `self.optim` — the per-parameter optimiser every caller knows — stays as a VIEW for reading:
+        its moment tensors are slices of the flat moments and its `step` entries all alias the one captured counter.  That aliasing
+        must never reach a checkpoint (a plain Adam loaded from it would advance the shared counter once per parameter):
+        `optim_state_dict()` exports per-parameter clones, and `checkpoint.save_checkpoint` uses it."""
         with torch.no_grad():
             flat_p = torch.cat([p.detach().reshape(-1) for p in self._params]).contiguous()
             off = 0
@@ -373,22 +490,40 @@ class GraphedKDStep(KDStep):
             self.optim.state[p] = {"step": step, "exp_avg": flat_m[off:off + n].view_as(p), "exp_avg_sq": flat_v[off:off + n].view_as(p)}
             off += n
 
+    def optim_state_dict(self):
+        """`optim.state_dict()` with every tensor CLONED per parameter (own `step` counters, own moments): what a checkpoint may hold.
+        Loadable by a plain torch.optim.Adam (eager KDStep / TrainIteration, the reference's train.py) and by `load_optim_state`."""
+        sd = self.optim.state_dict()
+        sd["state"] = {k: {n: (v.detach().clone() if torch.is_tensor(v) else v) for n, v in st.items()} for k, st in sd["state"].items()}
+        return sd
+
     def _fwd_bwd(self):
         if self.random_noise:
             self.z.normal_()
-        g_loss, kd_l1, _ = self.g_losses([self.z[0], self.z[1]], self.inj, self.mask, self.s_noise, self.t_noise)
+        total, g_loss, kd_l1 = self.g_total([self.z[0], self.z[1]], self.inj, self.mask, self.s_noise, self.t_noise, grad_scale=self._grad_scale)
         # Gradients are produced into fresh tensors (grad = None: autograd assigns instead of launching one accumulate-add per
-        # parameter into a pre-zeroed buffer) and gathered into the flat all-reduce / Adam buffer by ONE concatenation.
+        # parameter into a pre-zeroed buffer); each bucket is gathered into the flat all-reduce / Adam buffer by ONE concatenation as
+        # soon as its last gradient exists (_on_grad).
         for p in self._params:
             p.grad = None
-        (g_loss + kd_l1).backward()
-        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._params]
-        torch.cat(grads, out=self.flat_grad)
+        self._closed = [False] * len(self._buckets)
+        self._works = []
+        self._armed = True
+        try:
+            total.backward()
+        finally:
+            self._armed = False
+        for k, done in enumerate(self._closed):      # buckets whose closing parameter received no gradient
+            if not done:
+                self._close_bucket(k)
+        for w in self._works:                        # Adam (and everything after) waits for the collectives: the join of RCCL's stream
+            w.wait()
+        self._works = []
         for p, v in zip(self._params, self._grad_views):
             p.grad = v
-        return torch.stack([g_loss.detach(), kd_l1.detach()])
+        return torch.stack([g_loss, kd_l1])
 
-    def _capture(self):
+    def _capture(self, mode):
         requires_grad(self.student, True)
         requires_grad(self.disc, False)
         # The warm-up (allocator pools, lazy inits, Adam state creation) takes real optimiser steps: snapshot the
@@ -396,6 +531,7 @@ class GraphedKDStep(KDStep):
         # as it found them (and replicas that started identical stay identical — no collective runs in the warm-up).
         params = self._params
         snap = [p.detach().clone() for p in params]
+        self._in_graph_comm = False
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -407,32 +543,46 @@ class GraphedKDStep(KDStep):
         with torch.no_grad():
             for p, s in zip(params, snap):
                 p.copy_(s)
-            for st in self.optim.state.values():     # in place: the captured Adam graph keeps these tensors
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            st = self._flat_optim.state[self._flat_param]
+            for v in st.values():     # in place: the captured Adam graph keeps these tensors
+                if torch.is_tensor(v):
+                    v.zero_()
             self.flat_grad.zero_()
         if self.world > 1:                            # belt and braces: every replica starts from rank 0's weights
             import torch.distributed as dist
-            for p in params:
-                dist.broadcast(p.data, src=0)
-        self.graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fb):
-            self.losses = self._fwd_bwd()
-        self.graph_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_opt):
-            self._flat_optim.step()
+            dist.broadcast(self._flat_param.data, src=0)
+        self.graph_fb = self.graph_opt = None
+        if mode == "graph":       # ONE graph: forward, backward with the bucket collectives inside it, Adam
+            self._in_graph_comm = self._reduce
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    self.losses = self._fwd_bwd()
+                    self._flat_optim.step()
+            except Exception:
+                self._in_graph_comm = False
+                torch.cuda.synchronize()
+                raise
+            self.graph_fb = g
+        else:                     # two graphs around one host-issued flat all-reduce
+            self._in_graph_comm = False
+            self.graph_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_fb):
+                self.losses = self._fwd_bwd()
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt):
+                self._flat_optim.step()
 
     def replay(self, inject_index=None):
         """One step on whatever the static buffers hold.  inject_index: int in 1..n_latent-1, or None = no mixing."""
         self._inj_host[0] = self.n_latent if inject_index is None else int(inject_index)
         self.inj.copy_(self._inj_host, non_blocking=True)
         self.graph_fb.replay()
-        if self.world > 1 or self.always_reduce:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
-            self.flat_grad.div_(self.world)
-        self.graph_opt.replay()
+        if self.graph_opt is not None:
+            if self._reduce:
+                import torch.distributed as dist
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)      # (the mean's 1 / world is in the backward seed)
+            self.graph_opt.replay()
         # the replayed Adam rewrites the weights without bumping Tensor._version: frozen uses of this student between
         # replays (TrainIteration.d_step, an eval after requires_grad_(False)) must not see stale packed weights
         M.invalidate_caches(self.student)
@@ -447,7 +597,7 @@ class GraphedKDStep(KDStep):
         params = [p for g in self.optim.param_groups for p in g["params"]]
         assert len(ids) == len(params), "optimizer state does not match this student's parameters"
         # hyper-parameters are baked into the captured Adam graph: a checkpoint written with others cannot be honoured here
-        for gs, gl in zip(state_dict["param_groups"], self.optim.param_groups):
+        for gs, gl in zip(state_dict["param_groups"], self._flat_optim.param_groups):      # what the graph actually captured
             for key in ("lr", "betas", "eps", "weight_decay", "amsgrad"):
                 if key not in gs:
                     continue

@@ -1107,3 +1107,67 @@ def masked_l1(student, teacher, mask):
     if use_hip(student) and student.dtype == torch.float32 and one_channel and not mask.requires_grad:
         return _MaskedL1.apply(student, teacher.detach(), mask)
     return torch.mean(torch.abs(teacher.detach() * mask - student * mask))
+
+
+_LOSS_TAIL_WS = {}      # (device index, floats) -> zero-initialised workspace (the kernel leaves its arrival ticket at zero)
+
+
+class _GanKdLossTail(Function):
+    """g_nonsaturating_loss(pred) + lambda * mean|mask*(teacher - student)| and both backward seeds in ONE launch
+    (cagc_gan_kd_loss_tail; reference train.py:203-206, :156-164, :184, :304).  Returns (total, g, kd); only `total` is
+    differentiable.  `grad_scale` is folded into the stored gradients (the 1 / world_size of a data-parallel mean).  With
+    `unit_seed` the caller promises to differentiate `total` with the implicit unit gradient — backward then hands the stored
+    gradients on without the full-size multiply by the upstream scalar."""
+
+    @staticmethod
+    def forward(ctx, pred, student, teacher, mask, lam, grad_scale, unit_seed):
+        s, t = student.contiguous(), teacher.contiguous()
+        B, C, H, W = s.shape
+        m = mask.to(device=s.device, dtype=s.dtype)
+        if m.dim() == 3:
+            m = m.unsqueeze(1)
+        if tuple(m.shape) != (B, 1, H, W):
+            if m.dim() != 4 or m.shape[1] != 1:
+                raise ValueError(f"gan_kd_loss_tail: mask must broadcast to [B,1,H,W] = {(B, 1, H, W)}, got {tuple(mask.shape)}")
+            m = m.expand(B, 1, H, W)
+        m = m.contiguous()
+        pr = pred.contiguous()
+        P = pr.numel()
+        n_ws = int(_lib.query("cagc_gan_kd_loss_tail_ws_floats", B, C, H * W))
+        key = (s.device.index, n_ws, torch.cuda.current_stream(s.device).cuda_stream)
+        ws = _LOSS_TAIL_WS.get(key)
+        if ws is None:
+            ws = _LOSS_TAIL_WS[key] = torch.zeros(n_ws, dtype=torch.float32, device=s.device)
+        out = torch.empty(3, dtype=s.dtype, device=s.device)
+        gs = torch.empty_like(s)
+        gp = torch.empty_like(pr)
+        with _lib.on_device(s):
+            _lib.call("cagc_gan_kd_loss_tail", _lib.ptr(out), _lib.ptr(gs), _lib.ptr(gp), _lib.ptr(pr), P, _lib.ptr(t), _lib.ptr(s),
+                      _lib.ptr(m), B, C, H * W, float(lam), float(grad_scale), _lib.ptr(ws))
+        ctx.save_for_backward(gs, gp)
+        ctx.unit_seed = bool(unit_seed)
+        ctx.pred_shape = pred.shape
+        g, kd = out[0], out[1]
+        ctx.mark_non_differentiable(g, kd)
+        return out[2], g, kd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_total, _g, _kd):
+        gs, gp = ctx.saved_tensors
+        gp = gp.view(ctx.pred_shape)
+        if ctx.unit_seed:
+            return gp, gs, None, None, None, None, None
+        return gp * g_total, gs * g_total, None, None, None, None, None
+
+
+def gan_kd_loss_tail_ok(pred, student, teacher, mask):
+    one_channel = torch.is_tensor(mask) and ((mask.dim() == 3) or (mask.dim() == 4 and mask.shape[1] == 1))
+    return (use_hip(student) and student.dtype == torch.float32 and pred.dtype == torch.float32 and teacher.dtype == torch.float32
+            and one_channel and not mask.requires_grad and student.dim() == 4)
+
+
+def gan_kd_loss_tail(pred, student, teacher, mask, lam, grad_scale=1.0, unit_seed=False):
+    """(total, g_loss, kd_l1) with total = mean softplus(-pred) + lam * mean|mask * (teacher - student)|; the gradients of `total`
+    come out multiplied by `grad_scale`."""
+    return _GanKdLossTail.apply(pred, student, teacher.detach(), mask, lam, grad_scale, unit_seed)

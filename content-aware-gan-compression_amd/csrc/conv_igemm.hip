@@ -29,6 +29,7 @@
 #include "common.h"
 #include "prep_device.h"
 #include "conv_plan.h"
+#include "conv_up4.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -818,6 +819,10 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   // Two launches: the main regions keep the small staging footprint (NV = 4 -> 2 waves / SIMD); the thin strips
   // need longer halo tiles.  Split-K launches accumulate with atomics, so t is zeroed once up front.
   hipStream_t st = as_stream(stream);
+  {   // large launches: the fused-phase persistent kernel (conv_up4.hip)
+    const int u4 = run_conv_up4(a, 0, st, what);
+    if (u4 != CAGC_RD_DECLINED) return u4;
+  }
   {   // register-direct kernel (conv_rd.hip): all four phases over the FULL (H+1) x (W+1) phase grid in one launch — its tiles
       // are runs of the linearised pixel space, so the odd grid wastes nothing, there are no edge strips, and the rows /
       // columns the odd phases do not own come out as the zeros the blur expects (every tap there is out of range)
@@ -957,6 +962,10 @@ extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_b
       if (px == 0) strip_items[ns++] = RawItem{n, taps[ph], 0, 0, Wo, Ho, 1, py, px};                // col X = 2*Wo
     }
   hipStream_t st = as_stream(stream);
+  {   // large launches: the fused-phase persistent kernel (conv_up4.hip) — 8-byte stores of both column parities
+    const int u4 = run_conv_up4(a, 1, st, what);
+    if (u4 != CAGC_RD_DECLINED) return u4;
+  }
   {   // register-direct kernel: the four output parities over their exact (Ho+1-py) x (Wo+1-px) grids, one launch, no strips
     RawItem uni[4];
     for (int ph = 0; ph < 4; ++ph)

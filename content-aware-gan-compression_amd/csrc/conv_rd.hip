@@ -18,6 +18,7 @@
 #include "conv_plan.h"
 #include "conv_wino.h"
 #include "conv_wgrad_rd.h"
+#include "conv_up4.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -825,6 +826,11 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "rd_atomic_below")) t.atomic_below = value;
   else if (!strcmp(key, "rd_split_wgs")) t.split_target = value;
   else if (!strcmp(key, "rd_s2v")) t.s2v = value;
+  else if (!strcmp(key, "up4")) cagc::up4_tuning_on() = value;
+  else if (!strcmp(key, "up4_min_units")) cagc::up4_tuning_min_units() = value;
+  else if (!strcmp(key, "up4_lmin")) cagc::up4_tuning_lmin() = value;
+  else if (!strcmp(key, "up4_rotate")) cagc::up4_tuning_rotate() = value;
+  else if (!strcmp(key, "up4_nb")) cagc::up4_tuning_nb() = value;
   else if (!strcmp(key, "deterministic")) cagc::deterministic_mode() = value;
   else if (!strcmp(key, "wgrad_rd")) cagc::wgrad_rd_set_tuning(value, -1);
   else if (!strcmp(key, "wgrad_rd_wgs")) cagc::wgrad_rd_set_tuning(-1, value);
@@ -848,6 +854,12 @@ extern "C" int cagc_get_tuning(const char* key, int* value) {
   else if (!strcmp(key, "rd_atomic_below")) *value = t.atomic_below;
   else if (!strcmp(key, "rd_split_wgs")) *value = t.split_target;
   else if (!strcmp(key, "rd_s2v")) *value = t.s2v;
+  else if (!strcmp(key, "up4")) *value = cagc::up4_tuning_on();
+  else if (!strcmp(key, "up4_min_units")) *value = cagc::up4_tuning_min_units();
+  else if (!strcmp(key, "up4_lmin")) *value = cagc::up4_tuning_lmin();
+  else if (!strcmp(key, "up4_rotate")) *value = cagc::up4_tuning_rotate();
+  else if (!strcmp(key, "up4_nb")) *value = cagc::up4_tuning_nb();
+  else if (!strcmp(key, "up4_error")) *value = cagc::up4_error_word();
   else if (!strcmp(key, "deterministic")) *value = cagc::deterministic_mode();
   else if (!strcmp(key, "wgrad_rd")) *value = wm;
   else if (!strcmp(key, "wgrad_rd_wgs")) *value = wt;

@@ -1,0 +1,15 @@
+// Fused-phase stride-2 transposed 3x3 convolution (conv_up4.hip): the persistent, stream-K balanced register-direct kernel behind
+// cagc_modconv_up_fwd (mode 0: phase-planar output) and cagc_conv3x3s2_dgrad (mode 1: strided output) on their large launches.
+#pragma once
+#include "conv_plan.h"
+
+namespace cagc {
+// CAGC_RD_DECLINED when the launch is not one it takes (small layers, ragged channel tiles, > 2 GB tensors), else the launch status
+int run_conv_up4(const ConvArgs& a, int mode, hipStream_t st, const char* what);
+int& up4_tuning_on();          // cagc_set_tuning("up4"), CAGC_UP4 (default 1)
+int& up4_tuning_min_units();   // cagc_set_tuning("up4_min_units"), CAGC_UP4_MIN_UNITS: launches with fewer (256 positions x 64 channels) units' worth of work keep conv_rd.hip's kernels
+int& up4_tuning_lmin();        // cagc_set_tuning("up4_lmin"), CAGC_UP4_LMIN: shortest stream-K job in K-steps (default 8)
+int& up4_tuning_rotate();      // cagc_set_tuning("up4_rotate"), CAGC_UP4_ROTATE: K-rotate each workgroup's first whole unit (default 1)
+int& up4_tuning_nb();          // cagc_set_tuning("up4_nb"), CAGC_UP4_NB: 4 (default) = 64 positions per wave, one workgroup per CU; 2 = 32 positions, two per CU
+int up4_error_word();          // cagc_get_tuning("up4_error"): 1 after a bounded stream-K spin gave up (synchronises the device)
+}  // namespace cagc

@@ -344,9 +344,92 @@ __global__ __launch_bounds__(EW_THREADS) void k_masked_l1(float* __restrict__ lo
   if (threadIdx.x == 0) sink_add(det, loss_sum, tot);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The loss tail of the KD generator step in ONE launch (reference train.py:203-206 g_nonsaturating_loss, :156-164 + :184 the
+// content-masked L1 term and the sum `g_loss + kd_l1_loss`, and the backward seeds of both): replaces softplus / neg / mean / zeros /
+// div / mul / add forward and ones / expand / sigmoid-backward / neg / div / mul backward — a serial chain of ~14 five-microsecond
+// launches, each behind a dependency gap, that matters at the per-GPU batch of an 8-GPU run (profiles/r04_graph_bs2_timeline.md).
+//   partial[block] = sum over the block's elements of |mask * (s - t)|;  gs = grad_scale * lambda / n * mask * sign(s - t)
+//   the LAST block to arrive (ticket in ws[0], agent scope; it resets the ticket: the workspace is zeroed once, at allocation) adds
+//   the partials in block order — bit-reproducible, no atomics on floats, no zero fill — and finishes:
+//   out[0] = g = mean softplus(-pred), out[1] = kd = lambda * sum / n, out[2] = g + kd;  gpred = -grad_scale * sigmoid(-pred) / P
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void k_gan_kd_loss_tail(float* __restrict__ out, float* __restrict__ gs, float* __restrict__ gpred,
+                                                                 const float* __restrict__ pred, int P, const float* __restrict__ t,
+                                                                 const float* __restrict__ s, const float* __restrict__ mask, int C,
+                                                                 int64_t HW, int nchunk, float lambda, float inv_n, float grad_scale,
+                                                                 float* __restrict__ ws, int nblocks) {
+  __shared__ float sm[4];
+  __shared__ int last;
+  const int plane = blockIdx.x / nchunk;  // b*C + c
+  const int chunk = blockIdx.x - plane * nchunk;
+  const int b = plane / C;
+  const int64_t base = (int64_t)plane * HW, mbase = (int64_t)b * HW;
+  const int64_t lo = (int64_t)chunk * EW_CHUNK;
+  const float coef = grad_scale * lambda * inv_n;
+  float acc = 0.f;
+  for (int it = 0; it < EW_ITERS * EW_VEC; ++it) {
+    const int64_t i = lo + (int64_t)it * EW_THREADS + threadIdx.x;
+    if (i < HW) {
+      const float m = mask[mbase + i];
+      const float diff = m * s[base + i] - m * t[base + i];
+      acc += fabsf(diff);
+      gs[base + i] = diff > 0.f ? coef * m : (diff < 0.f ? -coef * m : 0.f);
+    }
+  }
+  const float tot = block_sum(acc, sm);
+  int* ticket = reinterpret_cast<int*>(ws);
+  float* partial = ws + 4;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(partial + blockIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through: visible to the last block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int prev = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = prev == nblocks - 1 ? 1 : 0;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!last) return;
+  // fixed-order sum of the partials: thread i takes partials i, i + 256, ... (ascending), then the block tree — the same tree every run
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += EW_THREADS) sum += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  sum = block_sum(sum, sm);
+  float sp = 0.f;
+  for (int i = threadIdx.x; i < P; i += EW_THREADS) {
+    const float x = -pred[i];
+    sp += x > 20.f ? x : log1pf(expf(x));                 // softplus(-pred), torch's threshold (train.py:204)
+    gpred[i] = -grad_scale / (float)P / (1.f + expf(-x));  // d/dpred softplus(-pred) = -sigmoid(-pred)
+  }
+  __syncthreads();
+  sp = block_sum(sp, sm);
+  if (threadIdx.x == 0) {
+    const float g = sp / (float)P, kd = lambda * sum * inv_n;
+    out[0] = g; out[1] = kd; out[2] = g + kd;
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 }  // namespace cagc
 
 using namespace cagc;
+
+extern "C" int64_t cagc_gan_kd_loss_tail_ws_floats(int B, int C, int64_t HW) { return 4 + (int64_t)B * C * cdiv(HW, EW_CHUNK); }
+
+extern "C" int cagc_gan_kd_loss_tail(float* out3, float* gs, float* gpred, const float* pred, int P, const float* t, const float* s,
+                                     const float* mask, int B, int C, int64_t HW, float lambda, float grad_scale, float* ws,
+                                     cagc_stream_t stream) {
+  CAGC_REQUIRE(out3 && gs && gpred && pred && t && s && mask && ws && P > 0 && B > 0 && C > 0 && HW > 0, "cagc_gan_kd_loss_tail: bad argument");
+  const int nchunk = cdiv(HW, EW_CHUNK);
+  const int64_t nb = (int64_t)B * C * nchunk;
+  CAGC_REQUIRE(nb < (1ll << 24), "cagc_gan_kd_loss_tail: too large");
+  const double n = (double)B * C * (double)HW;
+  hipLaunchKernelGGL(k_gan_kd_loss_tail, dim3((unsigned)nb), dim3(EW_THREADS), 0, as_stream(stream), out3, gs, gpred, pred, P, t, s, mask, C,
+                     HW, nchunk, lambda, (float)(1.0 / n), grad_scale, ws, (int)nb);
+  return check_launch("cagc_gan_kd_loss_tail");
+}
 
 extern "C" int cagc_fused_bias_act_fwd(float* out, const float* x, const float* bias, int64_t outer, int64_t C,
                                        int64_t inner, float alpha, float scale, cagc_stream_t stream) {

@@ -22,7 +22,11 @@
  *       (a) every mode: the K-split slabs of FORWARD convolution launches (deterministic mode: of the data-gradient launches too) — a small layer whose reduction is cut across
  *           workgroups writes one partial-sum slab per slice and an ordered reduce adds them (bit-reproducible
  *           activations; no fp32 atomics in any forward pass); >= 4 MB, the largest split output x its slices
- *           (< 32 MB on this path; a launch that would need > 256 MB falls back to not splitting);
+ *           (< 32 MB on this path; a launch that would need > 256 MB falls back to not splitting).  The same scratch holds the
+           partial-sum slabs (128 MB + a 4 KB flag block) of the persistent stream-K kernel behind cagc_modconv_up_fwd /
+           cagc_conv3x3s2_dgrad on their large launches (csrc/conv_up4.hip);  the LDS-staged fallback kernel (CAGC_RD=0, or tensors
+           beyond the register-direct kernels' 32-bit offsets) still splits a small forward layer's K with fp32 atomics in the
+           default mode — the "no fp32 atomics in a forward pass" statement holds for the kernels a launch takes by default;
  *       (b) deterministic mode (cagc_set_tuning("deterministic", 1) / CAGC_DETERMINISTIC=1): the order-independent
  *           reduction sink of the backward pass — 16 bytes per reduced element, < 1 MB on this path.
  *   - ERRORS: every function returns CAGC_OK (0) or a negative code; the message is available from
@@ -51,7 +55,7 @@ extern "C" {
 #define CAGC_ERR_LAUNCH (-2)   /* hipGetLastError() after a launch */
 #define CAGC_ERR_UNSUPPORTED (-3)
 
-#define CAGC_ABI_VERSION 1
+#define CAGC_ABI_VERSION 2 /* 2: round-4 signature / buffer-size changes (cagc_torgb_bwd_finish, cagc_torgb_bwd's gws, the F(4x4) packed layout) + cagc_gan_kd_loss_tail */
 
 typedef void* cagc_stream_t; /* hipStream_t */
 
@@ -442,6 +446,22 @@ int cagc_fromrgb_act_dgrad(float* gx, const float* gout, const float* act_out, c
  * ---------------------------------------------------------------------------------------------- */
 int cagc_masked_l1(float* loss_sum, float* gs, const float* t, const float* s, const float* mask, int B,
                    int C, int64_t HW, float coef, cagc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss tail of the KD generator step in one launch      replaces g_nonsaturating_loss (train.py:203-206), the content-masked L1 term
+ *                                   (train.py:156-164), their sum (:184, :304) and the backward seeds of both.
+ * out3 = { g = mean softplus(-pred), kd = lambda * mean|mask*(t - s)|, g + kd };
+ * gs   [B,C,H,W] = grad_scale * lambda / numel * mask * sign(s - t)      (d(g + kd)/d student image, times grad_scale);
+ * gpred [P]      = -grad_scale * sigmoid(-pred) / P                      (d(g + kd)/d pred, times grad_scale);
+ * pred [P] discriminator scores; t, s [B,C,H,W]; mask [B,1,H,W].
+ * ws: caller-owned workspace of cagc_gan_kd_loss_tail_ws_floats(B, C, HW) floats, ZEROED ONCE when allocated (the kernel keeps its
+ * arrival ticket there and leaves it zero); one workspace must not be used by two launches that can run concurrently.
+ * The per-block partial sums are added in block order by the last block to arrive: bit-reproducible, no float atomics.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t cagc_gan_kd_loss_tail_ws_floats(int B, int C, int64_t HW);
+int cagc_gan_kd_loss_tail(float* out3, float* gs, float* gpred, const float* pred, int P, const float* t, const float* s,
+                          const float* mask, int B, int C, int64_t HW, float lambda, float grad_scale, float* ws,
+                          cagc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * On-device content mask            replaces Batch_Img_Parsing + the mask half of Get_Masked_Tensor

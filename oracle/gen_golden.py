@@ -838,7 +838,8 @@ def _get_masked_tensor_any_dtype(img_tensor, batch_parsing, device, mask_grad=Fa
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["float64", "kd_modes", "fused_act", "upfirdn2d", "modconv", "generator", "kd_step", "discriminator", "contract", "train_iter", "saliency", "content_mask"]
+    # float64 / kd_modes READ kd_step_tiny.npz and the other fixtures: they come last so that a from-scratch regeneration works in one go
+    which = sys.argv[1:] or ["fused_act", "upfirdn2d", "modconv", "generator", "kd_step", "discriminator", "contract", "train_iter", "saliency", "content_mask", "float64", "kd_modes"]
     for w in which:
         print("==", w)
         globals()["gold_" + w]()

@@ -107,6 +107,8 @@ def test_reference_fid_and_ppl_generator_loops_drive_the_product(tmp_path):
     calc.load_patched_inception_v3 = lambda: None
     sys.modules.update(stubs)
     sys.path.append(REF)
+    old_bytecode = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True            # nothing is written into the read-only checkout (no __pycache__)
     try:
         import Evaluation
         sys.modules["Evaluation.calc_inception"] = calc
@@ -134,6 +136,7 @@ def test_reference_fid_and_ppl_generator_loops_drive_the_product(tmp_path):
         img = ppl.Generate_Interpolated_Image(ref_built, batch_size=3, eps=1e-4, device="cpu", latent_dim=24)
         assert tuple(img.shape) == (6, 3, 32, 32) and torch.isfinite(img).all()
     finally:
+        sys.dont_write_bytecode = old_bytecode
         sys.path.remove(REF)
         for k in list(sys.modules):
             if k not in saved:

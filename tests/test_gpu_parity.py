@@ -1098,6 +1098,20 @@ def test_graphed_kd_step_resumes_from_saved_optimizer_state_and_invalidates_froz
     for i in st0:
         assert_close(st1[i]["exp_avg_sq"], st0[i]["exp_avg_sq"], 2e-3, f"resumed Adam second moment {i}")
         assert float(st1[i]["step"]) == float(st0[i]["step"]) == 2.0
+    # advisor round 4: a checkpoint WRITTEN from the graphed step must not carry its aliased state (one shared `step` tensor, moments
+    # that are slices of one buffer) — a plain Adam resumed from it would advance the shared counter once per parameter per step
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = ck.save_checkpoint(td, 2, s0, d0, s0, g_optim=run0)
+        raw = torch.load(path)
+    steps_saved = [st["step"] for st in raw["g_optim"]["state"].values()]
+    assert len({t.data_ptr() for t in steps_saved}) == len(steps_saved), "every parameter owns its step counter in the checkpoint"
+    s2, t2, d2 = build()
+    s2.load_state_dict(raw["g"])
+    eager = kd.KDStep(s2, t2, d2, latent=24)
+    ck.restore_optimizers(raw, eager.optim)
+    eager.g_step(*inputs(steps[1], s2))
+    assert all(float(st["step"]) == 3.0 for st in eager.optim.state_dict()["state"].values()), "plain Adam resumed from the graphed step's checkpoint: t + 1"
     # hyper-parameters live inside the captured Adam graph: a checkpoint written with others is refused, not silently ignored
     bad = {"g_optim": {"state": saved["g_optim"]["state"], "param_groups": [dict(pg, lr=pg["lr"] * 2) for pg in saved["g_optim"]["param_groups"]]}}
     with pytest.raises(ValueError, match="lr"):

@@ -1,6 +1,8 @@
 """-m gpu: RCCL smoke on the hardware there is.  A 1-GPU box cannot run a multi-GPU collective, but it can
-prove that `backend="nccl"` (= librccl on ROCm) initialises, that the flat student-gradient all-reduce sits legally between
-the two HIP-graph replays of `GraphedKDStep.replay` (cagc/kd.py: graph_fb -> all_reduce(flat_grad) -> graph_opt), and that
+prove that `backend="nccl"` (= librccl on ROCm) initialises, that the student-gradient all-reduce runs both ways `GraphedKDStep`
+issues it — `comm="graph"`: four bucket collectives CAPTURED INSIDE the one forward / backward / Adam graph, each launched by the
+post-accumulate hook of its bucket's last gradient (no host-side collective between replays), and the fall-back
+`comm="host"`: graph_fb -> all_reduce(flat_grad) -> graph_opt — and that
 DistributedDataParallel's bucket hooks fire from the custom autograd nodes while the teacher runs on its side stream — at world
 size 1 the reduced gradient must equal the local one, so the results are checked against the same steps without a process
 group.  Replaces the reference's nn.DataParallel (train.py:522-525; intent of Miscellaneous/distributed.py:44-66)."""
@@ -58,18 +60,25 @@ def _worker(port):
     assert float(t[12345]) == 12345.0
 
     with _lib.tuning(deterministic=1):     # bit-reproducible steps: with / without the collective must agree exactly
-        # (1) HIP-graph step with the RCCL all-reduce between the forward/backward graph and the Adam graph
+        # (1) HIP-graph step with the RCCL all-reduces captured inside the graph (comm="graph") and, the fall-back form, as one host-issued
+        #     collective between the forward/backward graph and the Adam graph (comm="host"): both BIT-EQUAL to the collective-free step
         s0, t0, d0 = build()
-        s1, t1, d1 = build()
         ref = kd.GraphedKDStep(s0, t0, d0, B, cu(g["mask"]), random_noise=False, latent=24)
-        red = kd.GraphedKDStep(s1, t1, d1, B, cu(g["mask"]), random_noise=False, latent=24, world_size=1, always_reduce=True)
-        for st in meta["steps"]:
-            la = ref.g_step(*inputs(st, s0.num_layers))
-            lb = red.g_step(*inputs(st, s1.num_layers))
-        torch.cuda.synchronize()
-        worst = max(rel(b.detach(), a.detach()) for (_, a), (_, b) in zip(s0.named_parameters(), s1.named_parameters()))
-        assert worst <= 1e-6, f"graph replay with the world-1 RCCL all-reduce differs from the plain replay: {worst:.2e}"
-        assert abs(float(la["g"]) - float(lb["g"])) <= 1e-6
+        assert ref.comm == "graph" and ref.graph_opt is None, "no collective: one graph"
+        worst = 0.0
+        for comm in ("graph", "host"):
+            s1, t1, d1 = build()
+            red = kd.GraphedKDStep(s1, t1, d1, B, cu(g["mask"]), random_noise=False, latent=24, world_size=1, always_reduce=True, comm=comm)
+            assert red.comm == comm and len(red._buckets) == 4 and (red.graph_opt is None) == (comm == "graph")
+            sr, tr, dr = build()
+            again = kd.GraphedKDStep(sr, tr, dr, B, cu(g["mask"]), random_noise=False, latent=24)
+            for st in meta["steps"]:
+                la = again.g_step(*inputs(st, sr.num_layers))
+                lb = red.g_step(*inputs(st, s1.num_layers))
+            torch.cuda.synchronize()
+            for (n, a), (_, b) in zip(sr.named_parameters(), s1.named_parameters()):
+                assert torch.equal(a.detach(), b.detach()), f"comm={comm}: parameter {n} differs from the collective-free replay ({rel(b.detach(), a.detach()):.2e})"
+            assert float(la["g"]) == float(lb["g"]) and float(la["kd_l1_loss"]) == float(lb["kd_l1_loss"])
         # (2) eager step under DistributedDataParallel: bucket hooks from the custom autograd nodes, teacher on its side stream
         s2, t2, d2 = build()
         s3, t3, d3 = build()
@@ -84,7 +93,7 @@ def _worker(port):
         worst2 = max(rel(b.detach(), a.detach()) for (_, a), (_, b) in zip(s2.named_parameters(), s3.named_parameters()))
         assert worst2 <= 1e-6, f"DDP (world 1, RCCL) step differs from the unwrapped step: {worst2:.2e}"
     dist.destroy_process_group()
-    print(f"RCCL_WORLD1_OK graph {worst:.1e} ddp {worst2:.1e}")
+    print(f"RCCL_WORLD1_OK graph bit-equal (in-graph and host collectives) ddp {worst2:.1e}")
 
 
 def test_rccl_world1_graph_allreduce_and_ddp_hooks():

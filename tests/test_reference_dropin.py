@@ -28,11 +28,14 @@ def ref_utils():
     sys.modules.setdefault("PIL.Image", types.ModuleType("PIL.Image"))
     sys.modules["PIL"].Image = sys.modules["PIL.Image"]
     sys.path.append(REF)                     # AFTER the product: only `Util` is found there
+    old_bytecode = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True           # nothing is written into the read-only checkout (no __pycache__)
     try:
         from Util import mask_util, network_util, pruning_util
         assert network_util.Generator is product_model.Generator   # the reference code is driving the product class
         yield network_util, mask_util, pruning_util
     finally:
+        sys.dont_write_bytecode = old_bytecode
         sys.path.remove(REF)
         for k in [m for m in sys.modules if m == "Util" or m.startswith("Util.")]:
             del sys.modules[k]
