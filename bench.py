@@ -110,8 +110,8 @@ KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false, false", "c
              "cagc_wino_conv3x3_act_dgrad[k_wino<4, true, NH2>]": "k_wino<4, true, false, 2>", "cagc_wino_conv3x3_act_dgrad[k_wino<4, true, NH1>]": "k_wino<4, true, false, 1>",
              "cagc_wino_conv3x3[k_wino4<false>]": "k_wino4<false,", "cagc_wino_conv3x3_act_dgrad[k_wino4<true>]": "k_wino4<true,",   # both SCALE variants
              "cagc_modconv_fwd": "k_conv_rd<4, true, true, false>",
-             "cagc_modconv_up_fwd": "k_conv_rd<8, true, true, false>",
-             "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_act_fwd": "k_conv_s2v", "cagc_conv3x3s2_dgrad": "k_conv_rd<8, true, false, false>",
+             "cagc_modconv_up_fwd": "k_conv_up4<true, 0",
+             "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_act_fwd": "k_conv_s2v", "cagc_conv3x3s2_dgrad": "k_conv_up4<false, 1",
              "cagc_modconv_dgrad": "k_conv_rd<5, true, false, true>",
              "cagc_modconv_up_dgrad": "k_conv_rd<5, true, false, true>", "cagc_modconv_wgrad": "k_wgrad_rd<4, 1, false, 9>",
              "cagc_modconv_wgrad_demod": "k_wgrad_rd<3, 1, false, 9>"}
@@ -126,7 +126,7 @@ def pmc_traffic(symbol):
         return None, "the committed PMC passes profile the 256 px workload"
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_{c}.md") for r in ("r04", "r03")) if os.path.exists(q)), None)
+        path = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_{c}.md") for r in ("r05", "r04", "r03")) if os.path.exists(q)), None)
         if path is None:
             return None, "no committed PMC summary"
         for line in open(path):
@@ -231,6 +231,31 @@ def cpu_baseline(steps=3, batch=16, budget_s=120.0, threads=None):
             "sample": f"{len(times)} timed KD generator step(s) at batch {batch} of the 256px bs16 workload after a batch-2 warm-up; "
                       f"median {med:.1f} s/step (all: {', '.join(f'{t:.1f}' for t in times)} s)",
             "cpu_model": _cpu_model()}
+
+
+def configs0_cpu_forward(runs=3, batch=4, threads=None):
+    """BASELINE configs[0] through the PRODUCT's own CPU path (the composed-PyTorch branches of cagc/op/fused_act.py and
+    cagc/op/upfirdn2d.py — what the reference's ops do on CPU tensors, op/fused_act.py:105-116, op/upfirdn2d.py:146-149): the full
+    256 px Generator forward on random latents at batch 4, plumbing only (no GPU, no oracle).  BASELINE.md §2 has the reference at
+    2.3-2.7 s on 8 cores."""
+    from cagc import model as M
+    cores = threads if threads else min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    gen = M.Generator(256, 512, 8).eval()
+    z = [torch.randn(batch, 512)]
+    times = []
+    with torch.no_grad():
+        gen(z)                                   # warm-up (oneDNN primitive creation)
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            img = gen(z)
+            times.append(time.perf_counter() - t0)
+    assert tuple(img.shape) == (batch, 3, 256, 256) and bool(torch.isfinite(img).all())
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(batch / med, 3), "unit": "images/s", "seconds_per_forward": round(med, 3), "cores": cores, "batch": batch,
+            "what": "configs[0]: 256px StyleGAN2 Generator forward, random latents, bs=4, the product's CPU path (torch-native upfirdn2d / fused_act "
+                    "branches; no HIP library, no oracle)"}
 
 
 def _cpu_model():
@@ -633,7 +658,12 @@ def main():
         teacher.eval()
         kd.requires_grad(teacher, False)
     cpu = None
+    c0 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            c0 = configs0_cpu_forward()
+        except Exception as e:  # noqa: BLE001 — a secondary leg never takes the headline down
+            c0 = {"error": f"{type(e).__name__}: {e}"}
         cpu = cpu_baseline(args.cpu_steps, args.cpu_batch)
         allc = os.cpu_count() or 1
         if allc > cpu["cores"] and args.cpu_all_cores:
@@ -670,9 +700,17 @@ def main():
                                       f"global bs16 ({cfg_txt}); frozen D fwd+dgrad, masked-L1 KD, Adam; LPIPS/BiSeNet off"
                                       + (f"; {share}" if share else ""),
                           "global_batch": bs * world, "per_gpu_batch": bs, "parallelism": f"dp{world}", "launch_mode": mode, "launch_mode_calibration_ms": calib,
-                          "student_params": n_params},
+                          "student_params": n_params,
+                          # what rank 0 saw of the job: the driver can check "RCCL saw N ranks" against its own launch
+                          "world_size_env": world, "dist_initialized": dist.is_initialized(),
+                          "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                          "dist_backend": dist.get_backend() if dist.is_initialized() else None,
+                          # graph mode: "graph" = bucketed RCCL all-reduces captured inside the one step graph, launched from the backward
+                          # as each gradient bucket completes; "host" = one flat all-reduce between two graphs (fallback); eager: DDP buckets
+                          "grad_collective": (getattr(step, "comm", None) if mode == "graph" else "ddp_buckets") if world > 1 else None,
+                          "grad_buckets": len(getattr(step, "_buckets", [])) if (mode == "graph" and world > 1) else None},
                "roofline": roof, "cpu_baseline": cpu, "full_iteration": full, "saliency_sweep": sweep,
-               "strong_scaling_proxy_1gpu": proxy, "deterministic_mode": det, "config3_1024": c3}
+               "strong_scaling_proxy_1gpu": proxy, "deterministic_mode": det, "config3_1024": c3, "configs0_cpu_forward": c0}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

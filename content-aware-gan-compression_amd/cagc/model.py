@@ -145,6 +145,8 @@ class EqualLinear(nn.Module):
         w, b = self.weight, self.bias
         if mc.map_linear_ok(input, self):     # few rows: GEMM + bias (+ LeakyReLU) as one launch, the whole backward as another
             return mc._MapLinear.apply(input, w, b, self.scale, self.lr_mul, bool(self.activation))
+        if input.is_cuda and not mc.composed_active():
+            mc.warn_library_gemm_once(f"EqualLinear({w.shape[1]}, {w.shape[0]}) on a {tuple(input.shape)} {input.dtype} input")
         # the cache is only for FROZEN layers (requires_grad False: teacher, D on the generator step).  A layer that
         # merely runs under no_grad (g_ema sampling) is not cached: the reference's EMA updates weights through `.data`
         # (train.py:129), which does not bump the version counter the cache is validated against.

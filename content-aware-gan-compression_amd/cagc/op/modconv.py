@@ -117,6 +117,18 @@ def _side_stream(dev):
 _stock_conv_warned = set()
 
 
+def warn_library_gemm_once(what):
+    """An EqualLinear on a GPU tensor is about to take a library GEMM (rocBLAS through torch.addmm / F.linear) because the one-launch
+    kernels of csrc/mapping.hip do not cover its pattern (more than 256 rows, in_dim not a multiple of 512, out_dim > 1024, non-fp32).
+    Never on the KD step or the training iteration; said ONCE per pattern, an error under CAGC_STRICT_HIP=1 — like the stock convs."""
+    if os.environ.get("CAGC_STRICT_HIP", "0") == "1":
+        raise RuntimeError(f"cagc: {what} has no HIP kernel and CAGC_STRICT_HIP=1 forbids the library GEMM")
+    if what not in _stock_conv_warned:
+        _stock_conv_warned.add(what)
+        import warnings
+        warnings.warn(f"cagc: {what} runs on a library GEMM (rocBLAS), not on libcagc_hip", RuntimeWarning, stacklevel=3)
+
+
 def warn_stock_conv_once(what):
     """A GPU tensor is about to take a stock PyTorch convolution (MIOpen) because no hand-written kernel covers the layer
     pattern / dtype (non-fp32 modulated convs, EqualConv2d shapes outside conv_closure.supported).  Never on the KD step or
@@ -935,6 +947,7 @@ def map_linear_ok(x, lin):
     """Few-row EqualLinear on the one-launch kernels: the mapping network (512 -> 512, activation) and D's final linears."""
     return (use_hip(x) and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] <= 256 and x.shape[1] % 512 == 0
             and lin.weight.shape[1] == x.shape[1] and lin.weight.dtype == torch.float32
+            and lin.weight.shape[0] <= 1024      # the fallback backward kernel's row buffer (csrc/mapping.hip); never a forward-only launch
             and (lin.bias is not None or not lin.activation) and lin.activation in (None, "fused_lrelu"))
 
 

@@ -602,7 +602,7 @@ static int env_or(const char* name, int dflt) { const char* v = getenv(name); re
 static RdTuning& rd_tuning() {
   static RdTuning t = {env_or("CAGC_RD", 1), env_or("CAGC_RD_MIN_WGS", 512), env_or("CAGC_RD_MB", 0), env_or("CAGC_RD_KW", 0),
                        env_or("CAGC_RD_SPLIT", 1), env_or("CAGC_RD_ATOMIC_BELOW", 160), env_or("CAGC_RD_SPLIT_WGS", 512),
-                       env_or("CAGC_RD_MIN_WGS_LONG", 768), env_or("CAGC_RD_S2V", 1)};
+                       env_or("CAGC_RD_MIN_WGS_LONG", -1), env_or("CAGC_RD_S2V", 1)};
   return t;
 }
 
@@ -689,7 +689,11 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
   // 768 workgroups (round 4 sweeps, gpurun_out/r4_sweep*.log: per-GPU batch 2 / 4 -2 % / -1 %; halving the channel tile as well cost
   // the batch-16 step 0.9 %: twice the B-operand traffic per MFMA)
   const int min_wgs = tune.min_wgs;
-  const int min_wgs_kw = (a.Kp >= 256 && tune.min_wgs_long > tune.min_wgs) ? tune.min_wgs_long : tune.min_wgs;
+  // rd_min_wgs_long = -1 (default): derived from rd_min_wgs here, at plan time — 768 at the default 512, never below rd_min_wgs, and
+  // rd_min_wgs itself when that was lowered — so that setting one knob never rewrites the other (advisor r4)
+  const int long_auto = tune.min_wgs > 768 ? tune.min_wgs : (tune.min_wgs < 512 ? tune.min_wgs : 768);
+  const int min_wgs_long = tune.min_wgs_long >= 0 ? tune.min_wgs_long : long_auto;
+  const int min_wgs_kw = (a.Kp >= 256 && min_wgs_long > tune.min_wgs) ? min_wgs_long : tune.min_wgs;
   const int force_mb = tune.force_mb, force_kw = tune.force_kw, split_on = tune.split_on;
   auto tiles_for = [&](int kw) {
     int64_t t = 0;
@@ -818,7 +822,7 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   CAGC_REQUIRE(key, "cagc_set_tuning: null key");
   cagc::RdTuning& t = cagc::rd_tuning();
   if (!strcmp(key, "rd")) t.mode = value;
-  else if (!strcmp(key, "rd_min_wgs")) { t.min_wgs = value; t.min_wgs_long = value > 768 ? value : (value < 512 ? value : 768); }
+  else if (!strcmp(key, "rd_min_wgs")) t.min_wgs = value;
   else if (!strcmp(key, "rd_min_wgs_long")) t.min_wgs_long = value;
   else if (!strcmp(key, "rd_mb")) t.force_mb = value;
   else if (!strcmp(key, "rd_kw")) t.force_kw = value;
@@ -827,7 +831,7 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "rd_split_wgs")) t.split_target = value;
   else if (!strcmp(key, "rd_s2v")) t.s2v = value;
   else if (!strcmp(key, "up4")) cagc::up4_tuning_on() = value;
-  else if (!strcmp(key, "up4_min_units")) cagc::up4_tuning_min_units() = value;
+  else if (!strcmp(key, "up4_min_ksteps")) cagc::up4_tuning_min_ksteps() = value;
   else if (!strcmp(key, "up4_lmin")) cagc::up4_tuning_lmin() = value;
   else if (!strcmp(key, "up4_rotate")) cagc::up4_tuning_rotate() = value;
   else if (!strcmp(key, "up4_nb")) cagc::up4_tuning_nb() = value;
@@ -855,7 +859,7 @@ extern "C" int cagc_get_tuning(const char* key, int* value) {
   else if (!strcmp(key, "rd_split_wgs")) *value = t.split_target;
   else if (!strcmp(key, "rd_s2v")) *value = t.s2v;
   else if (!strcmp(key, "up4")) *value = cagc::up4_tuning_on();
-  else if (!strcmp(key, "up4_min_units")) *value = cagc::up4_tuning_min_units();
+  else if (!strcmp(key, "up4_min_ksteps")) *value = cagc::up4_tuning_min_ksteps();
   else if (!strcmp(key, "up4_lmin")) *value = cagc::up4_tuning_lmin();
   else if (!strcmp(key, "up4_rotate")) *value = cagc::up4_tuning_rotate();
   else if (!strcmp(key, "up4_nb")) *value = cagc::up4_tuning_nb();

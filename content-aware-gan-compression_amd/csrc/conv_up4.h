@@ -7,7 +7,7 @@ namespace cagc {
 // CAGC_RD_DECLINED when the launch is not one it takes (small layers, ragged channel tiles, > 2 GB tensors), else the launch status
 int run_conv_up4(const ConvArgs& a, int mode, hipStream_t st, const char* what);
 int& up4_tuning_on();          // cagc_set_tuning("up4"), CAGC_UP4 (default 1)
-int& up4_tuning_min_units();   // cagc_set_tuning("up4_min_units"), CAGC_UP4_MIN_UNITS: launches with fewer (256 positions x 64 channels) units' worth of work keep conv_rd.hip's kernels
+int& up4_tuning_min_ksteps();  // cagc_set_tuning("up4_min_ksteps"), CAGC_UP4_MIN_KSTEPS: launches with fewer K-steps (of 64 positions x 64 channels x 4 parities) per workgroup keep conv_rd.hip's kernels (default 288)
 int& up4_tuning_lmin();        // cagc_set_tuning("up4_lmin"), CAGC_UP4_LMIN: shortest stream-K job in K-steps (default 8)
 int& up4_tuning_rotate();      // cagc_set_tuning("up4_rotate"), CAGC_UP4_ROTATE: K-rotate each workgroup's first whole unit (default 1)
 int& up4_tuning_nb();          // cagc_set_tuning("up4_nb"), CAGC_UP4_NB: 4 (default) = 64 positions per wave, one workgroup per CU; 2 = 32 positions, two per CU

@@ -376,15 +376,15 @@ __global__ __launch_bounds__(256, NB == 4 ? 1 : 2) void k_conv_up4(const Up4Args
   clock_probe_end(A.clk, c0, w0);
 }
 
-struct Up4Tuning { int on, min_units, lmin, rotate, nb; };
+struct Up4Tuning { int on, min_ksteps, lmin, rotate, nb; };
 static Up4Tuning& up4_tuning() {
-  static Up4Tuning t = {getenv("CAGC_UP4") ? atoi(getenv("CAGC_UP4")) : 1, getenv("CAGC_UP4_MIN_UNITS") ? atoi(getenv("CAGC_UP4_MIN_UNITS")) : 256,
+  static Up4Tuning t = {getenv("CAGC_UP4") ? atoi(getenv("CAGC_UP4")) : 1, getenv("CAGC_UP4_MIN_KSTEPS") ? atoi(getenv("CAGC_UP4_MIN_KSTEPS")) : 288,
                         getenv("CAGC_UP4_LMIN") ? atoi(getenv("CAGC_UP4_LMIN")) : 8, getenv("CAGC_UP4_ROTATE") ? atoi(getenv("CAGC_UP4_ROTATE")) : 0,
                         getenv("CAGC_UP4_NB") ? atoi(getenv("CAGC_UP4_NB")) : 4};
   return t;
 }
 int& up4_tuning_on() { return up4_tuning().on; }
-int& up4_tuning_min_units() { return up4_tuning().min_units; }
+int& up4_tuning_min_ksteps() { return up4_tuning().min_ksteps; }
 int& up4_tuning_lmin() { return up4_tuning().lmin; }
 int& up4_tuning_rotate() { return up4_tuning().rotate; }
 int& up4_tuning_nb() { return up4_tuning().nb; }
@@ -451,7 +451,10 @@ int run_conv_up4(const ConvArgs& a, int mode, hipStream_t st, const char* what) 
   if (G < 8 || G > 512 || (G / 8) % mt != 0) return CAGC_RD_DECLINED;      // (flag block: 2G words in 4 KB)
   const int ptiles = cdiv((int64_t)a.B * region, TP);
   const int64_t units = (int64_t)ptiles * mt;
-  if (units * nb < (int64_t)tune.min_units * 4) return CAGC_RD_DECLINED;     // small launches: the finer units of conv_rd.hip (below G units everything is stream-K)
+  // Launches that give a workgroup fewer than ~290 K-steps (144 MFMAs per wave each at NB = 4) keep conv_rd.hip's finer units: below
+  // that the stream-K part is most of the launch — every unit is cut across workgroups, its partial sums cross the slab, its owner waits
+  // (measured per layer at batch 4 / 8 / 16, gpurun_out/r5_time_up4_bs48.log: wins from ~300 K-steps per workgroup up, loses below ~280)
+  if (units * (a.Kp / 4) < (int64_t)tune.min_ksteps * G) return CAGC_RD_DECLINED;
 
   Up4Args r;
   memset(&r, 0, sizeof(r));

@@ -415,7 +415,6 @@ extern "C" int cagc_maplin_bwd(float* gx, float* gweight, float* gbias, const fl
   CAGC_REQUIRE(gy && (y || !act) && x && weight && R > 0 && out_dim > 0, "cagc_maplin_bwd: bad argument");
   CAGC_REQUIRE(in_dim > 0 && in_dim % ML_D == 0, "cagc_maplin_bwd: in_dim %d unsupported (multiples of 512 only)", in_dim);
   CAGC_REQUIRE(!gbias || gweight, "cagc_maplin_bwd: the bias gradient comes with the weight gradient");
-  CAGC_REQUIRE(!gx || out_dim <= 1024, "cagc_maplin_bwd: out_dim %d > 1024 unsupported for the input gradient", out_dim);
   CAGC_REQUIRE(((uintptr_t)x % 16) == 0 && (!gweight || ((uintptr_t)gweight % 16) == 0) && (!gx || ((uintptr_t)gx % 8) == 0) &&
                ((uintptr_t)weight % 8) == 0, "cagc_maplin_bwd: unaligned tensor");
   if (mm_ok(R, in_dim, out_dim, gx, gweight, gy, act ? y : nullptr) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)weight % 16) == 0 &&
@@ -430,6 +429,7 @@ extern "C" int cagc_maplin_bwd(float* gx, float* gweight, float* gbias, const fl
     hipLaunchKernelGGL(k_maplin_mfma, dim3(a.nb_x + a.nb_w, gx ? cdiv(R, 16 * MM_RT) : 1), dim3(256), 0, as_stream(stream), a);
     return check_launch("cagc_maplin_bwd");
   }
+  CAGC_REQUIRE(!gx || out_dim <= 1024, "cagc_maplin_bwd: out_dim %d > 1024 unsupported for the input gradient off the matrix-core path", out_dim);
   hipLaunchKernelGGL(k_maplin_bwd, dim3(cdiv(out_dim, 16) + in_dim / 128), dim3(1024), 0, as_stream(stream), gx, gweight, gbias, gy, y, x,
                      weight, R, in_dim, out_dim, scale, lr_mul, act, alpha, act_scale);
   return check_launch("cagc_maplin_bwd");

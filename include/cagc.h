@@ -69,7 +69,9 @@ const char* cagc_last_error(void);
 /* Test / tuning hook: override a launch-shape heuristic of the convolution kernels (process-wide, not synchronised; results
  * never depend on it beyond fp32 rounding: summation order, and for "wino4_min_wgs" the Winograd flavour — F(4x4) and F(2x2)
  * differ by ~1e-5 of the output scale).  Keys: "rd" (0 = LDS-staged kernel only), "rd_min_wgs", "rd_mb", "rd_kw",
- * "rd_split", "rd_atomic_below", "rd_split_wgs", "rd_min_wgs_long", "rd_s2v" (0 = the stride-2 forward's big launches on the general kernel) — see csrc/conv_rd.hip; "wgrad_rd" (0 = LDS-staged weight-gradient kernels
+ * "rd_split", "rd_atomic_below", "rd_split_wgs", "rd_min_wgs_long" (-1 = derived from rd_min_wgs at plan time; setting one key never rewrites another), "rd_s2v" (0 = the stride-2 forward's big launches on the general kernel) — see csrc/conv_rd.hip;
+ * "up4" (0 = the transposed convs / stride-2 data gradients stay on conv_rd.hip's per-parity launches), "up4_min_ksteps", "up4_nb", "up4_lmin", "up4_rotate" (launch shape of the
+ * persistent stream-K kernel) and the read-only "up4_error" (1 after one of its bounded spins gave up; reading it synchronises the device) — csrc/conv_up4.hip; "wgrad_rd" (0 = LDS-staged weight-gradient kernels
  * only), "wgrad_rd_wgs" (workgroups a weight-gradient launch aims at; 0 = its launch model picks the K split, the default) — csrc/conv_wgrad_rd.hip; "wino4_hv" (0 per launch, 1 / 2: 64- / 128-channel workgroup shape of the F(4x4) kernel),
  * "wino4_min_wgs" (64-channel workgroups below which a launch takes the layer's F(2x2) packing; default 256) — csrc/conv_wino4.hip;
  * "deterministic" (also CAGC_DETERMINISTIC=1): forward passes are bit-reproducible run to run in EVERY mode (K splits through
