@@ -63,6 +63,9 @@ constexpr int UP4_SPIN_MAX = 1 << 22;          // x ~1 us sleeps: seconds, then 
 #ifndef CAGC_UP4_STORE_AUX
 #define CAGC_UP4_STORE_AUX 0      // cache policy bits of the epilogue's output stores (raw buffer store aux: 1 sc0, 2 nt, 16 sc1)
 #endif
+#ifndef CAGC_UP4_SLAB_AUX
+#define CAGC_UP4_SLAB_AUX 0       // cache policy bits of the slab stores / loads (16 = sc1: write-through stores, L1-bypassing loads)
+#endif
 #ifdef CAGC_UP4_ABL      // debug builds only (wrong results, timing only): 1 no stores, 2 no B loads, 4 no A loads, 8 phase-planar stores into the slab
 #define UP4_ABL(bit) ((CAGC_UP4_ABL & (bit)) != 0)
 #else
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, NB == 4 ? 1 : 2) void k_conv_up4(const Up4Args
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < NB; ++j) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[p][i][j]), rs, (unsigned)lane * 16u, sb + ((p * 4 + i) * NB + j) * 1024, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[p][i][j]), rs, (unsigned)lane * 16u, sb + ((p * 4 + i) * NB + j) * 1024, CAGC_UP4_SLAB_AUX);
             if (j == NB - 1) __builtin_amdgcn_sched_barrier(0);      // keep the accumulator reads next to their stores (no 256-register staging)
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256, NB == 4 ? 1 : 2) void k_conv_up4(const Up4Args
       f32x4 v = acc[p][i][j];
       int sb = (first_slot * 4 + wave) * WSL + ((p * 4 + i) * NB + j) * 1024;
       for (int c = 0; c < nc; ++c, sb += 4 * WSL)
-        v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)lane * 16u, sb, 0));
+        v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)lane * 16u, sb, CAGC_UP4_SLAB_AUX));
       return v;
     };
     // ---- epilogue: lane holds positions j*16 + 4g .. + 3 of channel mtile*64 + i*16 + lm, all four parities ----
@@ -313,7 +316,12 @@ __global__ __launch_bounds__(256, NB == 4 ? 1 : 2) void k_conv_up4(const Up4Args
           for (int py = 0; py < 2; ++py) {
             const f32x4 e = nc == 0 ? acc[2 * py][i][j] : gather(2 * py, i, j);
             const f32x4 o = nc == 0 ? acc[2 * py + 1][i][j] : gather(2 * py + 1, i, j);
-            const f32x4 lo = {e[0], o[0], e[1], o[1]}, hi = {e[2], o[2], e[3], o[3]};
+            f32x4 lo = {e[0], o[0], e[1], o[1]}, hi = {e[2], o[2], e[3], o[3]};
+            // the interleaved quads must be assembled in VGPRs: left alone hipcc builds them IN PLACE OF LIVE ACCUMULATORS (saves a[100:103]
+            // to VGPRs, v_accvgpr_write / _mov the quad into them, stores from a[100:103], restores) and rewrites those registers two
+            // instructions behind the store that reads them — intermittently wrong outputs with two waves per SIMD (scripts/stress_up4.py:
+            // 25 - 70 % of launches); no v_accvgpr_write may appear anywhere in this kernel
+            asm volatile("" : "+v"(lo), "+v"(hi));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), ro, py ? oodd[j] : ooff[j], i * 16 * chan, CAGC_UP4_STORE_AUX);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), ro, py ? oodd2[j] : ooff2[j], i * 16 * chan, CAGC_UP4_STORE_AUX);
           }

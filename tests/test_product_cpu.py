@@ -189,3 +189,31 @@ def test_configs0_full_256_generator_forward_bs4_on_the_products_cpu_path():
     err = float((img.double() - ref.double()).abs().max() / ref.double().abs().max())
     assert err <= 1e-4, err            # north-star bar 1e-3; two fp32 CPU evaluations of the same network agree to ~1e-6
     print(f"configs[0] CPU forward bs4: {dt:.2f} s (reference: 2.3-2.7 s on 8 cores, BASELINE.md §2), max rel err vs oracle {err:.1e}")
+
+
+def test_fused_phase_kernel_keeps_its_accumulators_in_the_accumulator_file():
+    """csrc/conv_up4.hip holds its 128 / 256 sums in AGPRs that only its asm MFMAs write.  hipcc once used live accumulators as staging
+    registers for the strided epilogue (v_accvgpr_write into a[100:103], store, restore) — intermittently wrong outputs on the GPU.  The
+    audit cdna_hip_programming.md §5.7 item 4 prescribes: no v_accvgpr_write / v_accvgpr_mov, no scratch, in any k_conv_up4 variant."""
+    import shutil
+    import subprocess
+    import tempfile
+    import pytest
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(ROOT, "content-aware-gan-compression_amd", "csrc", "conv_up4.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "up4.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-S", "--cuda-device-only", src, "-o", out],
+                       check=True, capture_output=True, timeout=600)
+        text = open(out).read()
+    kernels = [blk for blk in text.split("\n_ZN4cagc10k_conv_up4")[1:]]
+    assert len(kernels) >= 8, "eight variants: SCALE x MODE x NB"
+    for blk in kernels:
+        body = blk.split("s_endpgm")[0]
+        name = "k_conv_up4" + body.split(":")[0]
+        assert body.count("v_mfma_f32_16x16x4_f32") >= 288, name
+        for bad in ("v_accvgpr_write", "v_accvgpr_mov", "scratch_"):
+            assert bad not in body, (name, bad)
