@@ -333,7 +333,7 @@ class GraphedKDStep(KDStep):
 
     Data parallel (reference train.py:522-525 DistributedDataParallel, Miscellaneous/distributed.py:57-66): gradients live in ONE flat
     buffer laid out in the order in which backward produces them (probed once, eagerly) and cut into `n_buckets` contiguous buckets;
-    the post-accumulate hook of a bucket's last parameter gathers the bucket into its slice and issues its RCCL all-reduce FROM INSIDE
+    the post-accumulate hook of whichever parameter completes a bucket gathers the bucket into its slice and issues its RCCL all-reduce FROM INSIDE
     the captured backward (`comm='graph'`: the collective is a graph node on RCCL's stream that depends only on that bucket — it runs
     beside the rest of the backward, and Adam waits for all of them; the 1 / world_size of the mean is folded into the backward seed
     by the loss tail).  If capturing a collective fails on some rank, every rank falls back to `comm='host'`: two graphs with one
@@ -370,12 +370,16 @@ class GraphedKDStep(KDStep):
         self._in_graph_comm = False
         self._works = []
         self._params = self._probe_grad_order([p for p in self.student.parameters()])
-        n_flat = sum(p.numel() for p in self._params)
-        self.flat_grad = torch.zeros(n_flat, device=dev)
-        self._grad_views, off = [], 0
+        # every parameter starts at a 16-byte boundary of the flat buffers (the kernels' vector loads want aligned weights: p.data is
+        # re-pointed into the flat parameter); the <= 3 padding elements behind a parameter hold zeros (zero gradient, zero weight)
+        self._offs, off = [], 0
         for p in self._params:
-            self._grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            self._offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        n_flat = off
+        self.flat_grad = torch.zeros(n_flat, device=dev)
+        self._pad = torch.zeros(4, device=dev)
+        self._grad_views = [self.flat_grad[o:o + p.numel()].view_as(p) for o, p in zip(self._offs, self._params)]
         self._plan_buckets(max(1, int(n_buckets)))
         self._flatten_optimizer(n_flat, dev)
         self.losses = None
@@ -421,7 +425,8 @@ class GraphedKDStep(KDStep):
         requires_grad(self.disc, False)
         try:
             z = [torch.randn_like(self.z[0]), torch.randn_like(self.z[1])]
-            total, _, _ = self.g_total(z, self.inj, self.mask, self.s_noise, self.t_noise)
+            inj = torch.full_like(self.inj, max(1, self.n_latent // 2))      # with style mixing: both passes through the mapping network
+            total, _, _ = self.g_total(z, inj, self.mask, self.s_noise, self.t_noise)
             total.backward()
         finally:
             for h in hooks:
@@ -434,7 +439,7 @@ class GraphedKDStep(KDStep):
 
     def _plan_buckets(self, n_buckets):
         """contiguous slices of the flat buffer of ~equal size, cut at parameter boundaries: (lo, hi, first param, last param + 1)"""
-        sizes = [p.numel() for p in self._params]
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self._params]      # padded extents (16-byte aligned starts)
         total, target = sum(sizes), sum(sizes) / n_buckets
         self._buckets, lo, first, acc = [], 0, 0, 0
         for i, n in enumerate(sizes):
@@ -443,18 +448,30 @@ class GraphedKDStep(KDStep):
                 self._buckets.append((lo, acc, first, i + 1))
                 lo, first = acc, i + 1
         assert self._buckets[-1][1] == total
-        self._closer = {id(self._params[b[3] - 1]): k for k, b in enumerate(self._buckets)}
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params if id(p) in self._closer]
+        # a bucket closes when ALL of its parameters have their gradient — counted, not "when its last parameter in the probed order
+        # fires": the order inside a bucket changes with the autograd graph (style mixing adds a second pass through the mapping network)
+        self._bucket_of = {}
+        for k, bk in enumerate(self._buckets):
+            for q in self._params[bk[2]:bk[3]]:
+                self._bucket_of[id(q)] = k
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params]
         self._armed = False
 
     def _on_grad(self, p):
         if self._armed:
-            self._close_bucket(self._closer[id(p)])
+            k = self._bucket_of[id(p)]
+            self._arrived[k] += 1
+            if self._arrived[k] == self._buckets[k][3] - self._buckets[k][2]:
+                self._close_bucket(k)
 
     def _close_bucket(self, k):
         """gather bucket k's fresh gradients into its slice of the flat buffer and, under comm='graph', launch its all-reduce"""
         lo, hi, first, last = self._buckets[k]
-        grads = [(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1) for q in self._params[first:last]]
+        grads = []
+        for q in self._params[first:last]:
+            grads.append((q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1))
+            if q.numel() % 4:
+                grads.append(self._pad[:4 - q.numel() % 4])
         torch.cat(grads, out=self.flat_grad[lo:hi])
         self._closed[k] = True
         if self._in_graph_comm:
@@ -470,11 +487,10 @@ class GraphedKDStep(KDStep):
         must never reach a checkpoint (a plain Adam loaded from it would advance the shared counter once per parameter):
         `optim_state_dict()` exports per-parameter clones, and `checkpoint.save_checkpoint` uses it."""
         with torch.no_grad():
-            flat_p = torch.cat([p.detach().reshape(-1) for p in self._params]).contiguous()
-            off = 0
-            for p in self._params:
-                p.data = flat_p[off:off + p.numel()].view_as(p)
-                off += p.numel()
+            flat_p = torch.zeros(n_flat, device=dev)
+            for o, p in zip(self._offs, self._params):
+                flat_p[o:o + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = flat_p[o:o + p.numel()].view_as(p)
         M.invalidate_caches(self.student)
         self._flat_param = torch.nn.Parameter(flat_p)
         self._flat_param.grad = self.flat_grad
@@ -484,11 +500,9 @@ class GraphedKDStep(KDStep):
         flat_m, flat_v = torch.zeros(n_flat, device=dev), torch.zeros(n_flat, device=dev)
         step = torch.zeros((), dtype=torch.float32, device=dev)
         self._flat_optim.state[self._flat_param] = {"step": step, "exp_avg": flat_m, "exp_avg_sq": flat_v}
-        off = 0
-        for p in self._params:
+        for off, p in zip(self._offs, self._params):
             n = p.numel()
             self.optim.state[p] = {"step": step, "exp_avg": flat_m[off:off + n].view_as(p), "exp_avg_sq": flat_v[off:off + n].view_as(p)}
-            off += n
 
     def optim_state_dict(self):
         """`optim.state_dict()` with every tensor CLONED per parameter (own `step` counters, own moments): what a checkpoint may hold.
@@ -507,13 +521,14 @@ class GraphedKDStep(KDStep):
         for p in self._params:
             p.grad = None
         self._closed = [False] * len(self._buckets)
+        self._arrived = [0] * len(self._buckets)
         self._works = []
         self._armed = True
         try:
             total.backward()
         finally:
             self._armed = False
-        for k, done in enumerate(self._closed):      # buckets whose closing parameter received no gradient
+        for k, done in enumerate(self._closed):      # buckets with a parameter that received no gradient
             if not done:
                 self._close_bucket(k)
         for w in self._works:                        # Adam (and everything after) waits for the collectives: the join of RCCL's stream

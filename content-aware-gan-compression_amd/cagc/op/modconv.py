@@ -62,19 +62,17 @@ def _first_order_only(what):
                            "leave the discriminator's parameters trainable")
 
 
-_flip_cache = {}
-
-
 def _flipped(fir):
-    """fir flipped along both axes (the adjoint FIR), cached per tensor OBJECT: saves a flip + copy launch per backward
-    call.  The entry keeps a reference to `fir`, so neither its id nor its storage can be recycled while it is cached."""
-    e = _flip_cache.get(id(fir))
-    if e is None or e[0] is not fir or e[1] != fir._version:
-        if len(_flip_cache) > 64:
-            _flip_cache.clear()
-        e = (fir, fir._version, torch.flip(fir.detach(), [0, 1]).contiguous())
-        _flip_cache[id(fir)] = e
-    return e[2]
+    """fir flipped along both axes (the adjoint FIR), cached ON the tensor object (attribute `_cagc_flip`): saves a flip + copy launch per
+    backward call.  The cache entry lives exactly as long as `fir` (a module buffer) does.  It used to live in a module-level dict that
+    was cleared beyond 64 entries: a captured HIP graph holds the flipped tensor's ADDRESS, so a clear triggered by any other model's
+    backward freed memory a graph kept reading (garbage FIR taps in every replayed discriminator data gradient — round 5, found when a
+    test sequence pushed the dict past 64 entries)."""
+    e = getattr(fir, "_cagc_flip", None)
+    if e is None or e[0] != fir._version:
+        e = (fir._version, torch.flip(fir.detach(), [0, 1]).contiguous(), {})
+        fir._cagc_flip = e
+    return e[1]
 
 
 def use_hip(t):
@@ -699,19 +697,15 @@ class _BlurDownConv1x1(Function):
 # ---------------------------------------------------------------------------------------------------
 # Frozen discriminator ResBlock (generator step): one autograd node
 # ---------------------------------------------------------------------------------------------------
-_flip_scaled_cache = {}
-
-
 def _flipped_scaled(fir, scale):
-    """flip(fir) * scale, cached per tensor object (see _flipped)."""
-    key = (id(fir), float(scale))
-    e = _flip_scaled_cache.get(key)
-    if e is None or e[0] is not fir or e[1] != fir._version:
-        if len(_flip_scaled_cache) > 64:
-            _flip_scaled_cache.clear()
-        e = (fir, fir._version, (_flipped(fir) * scale).contiguous())
-        _flip_scaled_cache[key] = e
-    return e[2]
+    """flip(fir) * scale, cached on the tensor object next to its flip (see _flipped)."""
+    base = _flipped(fir)
+    scaled = fir._cagc_flip[2]
+    key = float(scale)
+    t = scaled.get(key)
+    if t is None:
+        t = scaled[key] = (base * scale).contiguous()
+    return t
 
 
 class _ResBlockFrozen(Function):
@@ -1147,10 +1141,16 @@ class _GanKdLossTail(Function):
         pr = pred.contiguous()
         P = pr.numel()
         n_ws = int(_lib.query("cagc_gan_kd_loss_tail_ws_floats", B, C, H * W))
-        key = (s.device.index, n_ws, torch.cuda.current_stream(s.device).cuda_stream)
-        ws = _LOSS_TAIL_WS.get(key)
-        if ws is None:
-            ws = _LOSS_TAIL_WS[key] = torch.zeros(n_ws, dtype=torch.float32, device=s.device)
+        if torch.cuda.is_current_stream_capturing():
+            # under HIP-graph capture the workspace belongs to the graph and its zero fill is a graph node: a cached tensor first
+            # created during a capture would have been "zeroed" only inside that graph's replays (a later capture that found it in the
+            # cache read a never-initialised arrival ticket: no block took the "last" branch, the D-score gradient stayed garbage)
+            ws = torch.zeros(n_ws, dtype=torch.float32, device=s.device)
+        else:
+            key = (s.device.index, n_ws, torch.cuda.current_stream(s.device).cuda_stream)
+            ws = _LOSS_TAIL_WS.get(key)
+            if ws is None:
+                ws = _LOSS_TAIL_WS[key] = torch.zeros(n_ws, dtype=torch.float32, device=s.device)
         out = torch.empty(3, dtype=s.dtype, device=s.device)
         gs = torch.empty_like(s)
         gp = torch.empty_like(pr)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel sums of one PMC counter from a rocprofv3 rocpd database (counters_collection view), restricted to the
-last K marker-delimited steps like rocpd_stats.py.   rocpd_pmc.py results.db [--marker k_masked_l1 --last 2] [--top 25]"""
+last K marker-delimited steps like rocpd_stats.py.   rocpd_pmc.py results.db [--marker k_gan_kd_loss_tail --last 2] [--top 25]"""
 import argparse
 import sqlite3
 

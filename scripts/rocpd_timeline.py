@@ -4,13 +4,13 @@ the wall time per step, the time at least one kernel is running (union of the di
 kernels, the average number of kernels in flight, and where the idle time sits (largest gaps with the kernels around them) —
 the view the small-per-GPU-batch work needs: a HIP-graph replay is bound by the dependency chain's gaps, not by kernel sums.
 
-    rocpd_timeline.py results.db --marker k_masked_l1 --last 4 [--gaps 25] [--chain]"""
+    rocpd_timeline.py results.db --marker k_gan_kd_loss_tail --last 4 [--gaps 25] [--chain]"""
 import argparse
 import sqlite3
 
 ap = argparse.ArgumentParser()
 ap.add_argument("db")
-ap.add_argument("--marker", default="k_masked_l1")
+ap.add_argument("--marker", default="k_gan_kd_loss_tail")
 ap.add_argument("--last", type=int, default=4)
 ap.add_argument("--gaps", type=int, default=25)
 ap.add_argument("--dump", action="store_true", help="print every dispatch of the LAST step: start offset, duration, name")
