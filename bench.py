@@ -629,10 +629,13 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()      # bs-64 fwd+bwd of the full generator: start from a released cache, whatever ran before
-        # This leg is BIMODAL PER PROCESS ON SOME BOXES (417 - 491 img/s against 522 - 554; one box 4 slow runs of 6, the next box 0 of 10,
-        # same code and flags: gpurun_out/diag_sweep3.log, diag_sweep_ab.log) — at the SAME shader clock in both modes (2285 - 2300 MHz,
-        # reported below), with or without any other leg before it, with or without the probe (interleaved A/B 544.5 vs 543.8 img/s).
-        # Not the power limit, not leg order, not the probe; cause not found.  The KD step on the same boxes is not affected.
+        # Rounds 3-4 called this leg "bimodal per process" (417 - 491 img/s against 522 - 554).  Round 5 (scripts/sweep_modes.py,
+        # profiles/r05_sweep_episodes.log: ten consecutive 3-batch segments in each of 8 processes): it is not per process — about one
+        # segment in eight runs 8 - 25 % slow and the next one is fast again, at the SAME in-kernel shader clock (2250 - 2290 MHz), and in a
+        # slow episode exactly two entry points are slower, the two that are both MFMA- and HBM-heavy at batch 64: cagc_modconv_wgrad_demod
+        # (66.5 -> 82.2 ms per batch) and the F(4x4) Winograd forward (40.0 -> 55.0 ms); every other kernel is within 2 %.  No allocation,
+        # launch-plan or address difference goes with it (same process, same tensors).  Reading: a board-level power / memory-clock
+        # management episode the shader-clock probe cannot see.  The leg therefore reports the MEDIAN batch as well as the mean.
         # BASELINE configs[4]: prune.py's content-aware saliency sweep over the FULL 256 px generator, bs 64 (forward +
         # backward incl. weight gradients of the 512-channel layers); bounded here to a few batches
         from cagc import prune
@@ -647,11 +650,17 @@ def main():
         if not args.no_sweep_clock:
             _lib.load().cagc_set_clock_probe(_ct2.c_void_p(sw_clk.data_ptr()))  # KD step's time is unchanged by it (30.09 vs 30.08 ms)
         t2 = time.perf_counter()
-        sc = prune.content_aware_scores(teacher, 64 * nb, 64, 0.05, mfn, dev)
-        torch.cuda.synchronize()
+        per_batch = []
+        for _ in range(nb):      # one bs-64 batch per call: per-batch wall times for the median (a transient slow episode hits 1 - 3 batches)
+            tb = time.perf_counter()
+            sc = prune.content_aware_scores(teacher, 64, 64, 0.05, mfn, dev)
+            torch.cuda.synchronize()
+            per_batch.append(time.perf_counter() - tb)
         dts = time.perf_counter() - t2
         _lib.load().cagc_set_clock_probe(None)
-        sweep = {"value": round(64 * nb / dts, 2), "unit": "images/s", "batches": nb, "batch_size": 64,
+        med_b = sorted(per_batch)[len(per_batch) // 2]
+        sweep = {"value": round(64 * nb / dts, 2), "value_median_batch": round(64 / med_b, 2), "slowest_batch_ms": round(max(per_batch) * 1e3, 1),
+                 "median_batch_ms": round(med_b * 1e3, 1), "unit": "images/s", "batches": nb, "batch_size": 64,
                  "shader_clock_mhz": round(float(sw_clk[0] / sw_clk[1])) if float(sw_clk[1]) > 0 else None,
                  "what": "content-aware saliency sweep, full 256px generator fwd+bwd (271 GFLOP/img), on-device mask/noise/score",
                  "tflops": round(64 * nb / dts * 271e9 / 1e12, 1), "score_layers": len(sc)}

@@ -19,6 +19,17 @@ t0 = time.perf_counter()
 prune.content_aware_scores(teacher, 64 * nb, 64, 0.05, mfn, dev)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+import ctypes
+segs = []
+clk = torch.zeros(2, device=dev)
+for seg in range(int(os.environ.get("SEGS", "0"))):      # consecutive timed segments of 3 batches with the in-kernel shader-clock probe
+    clk.zero_(); _lib.load().cagc_set_clock_probe(ctypes.c_void_p(clk.data_ptr()))
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    prune.content_aware_scores(teacher, 64 * 3, 64, 0.05, mfn, dev)
+    torch.cuda.synchronize(); d1 = time.perf_counter() - t1
+    _lib.load().cagc_set_clock_probe(None)
+    segs.append((round(64 * 3 / d1, 1), round(float(clk[0] / clk[1].clamp(min=1)))))
+if segs: print("segments (img/s, MHz):", segs)
 with bench.KernelTimer(_lib) as kt:
     prune.content_aware_scores(teacher, 64 * 2, 64, 0.05, mfn, dev)
 agg = kt.summary()
