@@ -384,6 +384,8 @@ class GraphedKDStep(KDStep):
         self._flatten_optimizer(n_flat, dev)
         self.losses = None
         self.comm = None
+        if comm == "auto" and os.environ.get("CAGC_GRAPH_COMM") in ("graph", "host"):
+            comm = os.environ["CAGC_GRAPH_COMM"]      # operator override: "host" = never capture a collective
         modes = ["graph", "host"] if comm == "auto" else [comm]
         if not self._reduce:
             modes = ["graph"]                 # nothing to communicate: one graph
@@ -571,7 +573,11 @@ class GraphedKDStep(KDStep):
             self._in_graph_comm = self._reduce
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g):
+                # thread-local capture-error mode while collectives are captured: RCCL's watchdog thread may query events of earlier
+                # (already finished) collectives while this thread captures; under the default "global" mode such a query from ANOTHER
+                # thread invalidates the capture.  Kernels launched by the autograd worker thread on the capturing stream are captured
+                # in either mode (capture is a property of the stream).
+                with torch.cuda.graph(g, capture_error_mode="thread_local" if self._in_graph_comm else "global"):
                     self.losses = self._fwd_bwd()
                     self._flat_optim.step()
             except Exception:

@@ -107,13 +107,24 @@ def test_full_iteration_gpu_matches_reference():
 
 
 @pytest.mark.gpu
-def test_full_iteration_gpu_matches_reference_winograd_f4():
-    """Same golden with the default kernels: D(32)'s 512-channel 32x32 layers run on Winograd F(4x4,3x3), whose activations differ
-    from the fp32 reference's by ~1e-5 instead of ~1e-6 — more LeakyReLU gates of the tiny random discriminator land on the other
-    side of 0 than with F(2x2), each moving a 3x3 patch of a gradient; observed up to 9.1e-3 on a student gradient
-    of this 4-sample, 32 px golden, 2.7e-4 on the Adam-step checksum — so this run only pins the trajectory loosely.  The kernel itself is held to 5e-5 per layer (tests/test_wino4_gpu.py) and the
-    discriminator to the common-gate protocol (test_discriminator_vs_float64_reference, tests/test_second_order_gpu.py)."""
-    _run("cuda", 5e-4, 5e-4)
+def test_full_iteration_gpu_matches_reference_default_kernels():
+    """Same golden with the library's DEFAULT launch policy, at the north-star bar: every G-step gradient <= 30 * 3.3e-5 = 1e-3 of the
+    reference's fp32 values with NO gate forcing (observed: passes at 3.4e-5).  Since round 4 F(4x4)
+    Winograd is chosen per launch, only when the grid fills the chip — D(32)'s 512-channel 32x32 layers at batch 4 are 128 workgroups and
+    take their F(2x2) packing, so the default kernels meet the bounds the golden has always been held to."""
+    _run("cuda", 3.3e-5, 2e-4)
+
+
+@pytest.mark.gpu
+def test_full_iteration_gpu_trajectory_with_f4_forced():
+    """F(4x4,3x3) forced on every eligible layer (`wino4_min_wgs` = 0): its activations differ from the fp32 reference's by ~1e-5 instead
+    of ~1e-6, so more LeakyReLU gates of the tiny random discriminator land on the other side of 0, each moving a 3x3 patch of a gradient
+    (DESIGN §2); observed up to 9.1e-3 on a student gradient of this 4-sample, 32 px golden — this run only pins the trajectory loosely.
+    The kernel itself is held to 5e-5 per layer (tests/test_wino4_gpu.py), the real-size step to the common-gate protocol AND to 1e-3 on
+    the oracle's own gates (tests/test_bench_selection_gpu.py)."""
+    from cagc import _lib
+    with _lib.tuning(wino4_min_wgs=0):
+        _run("cuda", 5e-4, 5e-4)
 
 
 def test_oracle_full_iteration_pieces_match_reference():
