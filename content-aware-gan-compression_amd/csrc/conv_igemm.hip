@@ -820,6 +820,8 @@ extern "C" int cagc_modconv_up_fwd(float* t, const float* x, const float* wp, co
   // need longer halo tiles.  Split-K launches accumulate with atomics, so t is zeroed once up front.
   hipStream_t st = as_stream(stream);
   {   // large launches: the fused-phase persistent kernel (conv_up4.hip)
+    const int u25 = run_conv_up25(a, 0, st, what);
+    if (u25 != CAGC_RD_DECLINED) return u25;
     const int u4 = run_conv_up4(a, 0, st, what);
     if (u4 != CAGC_RD_DECLINED) return u4;
   }
@@ -963,6 +965,8 @@ extern "C" int cagc_conv3x3s2_dgrad(float* gx, const float* g, const float* wp_b
     }
   hipStream_t st = as_stream(stream);
   {   // large launches: the fused-phase persistent kernel (conv_up4.hip) — 8-byte stores of both column parities
+    const int u25 = run_conv_up25(a, 1, st, what);
+    if (u25 != CAGC_RD_DECLINED) return u25;
     const int u4 = run_conv_up4(a, 1, st, what);
     if (u4 != CAGC_RD_DECLINED) return u4;
   }

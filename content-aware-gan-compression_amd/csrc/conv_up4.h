@@ -12,4 +12,12 @@ int& up4_tuning_lmin();        // cagc_set_tuning("up4_lmin"), CAGC_UP4_LMIN: sh
 int& up4_tuning_rotate();      // cagc_set_tuning("up4_rotate"), CAGC_UP4_ROTATE: K-rotate each workgroup's first whole unit (default 1)
 int& up4_tuning_nb();          // cagc_set_tuning("up4_nb"), CAGC_UP4_NB: 4 (default) = 64 positions per wave, one workgroup per CU; 2 = 32 positions, two per CU
 int up4_error_word();          // cagc_get_tuning("up4_error"): 1 after a bounded stream-K spin gave up (synchronises the device)
+int up4_launch_count();        // cagc_get_tuning("up4_launches"): launches this process sent to the kernel (tests)
+int* up4_err_word_ptr();       // the library's device error word (shared with conv_up25.hip)
+// Winograd-domain variant (conv_up25.hip): 25 instead of 36 position-GEMMs per 2x2 tile of positions; same contract as run_conv_up4
+int run_conv_up25(const ConvArgs& a, int mode, hipStream_t st, const char* what);
+int& up25_tuning_on();         // cagc_set_tuning("up25"), CAGC_UP25
+int& up25_tuning_min_ksteps(); // cagc_set_tuning("up25_min_ksteps"), CAGC_UP25_MIN_KSTEPS
+int up25_launch_count();      // cagc_get_tuning("up25_launches"): launches this process sent to the kernel (tests)
+int& up25_tuning_lmin();       // cagc_set_tuning("up25_lmin"), CAGC_UP25_LMIN
 }  // namespace cagc

@@ -408,6 +408,10 @@ static int* up4_err_word() {
   return p;
 }
 
+int* up4_err_word_ptr() { return up4_err_word(); }
+static int g_up4_launches = 0;
+int up4_launch_count() { return g_up4_launches; }
+
 int up4_error_word() {      // 1 after a bounded spin gave up (a contributor never published): the outputs of that launch are garbage
   int* p = up4_err_word();
   int v = 0;
@@ -508,6 +512,7 @@ int run_conv_up4(const ConvArgs& a, int mode, hipStream_t st, const char* what) 
     if (dbg) fprintf(stderr, "[cagc] %s: UP4 mode %d scale %d G %d mt %d ptiles %d q %d r %d L %d J %d K %d M %d\n", what, mode,
                      (int)(a.in_scale != nullptr), G, mt, ptiles, r.q, r.r, r.skL, r.skJ, a.Kp, a.Mp);
   }
+  ++g_up4_launches;
   const dim3 grid((unsigned)G), block(256);
   const int variant = (a.in_scale ? 1 : 0) + 2 * mode + 4 * (nb == 4 ? 1 : 0);
   switch (variant) {

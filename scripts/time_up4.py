@@ -20,7 +20,8 @@ def timeit(f):
     for _ in range(3): f()
     torch.cuda.synchronize(); _lib.load().cagc_set_clock_probe(None)
     return dt, float(clk[0] / clk[1].clamp(min=1))
-tot = {0: 0.0, 1: 0.0}
+MODES = [("rd", dict(up4=0, up25=0)), ("up4", dict(up4=1, up25=0)), ("up25", dict(up4=1, up25=1))]
+tot = {m: 0.0 for m, _ in MODES}
 for (cin, cout, H) in [(512, 512, 16), (512, 512, 32), (512, 256, 64), (256, 128, 128)]:
     wt = torch.randn(1, cout, cin, 3, 3, device="cuda")
     wp_fwd, _, _ = mc.pack_weights(wt, True)
@@ -29,11 +30,11 @@ for (cin, cout, H) in [(512, 512, 16), (512, 512, 32), (512, 256, 64), (256, 128
     t = torch.empty(B, cout, 4, H + 1, P, device="cuda")
     fl = 2.0 * B * cin * cout * 9 * H * H
     row = f"up_fwd {cin}->{cout} @{H}^2:"
-    for up4 in (0, 1):
-        with _lib.tuning(up4=up4):
+    for name, kn in MODES:
+        with _lib.tuning(**kn):
             dt, c = timeit(lambda: _lib.call("cagc_modconv_up_fwd", _lib.ptr(t), _lib.ptr(x), _lib.ptr(wp_fwd), _lib.ptr(s), B, cin, cout, H, H))
-        tot[up4] += dt
-        row += f"   up4={up4} {dt*1e6:8.1f} us {fl/dt/1e12:6.1f} TF @{c:.0f} MHz"
+        tot[name] += dt
+        row += f"   {name} {dt*1e6:8.1f} us {fl/dt/1e12:6.1f} TF @{c:.0f} MHz"
     print(row, flush=True)
 for (cin, cout, H) in [(128, 256, 256), (256, 512, 128), (512, 512, 64), (512, 512, 32)]:
     hb = H + 1; pitch = (hb + 3) // 4 * 4; ho = (hb - 3) // 2 + 1
@@ -42,10 +43,10 @@ for (cin, cout, H) in [(128, 256, 256), (256, 512, 128), (512, 512, 64), (512, 5
     g = torch.randn(B, cout, ho, ho, device="cuda"); gx = torch.empty(B, cin, hb, pitch, device="cuda")
     fl = 2.0 * B * cin * cout * 9 * ho * ho
     row = f"s2 dgrad {cin}<-{cout} @{H}^2:"
-    for up4 in (0, 1):
-        with _lib.tuning(up4=up4):
+    for name, kn in MODES:
+        with _lib.tuning(**kn):
             dt, c = timeit(lambda: _lib.call("cagc_conv3x3s2_dgrad", _lib.ptr(gx), _lib.ptr(g), _lib.ptr(wp_bwd), B, cin, cout, hb, hb, pitch))
-        tot[up4] += dt
-        row += f"   up4={up4} {dt*1e6:8.1f} us {fl/dt/1e12:6.1f} TF @{c:.0f} MHz"
+        tot[name] += dt
+        row += f"   {name} {dt*1e6:8.1f} us {fl/dt/1e12:6.1f} TF @{c:.0f} MHz"
     print(row, flush=True)
-print(f"sum: up4=0 {tot[0]*1e3:.3f} ms   up4=1 {tot[1]*1e3:.3f} ms   error word {_lib.get_tuning('up4_error')}")
+print("sum: " + "   ".join(f"{m} {v*1e3:.3f} ms" for m, v in tot.items()) + f"   error word {_lib.get_tuning('up4_error')}   up25 launches {_lib.get_tuning('up25_launches')}")

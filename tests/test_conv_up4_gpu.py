@@ -3,7 +3,7 @@
 
 `cagc_modconv_up_fwd` (reference model.py:259-270, the conv_transpose2d before the blur) and `cagc_conv3x3s2_dgrad` (data gradient of
 model.py:693-706) route a launch to the persistent stream-K kernel when it has at least `up4_min_ksteps` (256 positions x 64 channels)
-units; `cagc_set_tuning("up4_min_ksteps", 1)` sends the small test shapes there: everything stream-K (fewer units than workgroups: a
+units; `cagc_set_tuning("up4_min_ksteps", 0)` sends the small test shapes there (`"up4_launches"` proves it): everything stream-K (fewer units than workgroups: a
 unit's K range is spread over many jobs), one whole round + a left-over, ragged last position tile, K not a multiple of 8 channels,
 non-square planes, with and without the input modulation, in both workgroup shapes (`up4_nb` 2 / 4: 32 / 64 positions per wave) and with
 the K rotation of a workgroup's first whole unit (`up4_rotate`).  The stream-K hand-off (slab + agent-scope release / acquire) is exercised
@@ -66,9 +66,11 @@ def test_up_fwd_fused_phase_kernel(shape, modulated, nb):
     outs = {}
     for up4 in (1, 0):
         t = torch.full((B, cout, 4, H + 1, P), float("nan"), device=DEV)
-        with _lib.tuning(up4=up4, up4_min_ksteps=1, up4_lmin=lmin, up4_nb=nb):
+        n0 = _lib.get_tuning("up4_launches")
+        with _lib.tuning(up4=up4, up25=0, up4_min_ksteps=0, up4_lmin=lmin, up4_nb=nb):
             _lib.call("cagc_modconv_up_fwd", _lib.ptr(t), _lib.ptr(xg), _lib.ptr(wp_fwd), _lib.ptr(sg), B, cin, cout, H, W)
         torch.cuda.synchronize()
+        assert _lib.get_tuning("up4_launches") == n0 + up4
         assert rel(t[..., :W + 1], tref[..., :W + 1]) <= TOL, (up4, shape, modulated, rel(t[..., :W + 1], tref[..., :W + 1]))
         outs[up4] = t[..., :W + 1]
     no_spin_timeout()
@@ -96,9 +98,11 @@ def test_stride2_data_gradient_fused_phase_kernel(shape, nb):
     outs = {}
     for up4 in (1, 0):
         gx = torch.full((B, cin, hb, pitch), float("nan"), device=DEV)
-        with _lib.tuning(up4=up4, up4_min_ksteps=1, up4_lmin=lmin, up4_nb=nb):
+        n0 = _lib.get_tuning("up4_launches")
+        with _lib.tuning(up4=up4, up25=0, up4_min_ksteps=0, up4_lmin=lmin, up4_nb=nb):
             _lib.call("cagc_conv3x3s2_dgrad", _lib.ptr(gx), _lib.ptr(gg), _lib.ptr(wp_bwd), B, cin, cout, hb, hb, pitch)
         torch.cuda.synchronize()
+        assert _lib.get_tuning("up4_launches") == n0 + up4
         assert rel(gx[..., :hb], gref) <= TOL, (up4, shape, rel(gx[..., :hb], gref))
         outs[up4] = gx[..., :hb]
     no_spin_timeout()
@@ -116,7 +120,7 @@ def test_fused_phase_kernel_declines_what_it_does_not_take():
     outs = []
     for up4 in (1, 0):
         t = torch.zeros(B, cout, 4, H + 1, P, device=DEV)
-        with _lib.tuning(up4=up4, up4_min_ksteps=1):
+        with _lib.tuning(up4=up4, up25=0, up4_min_ksteps=0):
             _lib.call("cagc_modconv_up_fwd", _lib.ptr(t), _lib.ptr(x), _lib.ptr(wp_fwd), _lib.ptr(s), B, cin, cout, H, H)
         outs.append(t)
     assert torch.equal(outs[0], outs[1])
@@ -136,7 +140,7 @@ def test_stream_k_handoff_is_bit_reproducible_under_uneven_load(nb, rotate):
         x, s = torch.randn(B, cin, H, H, device=DEV), torch.rand(B, cin, device=DEV) + 0.5
         P = _lib.query("cagc_phase_pitch", H)
         first = None
-        with _lib.tuning(up4=1, up4_min_ksteps=1, up4_lmin=2, up4_nb=nb, up4_rotate=rotate):
+        with _lib.tuning(up4=1, up25=0, up4_min_ksteps=0, up4_lmin=2, up4_nb=nb, up4_rotate=rotate):
             for it in range(40):
                 t = torch.full((B, cout, 4, H + 1, P), float("nan"), device=DEV)
                 if it % 2:
