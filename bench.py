@@ -44,14 +44,21 @@ def wino_macs(k_ch, m_ch, B, H, W):
     return 2.25 if wino_f4(k_ch, m_ch, B, H, W) else 4.0
 
 
+def up_macs(k_ch, m_ch, B, H, W):
+    """MACs per input pixel and channel pair that a stride-2 transposed 3x3 conv EXECUTES: 9 on the direct kernels, 9 * 25 / 36 in the
+    Winograd domain of its four output parities (csrc/conv_up25.hip) — the library's own launch decision (cagc_up_plan)."""
+    from cagc import _lib
+    return 9.0 * _lib.query("cagc_up_plan", int(B), int(k_ch), int(m_ch), int(H), int(W)) / 36.0
+
+
 def conv_flops(name, a):
     """Algorithmic FLOPs (2 * MACs, the repo's own MAC convention of Util/Calculators.py) of one MFMA launch."""
     if name == "cagc_modconv_fwd":       # (out,x,wp,s,B,Cin,Cout,H,W,k,...)
         B, cin, cout, H, W, k = a[4:10]
         return 2.0 * B * cin * cout * k * k * H * W
-    if name == "cagc_modconv_up_fwd":    # (t,x,wp,s,B,Cin,Cout,H,W): 9 MACs per input pixel
+    if name == "cagc_modconv_up_fwd":    # (t,x,wp,s,B,Cin,Cout,H,W): 9 MACs per input pixel (6.25 executed in the Winograd domain)
         B, cin, cout, H, W = a[4:9]
-        return 2.0 * B * cin * cout * 9 * H * W
+        return 2.0 * B * cin * cout * up_macs(cin, cout, B, H, W) * H * W
     if name == "cagc_modconv_dgrad":     # (gx,gs,gz,wp,s,x,B,Cin,Cout,H,W,k)
         B, cin, cout, H, W, k = a[6:12]
         return 2.0 * B * cin * cout * k * k * H * W
@@ -70,9 +77,13 @@ def conv_flops(name, a):
     if name == "cagc_wino_conv3x3_act_dgrad":   # (gx,gout,act_out,up,residual,B,Cin,Cout,H,W,...)
         B, cin, cout, H, W = a[5:10]
         return 2.0 * B * cin * cout * wino_macs(cout, cin, B, H, W) * H * W     # data gradient: GEMM K = Cout, M = Cin
-    if name in ("cagc_conv3x3s2_fwd", "cagc_conv3x3s2_dgrad"):   # (out,x,wp,B,Cin,Cout,Hin,Win,pitch)
+    if name == "cagc_conv3x3s2_fwd":     # (out,x,wp,B,Cin,Cout,Hin,Win,pitch)
         B, cin, cout, hin, win = a[3:8]
         return 2.0 * B * cin * cout * 9 * ((hin - 3) // 2 + 1) * ((win - 3) // 2 + 1)
+    if name == "cagc_conv3x3s2_dgrad":   # same arguments; a transposed conv of the (ho x wo) gradient: GEMM K = Cout, M = Cin
+        B, cin, cout, hin, win = a[3:8]
+        ho, wo = (hin - 3) // 2 + 1, (win - 3) // 2 + 1
+        return 2.0 * B * cin * cout * up_macs(cout, cin, B, ho, wo) * ho * wo
     if name == "cagc_conv3x3s2_act_fwd":     # (out,x,wp,bias,B,Cin,Cout,Hin,Win,pitch,...)
         B, cin, cout, hin, win = a[4:9]
         return 2.0 * B * cin * cout * 9 * ((hin - 3) // 2 + 1) * ((win - 3) // 2 + 1)
@@ -110,8 +121,8 @@ KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false, false", "c
              "cagc_wino_conv3x3_act_dgrad[k_wino<4, true, NH2>]": "k_wino<4, true, false, 2>", "cagc_wino_conv3x3_act_dgrad[k_wino<4, true, NH1>]": "k_wino<4, true, false, 1>",
              "cagc_wino_conv3x3[k_wino4<false>]": "k_wino4<false,", "cagc_wino_conv3x3_act_dgrad[k_wino4<true>]": "k_wino4<true,",   # both SCALE variants
              "cagc_modconv_fwd": "k_conv_rd<4, true, true, false>",
-             "cagc_modconv_up_fwd": "k_conv_up4<true, 0",
-             "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_act_fwd": "k_conv_s2v", "cagc_conv3x3s2_dgrad": "k_conv_up4<false, 1",
+             "cagc_modconv_up_fwd": "k_conv_up25<true, 0",
+             "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_act_fwd": "k_conv_s2v", "cagc_conv3x3s2_dgrad": "k_conv_up25<false, 1",
              "cagc_modconv_dgrad": "k_conv_rd<5, true, false, true>",
              "cagc_modconv_up_dgrad": "k_conv_rd<5, true, false, true>", "cagc_modconv_wgrad": "k_wgrad_rd<4, 1, false, 9>",
              "cagc_modconv_wgrad_demod": "k_wgrad_rd<3, 1, false, 9>"}

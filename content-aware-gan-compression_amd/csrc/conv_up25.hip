@@ -58,8 +58,16 @@ constexpr int UP25_WSL = 50 * 1024;      // bytes of one wave's slab slot
 #define UP25_ABL(bit) false
 #endif
 
-#ifndef CAGC_UP25_LSP
-#define CAGC_UP25_LSP 1      // MFMAs between two operand loads of the next K-step (1: all 17 are out by MFMA 19 of 50)
+
+#ifndef CAGC_UP25_XDIST
+#define CAGC_UP25_XDIST 2    // K-steps the input patch is fetched ahead (1 or 2)
+#endif
+#ifndef CAGC_UP25_LPM
+#define CAGC_UP25_LPM 1      // operand loads issued behind each MFMA (from the third MFMA of a K-step on)
+#endif
+#ifndef CAGC_UP25_XL
+#define CAGC_UP25_XL 1       // input patch loads when W is even: 0 nine 4-byte loads; 1 per patch row one 8-byte load (columns n0, n0+1: both valid or both
+                             // beyond W) + one 4-byte load (column n0-1)
 #endif
 
 // weight operand / input operand of product p (0 .. 24)
@@ -71,9 +79,10 @@ __host__ __device__ constexpr int up25_v(int p) {
   return p == 21 ? 4 : (p == 22 ? 10 : (p == 23 ? 13 : 15));
 }
 
-template <bool SCALE>
+template <bool SCALE, int XL>
 __device__ __forceinline__ void up25_kloop(const Up25Args& A, f32x4 (&acc)[25][2], const unsigned (&voff)[9], const unsigned sbase,
                                            const int b0, const int mtile, const int lane, const int kq_lo, const int kq_hi) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int cs = A.H * A.Wpitch;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.up), 0, (int)A.up_bytes, 0x00020000);
   const unsigned a_lane = (unsigned)lane * 16u;
@@ -85,32 +94,50 @@ __device__ __forceinline__ void up25_kloop(const Up25Args& A, f32x4 (&acc)[25][2
   int ao = (kq_lo * A.mt + mtile) * 1024;
   float4 uv[2][8];
   float xr[2][9], sv[2];
-  if (UP25_ABL(2)) { for (int n = 0; n < 9; ++n) xr[0][n] = xr[1][n] = (float)(lane + n); }
+  f32x2 xp[2][3];       // XL 1: columns n0, n0+1 of patch row i
+  if (UP25_ABL(2)) {
+    for (int n = 0; n < 9; ++n) xr[0][n] = xr[1][n] = (float)(lane + n);
+    for (int i = 0; i < 3; ++i) { xp[0][i] = xp[1][i] = (f32x2){(float)lane, (float)i}; }
+  }
   if (UP25_ABL(4)) { for (int t = 0; t < 8; ++t) uv[0][t] = uv[1][t] = make_float4((float)lane, 1.f, 2.f, 3.f); }
   __amdgpu_buffer_rsrc_t ri, rs;
   auto set_rsrc = [&]() __attribute__((always_inline)) {
     ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_ptr), 0, in_left > 0x7fffffff ? 0x7fffffff : (in_left > 0 ? (int)in_left : 0), 0x00020000);
     if constexpr (SCALE) rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc_ptr), 0, sc_left > 0 ? sc_left : 0, 0x00020000);
   };
-  auto advance = [&](const bool fwd) __attribute__((always_inline)) {
-    if (fwd) { in_ptr += 4 * (int64_t)cs; in_left -= step_bytes; ao += A.mt * 1024; if constexpr (SCALE) { sc_ptr += 4; sc_left -= 16; } }
+  auto advance_x = [&](const bool fwd) __attribute__((always_inline)) {
+    if (fwd) { in_ptr += 4 * (int64_t)cs; in_left -= step_bytes; if constexpr (SCALE) { sc_ptr += 4; sc_left -= 16; } }
   };
-  constexpr int NL = 9 + (SCALE ? 1 : 0) + 8;
-  auto load_one = [&](const int slot, const int n) __attribute__((always_inline)) {
-    if (n < 9) {
-      if (!UP25_ABL(2)) xr[slot][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, voff[n], 0, 0));
-    } else if (SCALE && n == 9) {
-      sv[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, sbase, 0, 0));
-    } else {
-      const int t = n - (SCALE ? 10 : 9);
-      if (!UP25_ABL(4)) uv[slot][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, a_lane, ao + t * A.u8_bytes, 0));
+  auto advance_u = [&](const bool fwd) __attribute__((always_inline)) { if (fwd) ao += A.mt * 1024; };
+  constexpr int NX = (XL == 0 ? 9 : 6) + (SCALE ? 1 : 0);     // loads of one K-step's input patch (+ its modulation factor)
+  constexpr int NL = NX + 8;
+  auto load_x = [&](const int slot, const int n) __attribute__((always_inline)) {
+    if (SCALE && n == NX - 1) { sv[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, sbase, 0, 0)); return; }
+    if (UP25_ABL(2)) return;
+    if constexpr (XL == 0) xr[slot][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, voff[n], 0, 0));
+    else {
+      if (n & 1) xr[slot][3 * (n >> 1)] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, voff[3 * (n >> 1)], 0, 0));
+      else xp[slot][n >> 1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ri, voff[3 * (n >> 1) + 1], 0, 0));
     }
   };
+  auto load_u = [&](const int slot, const int t) __attribute__((always_inline)) {
+    if (!UP25_ABL(4)) uv[slot][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, a_lane, ao + t * A.u8_bytes, 0));
+  };
+  // Prefetch distances: the weights of K-step k+1 go into the other register slot during K-step k (L2 hits: every workgroup of a channel
+  // tile streams the same operands); the INPUT PATCH of K-step k+2 goes into THIS K-step's slot — its registers are free once the
+  // transform at the head of the stage has read them — because a patch row that misses the L2 comes from HBM, and a 50-MFMA K-step
+  // (1600 cycles, 0.7 us) does not cover that latency for the only wave of a SIMD.  The weight loads are issued FIRST: vmcnt counts in
+  // issue order, so the next stage's wait for its weights does not cover the younger patch loads.
   // MFMAs as asm with "a" accumulators (conv_up4.hip explains why); loads and descriptor SALU spread over the MFMA stream
-  auto stage = [&](const int slot, const bool first, const bool fwd) __attribute__((always_inline)) {
+  auto stage = [&](const int slot, const bool first, const bool fwd_u, const bool fwd_x) __attribute__((always_inline)) {
     float d[9], V[16];
 #pragma unroll
-    for (int n = 0; n < 9; ++n) d[n] = SCALE ? xr[slot][n] * sv[slot] : xr[slot][n];
+    for (int n = 0; n < 9; ++n) {
+      float x;
+      if constexpr (XL == 0) x = xr[slot][n];
+      else x = (n % 3 == 0) ? xr[slot][n] : xp[slot][n / 3][n % 3 - 1];
+      d[n] = SCALE ? x * sv[slot] : x;
+    }
     if (UP25_ABL(8)) {
 #pragma unroll
       for (int n = 0; n < 16; ++n) V[n] = d[n % 9];
@@ -135,27 +162,45 @@ __device__ __forceinline__ void up25_kloop(const Up25Args& A, f32x4 (&acc)[25][2
         if (first) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[p][blk]) : "v"(V[vi]), "v"(uu));
         else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[p][blk]) : "v"(V[vi]), "v"(uu));
         const int n = p * 2 + blk;
-        if (n == 1) { advance(fwd); set_rsrc(); __builtin_amdgcn_sched_barrier(0); }
-        if (n >= 2 && (n - 2) % CAGC_UP25_LSP == 0 && (n - 2) / CAGC_UP25_LSP < NL) { load_one(slot ^ 1, (n - 2) / CAGC_UP25_LSP); __builtin_amdgcn_sched_barrier(0); }
+        if (n == 1) { advance_u(fwd_u); advance_x(fwd_x); set_rsrc(); __builtin_amdgcn_sched_barrier(0); }
+        if (n >= 2) {      // CAGC_UP25_LPM loads behind each MFMA from the third on: the 8 weight loads first, then the patch
+#pragma unroll
+          for (int e = 0; e < CAGC_UP25_LPM; ++e) {
+            const int l = (n - 2) * CAGC_UP25_LPM + e;
+            if (l < 8) load_u(slot ^ 1, l);
+            else if (l < NL) load_x(CAGC_UP25_XDIST == 2 ? slot : slot ^ 1, l - 8);
+          }
+          if ((n - 2) * CAGC_UP25_LPM < NL) __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
   set_rsrc();
 #pragma unroll
-  for (int n = 0; n < NL; ++n) load_one(0, n);
+  for (int t = 0; t < 8; ++t) load_u(0, t);
+#pragma unroll
+  for (int n = 0; n < NX; ++n) load_x(0, n);
+  if constexpr (CAGC_UP25_XDIST == 2) {      // the patch of the second K-step (a segment has at least two)
+    advance_x(true);
+    set_rsrc();
+#pragma unroll
+    for (int n = 0; n < NX; ++n) load_x(1, n);
+  }
   __builtin_amdgcn_sched_barrier(0);
-  stage(0, true, true);
-  stage(1, false, kq_lo + 2 < kq_hi);
+  // stage(slot, first, weights move on, patch moves on): the last K-steps re-read valid operands instead of branching (never used)
+  constexpr int XD = CAGC_UP25_XDIST;
+  stage(0, true, true, kq_lo + XD < kq_hi);
+  stage(1, false, kq_lo + 2 < kq_hi, kq_lo + 1 + XD < kq_hi);
   for (int kq = kq_lo + 2; kq < kq_hi; kq += 2) {
-    stage(0, false, true);
-    stage(1, false, kq + 2 < kq_hi);
+    stage(0, false, true, kq + XD < kq_hi);
+    stage(1, false, kq + 2 < kq_hi, kq + 1 + XD < kq_hi);
   }
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool SCALE, int MODE>
+template <bool SCALE, int MODE, int XL>
 __global__ __launch_bounds__(256, 1) void k_conv_up25(const Up25Args A) {
   long long c0 = 0, w0 = 0;
   clock_probe_begin(A.clk, c0, w0);
@@ -190,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_up25(const Up25Args A) {
         }
       sbase = ok ? 4u * (unsigned)((b - b0) * A.K + g) : UP25_OOR;
     }
-    up25_kloop<SCALE>(A, acc, voff, sbase, b0, mtile, lane, k_lo, k_hi);
+    up25_kloop<SCALE, XL>(A, acc, voff, sbase, b0, mtile, lane, k_lo, k_hi);
 
     if (k_lo > 0) {   // not the owner: publish the partial sums (transformed domain: the transforms are linear)
       const int sb = (pub_slot * 4 + wave) * UP25_WSL;
@@ -382,7 +427,7 @@ __global__ __launch_bounds__(256) void k_up25_pack(float* __restrict__ up, const
 
 struct Up25Tuning { int on, min_ksteps, lmin; };
 static Up25Tuning& up25_tuning() {
-  static Up25Tuning t = {getenv("CAGC_UP25") ? atoi(getenv("CAGC_UP25")) : 0, getenv("CAGC_UP25_MIN_KSTEPS") ? atoi(getenv("CAGC_UP25_MIN_KSTEPS")) : 288,
+  static Up25Tuning t = {getenv("CAGC_UP25") ? atoi(getenv("CAGC_UP25")) : 1, getenv("CAGC_UP25_MIN_KSTEPS") ? atoi(getenv("CAGC_UP25_MIN_KSTEPS")) : 110,
                          getenv("CAGC_UP25_LMIN") ? atoi(getenv("CAGC_UP25_LMIN")) : 8};
   return t;
 }
@@ -392,14 +437,40 @@ int& up25_tuning_lmin() { return up25_tuning().lmin; }
 static int g_up25_launches = 0;
 int up25_launch_count() { return g_up25_launches; }
 
+static int up25_grid() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  return (n_cu / 8) * 8;
+}
+
+// The shape part of the launch decision (cagc_up_plan reports it to benchmarks): M = produced channels in whole 32-channel tiles that
+// divide the grid's workgroups per XCD, and at least `up25_min_ksteps` K-steps (of 256 positions x 64 channels: conv_up4.hip's unit) per
+// workgroup — below that the stream-K part is most of the launch and conv_rd.hip's finer units win (measured per layer at batch 2 .. 16,
+// profiles/r05_time_up25_bs.log: wins from ~134 up, loses from ~92 down)
+bool up25_for_launch(int B, int K, int M, int H, int W) {
+  const Up25Tuning& tune = up25_tuning();
+  if (!tune.on || M % 32 != 0 || K < 1 || H < 1 || W < 1) return false;
+  const int G = up25_grid(), mt = M / 32;
+  if (G < 8 || G > 512 || (G / 8) % mt != 0) return false;
+  const int KQ = igemm_kp(K) / 4;
+  const int region = ((H + 2) / 2) * round_up((W + 2) / 2, 2);
+  const int64_t units = (int64_t)cdiv((int64_t)B * region, 64) * mt;
+  return units * KQ / 2 >= (int64_t)tune.min_ksteps * G;
+}
+
 int run_conv_up25(const ConvArgs& a, int mode, hipStream_t st, const char* what) {
   const Up25Tuning& tune = up25_tuning();
   if (!tune.on) return CAGC_RD_DECLINED;
   if (a.kk != 9 || a.Kp % 8 != 0 || a.gs || a.out_scale || a.noise || a.epi != CAGC_EPI_LINEAR) return CAGC_RD_DECLINED;
   const int nblk = a.Mp / 16;
-  if (nblk % 2 != 0 || a.Cout != a.Mp) return CAGC_RD_DECLINED;
+  if (nblk % 2 != 0 || a.Cout != a.Mp || a.Kp != igemm_kp(a.Cin)) return CAGC_RD_DECLINED;
   const int H = a.Hin, W = a.Win;
   if (a.NPin != 1 || a.isy != 1 || a.isx != 1) return CAGC_RD_DECLINED;
+  if (!up25_for_launch(a.B, a.Cin, a.Cout, H, W)) return CAGC_RD_DECLINED;
   const int KQ = a.Kp / 4, mt = nblk / 2;
   const int64_t up_elems = (int64_t)8 * KQ * mt * 256;
   if (up_elems * 4 > 0x7fffffff) return CAGC_RD_DECLINED;
@@ -420,19 +491,8 @@ int run_conv_up25(const ConvArgs& a, int mode, hipStream_t st, const char* what)
     out_bytes = (int64_t)a.B * a.Cout * a.Hout * a.Wopitch * 4;
   }
   if (out_bytes > 0x7fffffff) return CAGC_RD_DECLINED;
-
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-  }
-  const int G = (n_cu / 8) * 8;
-  if (G < 8 || G > 512 || (G / 8) % mt != 0) return CAGC_RD_DECLINED;
+  const int G = up25_grid();
   const int ttiles = cdiv((int64_t)a.B * region, 64);
-  const int64_t units = (int64_t)ttiles * mt;
-  // threshold in conv_up4.hip's unit (a K-step of 64 positions x 64 channels): a unit here is 64 tiles = 256 positions x 32 channels
-  if (units * KQ / 2 < (int64_t)tune.min_ksteps * G) return CAGC_RD_DECLINED;
 
   Up25Args r;
   memset(&r, 0, sizeof(r));
@@ -479,14 +539,22 @@ int run_conv_up25(const ConvArgs& a, int mode, hipStream_t st, const char* what)
   }
   ++g_up25_launches;
   const dim3 grid((unsigned)G), block(256);
-  const int variant = (a.in_scale ? 1 : 0) + 2 * mode;
+  // wide patch loads need W even (columns n0, n0+1 are then both inside or both outside) and 8-byte aligned rows
+  const bool wide = CAGC_UP25_XL != 0 && W % 2 == 0 && a.Wpitch % 2 == 0 && ((uintptr_t)a.in % 8) == 0;
+  const int variant = (a.in_scale ? 1 : 0) + 2 * mode + (wide ? 4 : 0);
   switch (variant) {
-    case 0: hipLaunchKernelGGL((k_conv_up25<false, 0>), grid, block, 0, st, r); break;
-    case 1: hipLaunchKernelGGL((k_conv_up25<true, 0>), grid, block, 0, st, r); break;
-    case 2: hipLaunchKernelGGL((k_conv_up25<false, 1>), grid, block, 0, st, r); break;
-    default: hipLaunchKernelGGL((k_conv_up25<true, 1>), grid, block, 0, st, r); break;
+    case 0: hipLaunchKernelGGL((k_conv_up25<false, 0, 0>), grid, block, 0, st, r); break;
+    case 1: hipLaunchKernelGGL((k_conv_up25<true, 0, 0>), grid, block, 0, st, r); break;
+    case 2: hipLaunchKernelGGL((k_conv_up25<false, 1, 0>), grid, block, 0, st, r); break;
+    case 3: hipLaunchKernelGGL((k_conv_up25<true, 1, 0>), grid, block, 0, st, r); break;
+    case 4: hipLaunchKernelGGL((k_conv_up25<false, 0, CAGC_UP25_XL>), grid, block, 0, st, r); break;
+    case 5: hipLaunchKernelGGL((k_conv_up25<true, 0, CAGC_UP25_XL>), grid, block, 0, st, r); break;
+    case 6: hipLaunchKernelGGL((k_conv_up25<false, 1, CAGC_UP25_XL>), grid, block, 0, st, r); break;
+    default: hipLaunchKernelGGL((k_conv_up25<true, 1, CAGC_UP25_XL>), grid, block, 0, st, r); break;
   }
   return check_launch(what);
 }
 
 }  // namespace cagc
+
+extern "C" int cagc_up_plan(int B, int K, int M, int H, int W) { return cagc::up25_for_launch(B, K, M, H, W) ? 25 : 36; }

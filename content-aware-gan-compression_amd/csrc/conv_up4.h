@@ -16,6 +16,7 @@ int up4_launch_count();        // cagc_get_tuning("up4_launches"): launches this
 int* up4_err_word_ptr();       // the library's device error word (shared with conv_up25.hip)
 // Winograd-domain variant (conv_up25.hip): 25 instead of 36 position-GEMMs per 2x2 tile of positions; same contract as run_conv_up4
 int run_conv_up25(const ConvArgs& a, int mode, hipStream_t st, const char* what);
+bool up25_for_launch(int B, int K, int M, int H, int W);      // the shape part of its launch decision (include/cagc.h cagc_up_plan)
 int& up25_tuning_on();         // cagc_set_tuning("up25"), CAGC_UP25
 int& up25_tuning_min_ksteps(); // cagc_set_tuning("up25_min_ksteps"), CAGC_UP25_MIN_KSTEPS
 int up25_launch_count();      // cagc_get_tuning("up25_launches"): launches this process sent to the kernel (tests)

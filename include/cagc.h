@@ -363,6 +363,10 @@ int cagc_wino_eligible(int H, int W);
  * swaps the layer's Cin / Cout) takes under the current tuning: 0 = not eligible, 2 = F(2x2,3x3), 4 = F(4x4,3x3).  Benchmarks
  * use it to attribute executed FLOPs to the kernel that really ran. */
 int cagc_wino_plan(int B, int K, int M, int H, int W);
+/* Position-GEMMs per 2x2 tile of positions that a launch of cagc_modconv_up_fwd / cagc_conv3x3s2_dgrad (GEMM K = reduction channels, M =
+ * produced channels, H x W = the INPUT plane of the transposed convolution) executes under the current tuning: 25 = the Winograd-domain
+ * fused-phase kernel (csrc/conv_up25.hip), 36 = the direct kernels (conv_up4.hip / conv_rd.hip).  Benchmarks attribute executed FLOPs with it. */
+int cagc_up_plan(int B, int K, int M, int H, int W);
 /* Diagnostic (benchmarks): while `acc` is non-null, every 64th workgroup of every F(4x4) Winograd and register-direct
  * convolution launch adds the shader clock it measured over its own lifetime (MHz: s_memtime ticks per 100 MHz s_memrealtime
  * tick) to acc[0] and 1 to acc[1] — two device floats the caller owns and zeroes; acc[0] / acc[1] is the clock averaged over

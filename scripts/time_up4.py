@@ -21,6 +21,10 @@ def timeit(f):
     torch.cuda.synchronize(); _lib.load().cagc_set_clock_probe(None)
     return dt, float(clk[0] / clk[1].clamp(min=1))
 MODES = [("rd", dict(up4=0, up25=0)), ("up4", dict(up4=1, up25=0)), ("up25", dict(up4=1, up25=1))]
+if os.environ.get("FORCE"):      # no launch threshold: every layer goes to the named kernel
+    MODES = [(m, dict(kn, up4_min_ksteps=0, up25_min_ksteps=0)) for m, kn in MODES]
+if os.environ.get("ONLY"):
+    MODES = [m for m in MODES if m[0] in os.environ["ONLY"].split(",")]
 tot = {m: 0.0 for m, _ in MODES}
 for (cin, cout, H) in [(512, 512, 16), (512, 512, 32), (512, 256, 64), (256, 128, 128)]:
     wt = torch.randn(1, cout, cin, 3, 3, device="cuda")

@@ -137,7 +137,8 @@ def test_tuning_getters_and_wino_plan_are_host_side():
     from cagc import _lib
     lib = _lib.load()
     for key in ("rd", "rd_min_wgs", "rd_min_wgs_long", "rd_mb", "rd_kw", "rd_split", "rd_atomic_below", "rd_split_wgs", "rd_s2v", "deterministic", "wgrad_rd",
-                "wgrad_rd_wgs", "wino4_hv", "wino4_min_wgs", "up4", "up4_min_ksteps", "up4_nb", "up4_lmin", "up4_rotate"):
+                "wgrad_rd_wgs", "wino4_hv", "wino4_min_wgs", "up4", "up4_min_ksteps", "up4_nb", "up4_lmin", "up4_rotate",
+                "up25", "up25_min_ksteps", "up25_lmin"):
         v = _lib.get_tuning(key)
         assert _lib.set_tuning(key, v) == v and _lib.get_tuning(key) == v
     # setting one knob never rewrites another (advisor r4: "rd_min_wgs" used to overwrite "rd_min_wgs_long")
@@ -158,6 +159,12 @@ def test_tuning_getters_and_wino_plan_are_host_side():
             assert _lib.query("cagc_wino_plan", 2, 512, 512, 32, 32) == 2         # 2 * 4 * 1 * 8 = 64 workgroups < 256: the layer's F(2x2) packing
             with _lib.tuning(wino4_min_wgs=0):
                 assert _lib.query("cagc_wino_plan", 2, 512, 512, 32, 32) == 4
+    # the transposed conv's kernel choice (cagc_up_plan): 25 position-GEMMs per 2x2 tile on the Winograd-domain kernel, 36 on the direct ones
+    assert _lib.query("cagc_up_plan", 16, 256, 128, 128, 128) == 25
+    assert _lib.query("cagc_up_plan", 16, 154, 77, 64, 64) == 36          # ragged channel tiles
+    assert _lib.query("cagc_up_plan", 2, 512, 512, 16, 16) == 36          # too few K-steps per workgroup
+    with _lib.tuning(up25=0):
+        assert _lib.query("cagc_up_plan", 16, 256, 128, 128, 128) == 36
     assert _lib.get_tuning("wino4_min_wgs") in (256, int(__import__("os").environ.get("CAGC_WINO4_MIN_WGS", "256")))
 
 
@@ -215,5 +222,20 @@ def test_fused_phase_kernel_keeps_its_accumulators_in_the_accumulator_file():
         body = blk.split("s_endpgm")[0]
         name = "k_conv_up4" + body.split(":")[0]
         assert body.count("v_mfma_f32_16x16x4_f32") >= 288, name
+        for bad in ("v_accvgpr_write", "v_accvgpr_mov", "scratch_"):
+            assert bad not in body, (name, bad)
+    # the Winograd-domain variant (csrc/conv_up25.hip): 200 accumulators, same rule
+    src = os.path.join(ROOT, "content-aware-gan-compression_amd", "csrc", "conv_up25.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "up25.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-S", "--cuda-device-only", src, "-o", out],
+                       check=True, capture_output=True, timeout=600)
+        text = open(out).read()
+    kernels = [blk for blk in text.split("\n_ZN4cagc11k_conv_up25")[1:]]
+    assert len(kernels) >= 8, "eight variants: SCALE x MODE x patch-load width"
+    for blk in kernels:
+        body = blk.split("s_endpgm")[0]
+        name = "k_conv_up25" + body.split(":")[0]
+        assert body.count("v_mfma_f32_16x16x4_f32") >= 200, name
         for bad in ("v_accvgpr_write", "v_accvgpr_mov", "scratch_"):
             assert bad not in body, (name, bad)
