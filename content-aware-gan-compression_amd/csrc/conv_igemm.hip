@@ -926,6 +926,10 @@ static int conv3x3s2_fwd_impl(float* out, const float* x, const float* wp, const
     for (int kx = 0; kx < 3; ++kx) taps[n++] = RawTap{0, ky, kx, ky * 3 + kx};
   RawItem it{n, taps, 0, 0, 0, Ho, Wo};
   if (bias) { a.epi = CAGC_EPI_STYLED; a.bias = bias; a.alpha = alpha; a.act_scale = act_scale; }   // + bias, LeakyReLU in the MFMA epilogue
+  {   // large launches: the Winograd-domain persistent kernel (conv_s2w.hip)
+    const int sw = run_conv_s2w(a, as_stream(stream), what);
+    if (sw != CAGC_RD_DECLINED) return sw;
+  }
   return run_conv(a, &it, 1, as_stream(stream), what);
 }
 extern "C" int cagc_conv3x3s2_fwd(float* out, const float* x, const float* wp, int B, int Cin, int Cout, int Hin, int Win,

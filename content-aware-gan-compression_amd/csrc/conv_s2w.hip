@@ -1,0 +1,448 @@
+// 3x3 stride-2 convolution (no padding) in the WINOGRAD DOMAIN OF ITS FOUR INPUT PARITIES — the adjoint of conv_up25.hip.
+//
+// Serves the discriminator's down-sampling conv (reference model.py:683-706: Blur(pad=(2,2)) -> EqualConv2d(stride=2, padding=0)) behind
+// cagc_conv3x3s2_fwd / cagc_conv3x3s2_act_fwd on its large launches.
+//
+//     out[o, m, n] = sum_c sum_{ky, kx} W[o, c, ky, kx] * x[c, 2m + ky, 2n + kx]
+//
+// Split x into its parities x_pq[c, m, n] = x[c, 2m + p, 2n + q]: the sum is four stride-1 correlations with a 2x2 (p = q = 0: taps ky, kx in
+// {0, 2}), 2x1, 1x2 and 1x1 kernel that all land on the SAME output.  On a tile of 2 x 2 outputs the two-tap rule
+//     F(2, 2):   y0 = d0 g0 + d1 g1,  y1 = d1 g0 + d2 g1   =   (M0 + M1, M1 + M2),   M = (d0 - d1, d1, d2 - d1) (.) (g0, g0 + g1, g1)
+// turns them into 9 + 6 + 6 + 4 = 25 products (36 direct), and because the output transform is linear and the one-axis / plain products
+// are the two-axis transform's edge / corner terms (Y = A^T M A with A^T = (1 1 0; 0 1 1): a product that belongs to output column v
+// alone enters M[.][2v], one that belongs to output (u, v) alone enters M[2u][2v]), all 25 accumulate into NINE sums per tile and channel:
+//     M[i][j] += U00[i][j] V00[i][j];   M[i][2v] += U01[i] V01[i][v];   M[2u][j] += U10[j] V10[u][j];   M[2u][2v] += U11 x11[u][v]
+// A wave owns 16 tiles (64 outputs) x 64 output channels: 36 accumulator blocks (144 registers), one wave per SIMD.  Per K-step
+// (4 input channels): the 5 x 5 input patch as 5 x (16-byte + 4-byte) loads, 16 sixteen-byte weight loads (one per distinct transformed
+// weight, 4 channel blocks each), 20 subtractions, 100 MFMAs — 0.26 loads per MFMA.  The product is transposed (tiles are the MFMA's M
+// dimension): a lane's accumulator quad is 4 consecutive tiles of one channel = 8 consecutive outputs of a row, two 16-byte stores.
+// Scheduling is conv_up4.hip's: persistent workgroups, whole rounds + a stream-K split of the left-over units, slabs + flags.
+#include "common.h"
+#include "prep_device.h"
+#include "conv_plan.h"
+#include "conv_up4.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace cagc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct S2wArgs {
+  const float* in;        // x [B, K, Hin, Wpitch]
+  float* out;             // [B, Cout, Hout, Wout]
+  const float* up;        // transformed weights [16 operands][KQ][mt][lane][4 channel blocks]
+  const float* bias;      // styled epilogue: + bias, LeakyReLU * act_scale
+  float* slab;            // [G][4 waves][36][64 lanes] float4
+  int* flags;
+  int* err;
+  float* clk;
+  int B, K, KQ, Cout;
+  int Hin, Win, Wpitch, Hout, Wout;
+  int TR, Tq;             // tile grid: ceil(Hout/2) rows of Tq = round_up(ceil(Wout/2), 2) tiles
+  int u_bytes;            // stride between operands in `up`
+  unsigned up_bytes, out_bytes;
+  int mt;                 // channel tiles of 64
+  int q, r, skL, skJ;
+  float alpha, act_scale;
+};
+
+constexpr unsigned S2W_OOR = 0x80000000u;
+constexpr int S2W_SPIN_MAX = 1 << 22;
+constexpr int S2W_WSL = 36 * 1024;       // bytes of one wave's slab slot
+
+#ifdef CAGC_S2W_ABL       // debug builds only (wrong results, timing only): 1 no stores, 2 no x loads, 4 no weight loads
+#define S2W_ABL(bit) ((CAGC_S2W_ABL & (bit)) != 0)
+#else
+#define S2W_ABL(bit) false
+#endif
+
+// product p (0 .. 24): accumulator, weight operand, input operand (V index: 0-8 V00, 9-14 V01[i][v], 15-20 V10[u][j], 21-24 x11[u][v])
+__host__ __device__ constexpr int s2w_acc(int p) {
+  if (p < 9) return p;
+  if (p < 15) return 3 * ((p - 9) / 2) + 2 * ((p - 9) % 2);
+  if (p < 21) return 6 * ((p - 15) / 3) + (p - 15) % 3;
+  return 6 * ((p - 21) / 2) + 2 * ((p - 21) % 2);
+}
+__host__ __device__ constexpr int s2w_u(int p) { return p < 9 ? p : (p < 15 ? 9 + (p - 9) / 2 : (p < 21 ? 12 + (p - 15) % 3 : 15)); }
+
+__device__ __forceinline__ void s2w_kloop(const S2wArgs& A, f32x4 (&acc)[9][4], const unsigned (&voff)[5], const int b0, const int mtile,
+                                          const int lane, const int kq_lo, const int kq_hi) {
+  const int cs = A.Hin * A.Wpitch;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.up), 0, (int)A.up_bytes, 0x00020000);
+  const unsigned a_lane = (unsigned)lane * 16u;
+  const int64_t step_bytes = (int64_t)16 * cs;
+  const float* in_ptr = A.in + ((int64_t)b0 * A.K + (int64_t)4 * kq_lo) * cs;
+  int64_t in_left = (((int64_t)(A.B - b0) * A.K - 4 * kq_lo) * cs) * 4;
+  int ao = (kq_lo * A.mt + mtile) * 1024;
+  float4 uv[2][16];
+  float4 xq[2][5];      // patch row r: columns 0 .. 3
+  float xe[2][5];       //              column 4
+  if (S2W_ABL(2)) { for (int r = 0; r < 5; ++r) { xq[0][r] = xq[1][r] = make_float4((float)lane, 1.f, (float)r, 3.f); xe[0][r] = xe[1][r] = (float)lane; } }
+  if (S2W_ABL(4)) { for (int t = 0; t < 16; ++t) uv[0][t] = uv[1][t] = make_float4((float)lane, 1.f, 2.f, 3.f); }
+  __amdgpu_buffer_rsrc_t ri;
+  auto set_rsrc = [&]() __attribute__((always_inline)) {
+    ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_ptr), 0, in_left > 0x7fffffff ? 0x7fffffff : (in_left > 0 ? (int)in_left : 0), 0x00020000);
+  };
+  auto advance_x = [&](const bool fwd) __attribute__((always_inline)) { if (fwd) { in_ptr += 4 * (int64_t)cs; in_left -= step_bytes; } };
+  auto advance_u = [&](const bool fwd) __attribute__((always_inline)) { if (fwd) ao += A.mt * 1024; };
+  auto load_x = [&](const int slot, const int n) __attribute__((always_inline)) {
+    if (S2W_ABL(2)) return;
+    if (n & 1) xe[slot][n >> 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, voff[n >> 1] + 16u, 0, 0));
+    else xq[slot][n >> 1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ri, voff[n >> 1], 0, 0));
+  };
+  auto load_u = [&](const int slot, const int t) __attribute__((always_inline)) {
+    if (!S2W_ABL(4)) uv[slot][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rw, a_lane, ao + t * A.u_bytes, 0));
+  };
+  // Prefetch as in conv_up25.hip: weights of K-step k+1 into the other slot (issued first: vmcnt counts in issue order), the input patch of
+  // K-step k+2 into this K-step's slot once the transform at the head of the stage has read it.  MFMAs are asm with "a" accumulators.
+  auto stage = [&](const int slot, const bool first, const bool fwd_u, const bool fwd_x) __attribute__((always_inline)) {
+    float X[5][5], V[25];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) { X[r][0] = xq[slot][r].x; X[r][1] = xq[slot][r].y; X[r][2] = xq[slot][r].z; X[r][3] = xq[slot][r].w; X[r][4] = xe[slot][r]; }
+    {
+      float t[3][3];       // row stage of the two-axis transform on the even-even parity x00[i][j] = X[2i][2j]
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { t[i][0] = X[2 * i][0] - X[2 * i][2]; t[i][1] = X[2 * i][2]; t[i][2] = X[2 * i][4] - X[2 * i][2]; }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { V[j] = t[0][j] - t[1][j]; V[3 + j] = t[1][j]; V[6 + j] = t[2][j] - t[1][j]; }
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {      // x01[i][v] = X[2i][2v+1]: the rule along the rows
+        V[9 + v] = X[0][2 * v + 1] - X[2][2 * v + 1]; V[11 + v] = X[2][2 * v + 1]; V[13 + v] = X[4][2 * v + 1] - X[2][2 * v + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {      // x10[u][j] = X[2u+1][2j]: the rule along the columns
+        V[15 + 3 * u] = X[2 * u + 1][0] - X[2 * u + 1][2]; V[16 + 3 * u] = X[2 * u + 1][2]; V[17 + 3 * u] = X[2 * u + 1][4] - X[2 * u + 1][2];
+      }
+      V[21] = X[1][1]; V[22] = X[1][3]; V[23] = X[3][1]; V[24] = X[3][3];
+    }
+    asm volatile("s_nop 1" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(V[4]), "+v"(V[5]), "+v"(V[6]), "+v"(V[7]), "+v"(V[8]),
+                 "+v"(V[9]), "+v"(V[10]), "+v"(V[11]), "+v"(V[12]), "+v"(V[13]), "+v"(V[14]), "+v"(V[15]), "+v"(V[16]), "+v"(V[17]),
+                 "+v"(V[18]), "+v"(V[19]), "+v"(V[20]), "+v"(V[21]), "+v"(V[22]), "+v"(V[23]), "+v"(V[24]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 25; ++p) {
+      const int ai = s2w_acc(p), ui = s2w_u(p);
+      const float4 u4 = uv[slot][ui];
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        const float uu = blk == 0 ? u4.x : (blk == 1 ? u4.y : (blk == 2 ? u4.z : u4.w));
+        // the nine two-axis products come first and touch every accumulator once: in a unit's first K-step they WRITE (C = 0)
+        if (first && p < 9) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc[ai][blk]) : "v"(V[p]), "v"(uu));
+        else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[ai][blk]) : "v"(V[p]), "v"(uu));
+        const int n = p * 4 + blk;
+        if (n == 1) { advance_u(fwd_u); advance_x(fwd_x); set_rsrc(); __builtin_amdgcn_sched_barrier(0); }
+        if (n >= 2 && n - 2 < 26) {
+          const int l = n - 2;
+          if (l < 16) load_u(slot ^ 1, l); else load_x(slot, l - 16);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  set_rsrc();
+#pragma unroll
+  for (int t = 0; t < 16; ++t) load_u(0, t);
+#pragma unroll
+  for (int n = 0; n < 10; ++n) load_x(0, n);
+  advance_x(true);      // a segment has at least two K-steps
+  set_rsrc();
+#pragma unroll
+  for (int n = 0; n < 10; ++n) load_x(1, n);
+  __builtin_amdgcn_sched_barrier(0);
+  stage(0, true, true, kq_lo + 2 < kq_hi);
+  stage(1, false, kq_lo + 2 < kq_hi, kq_lo + 3 < kq_hi);
+  for (int kq = kq_lo + 2; kq < kq_hi; kq += 2) {
+    stage(0, false, true, kq + 2 < kq_hi);
+    stage(1, false, kq + 2 < kq_hi, kq + 3 < kq_hi);
+  }
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool STYLED>
+__global__ __launch_bounds__(256, 1) void k_conv_s2w(const S2wArgs A) {
+  long long c0 = 0, w0 = 0;
+  clock_probe_begin(A.clk, c0, w0);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lm = lane & 15, g = lane >> 4;
+  const int G = gridDim.x, w = blockIdx.x;
+  const int region = A.TR * A.Tq;
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)A.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(A.slab, 0, G * 4 * S2W_WSL, 0x00020000);
+
+  f32x4 acc[9][4];
+  auto run = [&](const int ttile, const int mtile, const int k_lo, const int k_hi, const int pub_slot, const int first_slot, const int nc) __attribute__((always_inline)) {
+    const int t0 = ttile * 64 + wave * 16;
+    const int b0 = __builtin_amdgcn_readfirstlane((ttile * 64) / region);
+    unsigned voff[5];
+    {   // operand loads: this lane feeds tile t0 + lm (outputs 2tr .. 2tr+1 x 2tc .. 2tc+1), input channel g of the K-step:
+        // input rows 4tr .. 4tr+4, columns 4tc .. 4tc+4 (16-byte aligned: the row pitch is a multiple of 4 floats)
+      const int T = t0 + lm;
+      const int b = T / region;
+      const int rem = T - b * region;
+      const int tr = rem / A.Tq, tc = rem - tr * A.Tq;
+      const bool ok = b < A.B && 4 * tc + 4 <= A.Wpitch;
+      const int base = (((b - b0) * A.K + g) * A.Hin + 4 * tr) * A.Wpitch + 4 * tc;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) voff[r] = (ok && 4 * tr + r < A.Hin) ? 4u * (unsigned)(base + r * A.Wpitch) : S2W_OOR;
+    }
+    s2w_kloop(A, acc, voff, b0, mtile, lane, k_lo, k_hi);
+
+    if (k_lo > 0) {   // not the owner: publish the partial sums (still in the transformed domain: the output transform is linear)
+      const int sb = (pub_slot * 4 + wave) * S2W_WSL;
+#pragma unroll
+      for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[p][blk]), rs, (unsigned)lane * 16u, sb + (p * 4 + blk) * 1024, 0);
+          if (blk == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(A.flags + pub_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    if (nc > 0) {
+      if (tid == 0) {
+        for (int c = first_slot; c < first_slot + nc; ++c) {
+          int spins = 0;
+          while (__hip_atomic_load(A.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > S2W_SPIN_MAX) { atomicExch(A.err, 1); break; }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+    }
+    if (S2W_ABL(1)) return;
+    // ---- epilogue: lane holds tiles t0 + 4g .. + 3 (two row-aligned pairs: Tq is even) of channels mtile*64 + blk*16 + lm ----------
+    unsigned ooff[2][2];      // [pair][output row u]
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int T = t0 + 4 * g + 2 * pr;
+      const int b = T / region;
+      const int rem = T - b * region;
+      const int tr = rem / A.Tq, tc = rem - tr * A.Tq;
+      const int m0 = 2 * tr, n0 = 2 * tc;
+      const bool ok = b < A.B && n0 < A.Wout;      // Wout % 4 == 0 and n0 % 4 == 0: the four outputs of a pair are inside together
+      const int co = mtile * 64 + lm;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        ooff[pr][u] = (ok && m0 + u < A.Hout) ? 4u * (unsigned)(((b * A.Cout + co) * A.Hout + m0 + u) * A.Wout + n0) : S2W_OOR;
+    }
+    auto gather = [&](const int p, const int blk) __attribute__((always_inline)) {
+      f32x4 v = acc[p][blk];
+      int sb = (first_slot * 4 + wave) * S2W_WSL + (p * 4 + blk) * 1024;
+      for (int c = 0; c < nc; ++c, sb += 4 * S2W_WSL)
+        v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)lane * 16u, sb, 0));
+      return v;
+    };
+    const int chan = A.Hout * A.Wout * 4;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      f32x4 M[9];
+#pragma unroll
+      for (int p = 0; p < 9; ++p) M[p] = gather(p, blk);
+      const f32x4 R00 = M[0] + M[3], R01 = M[1] + M[4], R02 = M[2] + M[5], R10 = M[3] + M[6], R11 = M[4] + M[7], R12 = M[5] + M[8];
+      f32x4 Y[2][2] = {{R00 + R01, R01 + R02}, {R10 + R11, R11 + R12}};      // [u][v], components = the lane's 4 tiles
+      if (STYLED) {
+        const float bs = A.bias[mtile * 64 + blk * 16 + lm];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y = Y[u][v][e] + bs;
+              Y[u][v][e] = (y > 0.f ? y : y * A.alpha) * A.act_scale;
+            }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 a = Y[u][0], b = Y[u][1];
+        f32x4 lo = {a[0], b[0], a[1], b[1]}, hi = {a[2], b[2], a[3], b[3]};
+        asm volatile("" : "+v"(lo), "+v"(hi));      // assembled in VGPRs, never in live accumulators (conv_up4.hip)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), ro, ooff[0][u], blk * 16 * chan, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), ro, ooff[1][u], blk * 16 * chan, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // work list: the stream-K job first, then the q whole units (conv_up4.hip)
+  const int per = G / A.mt;
+  const int s8 = w / 8, xcd = w - s8 * 8;
+  const int dp_mtile = s8 % A.mt;
+  const int dp_pl = (s8 / A.mt) * 8 + xcd;
+  int64_t sk_a = (int64_t)w * A.skL;
+  const int64_t sk_total = (int64_t)A.r * A.KQ;
+  const int64_t sk_b = (w < A.skJ) ? (sk_a + A.skL < sk_total ? sk_a + A.skL : sk_total) : sk_a;
+  int rd = 0;
+  for (;;) {
+    int ttile, mtile, k_lo, k_hi, first = 0, nc = 0;
+    if (sk_a < sk_b) {
+      const int u_lin = (int)(sk_a / A.KQ);
+      k_lo = (int)(sk_a - (int64_t)u_lin * A.KQ);
+      const int64_t rest = sk_b - (int64_t)u_lin * A.KQ;
+      k_hi = rest < A.KQ ? (int)rest : A.KQ;
+      ttile = A.q * per + u_lin / A.mt; mtile = u_lin % A.mt;
+      if (k_lo == 0 && k_hi < A.KQ) { first = w + 1; nc = (int)(((int64_t)(u_lin + 1) * A.KQ - 1) / A.skL) - w; }
+      sk_a += k_hi - k_lo;
+    } else if (rd < A.q) {
+      k_lo = 0; k_hi = A.KQ;
+      ttile = rd * per + dp_pl; mtile = dp_mtile;
+      ++rd;
+    } else break;
+    run(ttile, mtile, k_lo, k_hi, w, first, nc);
+  }
+  clock_probe_end(A.clk, c0, w0);
+}
+
+// transformed weights from the plain MFMA-order layout [tap][KQ][Mp/16][lane]: idx over [16][KQ][mt][64][4]
+__global__ __launch_bounds__(256) void k_s2w_pack(float* __restrict__ up, const float* __restrict__ wp, int KQ, int nblk, int mt, int64_t n) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const int comp = (int)(idx & 3), ln = (int)((idx >> 2) & 63);
+  int64_t rest = idx >> 8;
+  const int mtile = (int)(rest % mt); rest /= mt;
+  const int kq = (int)(rest % KQ);
+  const int ui = (int)(rest / KQ);
+  const int blk = mtile * 4 + comp;
+  auto Wt = [&](int ky, int kx) { return wp[((int64_t)((ky * 3 + kx) * KQ + kq) * nblk + blk) * 64 + ln]; };
+  // G rows (g0, g0 + g1, g1) with g_a = the tap at offset 2a
+  float v = 0.f;
+  if (ui < 9) {
+    const int i = ui / 3, j = ui % 3;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
+        if ((i == 1 || i == 2 * a) && (j == 1 || j == 2 * b)) v += Wt(2 * a, 2 * b);
+  } else if (ui < 12) {
+    const int i = ui - 9;
+    for (int a = 0; a < 2; ++a) if (i == 1 || i == 2 * a) v += Wt(2 * a, 1);
+  } else if (ui < 15) {
+    const int j = ui - 12;
+    for (int b = 0; b < 2; ++b) if (j == 1 || j == 2 * b) v += Wt(1, 2 * b);
+  } else v = Wt(1, 1);
+  up[idx] = v;
+}
+
+struct S2wTuning { int on, min_ksteps, lmin; };
+static S2wTuning& s2w_tuning() {
+  static S2wTuning t = {getenv("CAGC_S2W") ? atoi(getenv("CAGC_S2W")) : 1, getenv("CAGC_S2W_MIN_KSTEPS") ? atoi(getenv("CAGC_S2W_MIN_KSTEPS")) : 110,
+                        getenv("CAGC_S2W_LMIN") ? atoi(getenv("CAGC_S2W_LMIN")) : 8};
+  return t;
+}
+int& s2w_tuning_on() { return s2w_tuning().on; }
+int& s2w_tuning_min_ksteps() { return s2w_tuning().min_ksteps; }
+int& s2w_tuning_lmin() { return s2w_tuning().lmin; }
+static int g_s2w_launches = 0;
+int s2w_launch_count() { return g_s2w_launches; }
+
+static int s2w_grid() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  return (n_cu / 8) * 8;
+}
+
+// shape part of the launch decision (cagc_s2_plan): M = produced channels in whole 64-channel tiles that divide the grid's workgroups per
+// XCD, output rows of whole 16-byte stores, and at least `s2w_min_ksteps` K-steps (256 outputs x 64 channels each) per workgroup
+bool s2w_for_launch(int B, int K, int M, int Hout, int Wout) {
+  const S2wTuning& tune = s2w_tuning();
+  if (!tune.on || M % 64 != 0 || Wout % 4 != 0 || K < 1 || Hout < 1) return false;
+  const int G = s2w_grid(), mt = M / 64;
+  if (G < 8 || G > 512 || (G / 8) % mt != 0) return false;
+  const int KQ = igemm_kp(K) / 4;
+  const int region = ((Hout + 1) / 2) * round_up((Wout + 1) / 2, 2);
+  const int64_t units = (int64_t)cdiv((int64_t)B * region, 64) * mt;
+  return units * KQ >= (int64_t)tune.min_ksteps * G;
+}
+
+int run_conv_s2w(const ConvArgs& a, hipStream_t st, const char* what) {
+  const S2wTuning& tune = s2w_tuning();
+  if (!tune.on) return CAGC_RD_DECLINED;
+  if (a.kk != 9 || a.Kp % 8 != 0 || a.Kp != igemm_kp(a.Cin) || a.gs || a.in_scale || a.out_scale || a.noise) return CAGC_RD_DECLINED;
+  if (a.epi != CAGC_EPI_LINEAR && !(a.epi == CAGC_EPI_STYLED && a.bias)) return CAGC_RD_DECLINED;
+  if (a.NPin != 1 || a.NPout != 1 || a.isy != 2 || a.isx != 2 || a.osy != 1 || a.osx != 1) return CAGC_RD_DECLINED;
+  if (a.Hin != 2 * a.Hout + 1 || a.Win != 2 * a.Wout + 1 || a.Wopitch != a.Wout) return CAGC_RD_DECLINED;
+  if (a.Cout != a.Mp || a.Wpitch % 4 != 0 || ((uintptr_t)a.in % 16) != 0 || ((uintptr_t)a.out % 16) != 0) return CAGC_RD_DECLINED;
+  if (!s2w_for_launch(a.B, a.Cin, a.Cout, a.Hout, a.Wout)) return CAGC_RD_DECLINED;
+  const int nblk = a.Mp / 16, KQ = a.Kp / 4, mt = nblk / 4;
+  const int64_t up_elems = (int64_t)16 * KQ * mt * 256;
+  if (up_elems * 4 > 0x7fffffff) return CAGC_RD_DECLINED;
+  const int cs = a.Hin * a.Wpitch;
+  const int TR = (a.Hout + 1) / 2, Tq = round_up((a.Wout + 1) / 2, 2);
+  const int region = TR * Tq;
+  const int span = cdiv(64, region) + 1;
+  if ((int64_t)span * a.Cin * cs * 4 > 0x7fffffff) return CAGC_RD_DECLINED;
+  if ((int64_t)a.B * region + 64 >= (1ll << 31)) return CAGC_RD_DECLINED;
+  const int64_t out_bytes = (int64_t)a.B * a.Cout * a.Hout * a.Wout * 4;
+  if (out_bytes > 0x7fffffff) return CAGC_RD_DECLINED;
+  const int G = s2w_grid();
+  const int ttiles = cdiv((int64_t)a.B * region, 64);
+
+  S2wArgs r;
+  memset(&r, 0, sizeof(r));
+  r.in = a.in; r.out = a.out; r.bias = a.bias; r.alpha = a.alpha; r.act_scale = a.act_scale;
+  r.up_bytes = (unsigned)(up_elems * 4); r.out_bytes = (unsigned)out_bytes;
+  r.u_bytes = KQ * mt * 1024;
+  r.B = a.B; r.K = a.Cin; r.KQ = KQ; r.Cout = a.Cout;
+  r.Hin = a.Hin; r.Win = a.Win; r.Wpitch = a.Wpitch; r.Hout = a.Hout; r.Wout = a.Wout; r.TR = TR; r.Tq = Tq;
+  r.mt = mt;
+  const int per = G / mt;
+  r.q = ttiles / per;
+  r.r = (ttiles - r.q * per) * mt;
+  r.clk = clock_probe_ptr();
+  size_t slab_bytes = 0;
+  if (r.r > 0) {
+    const int64_t total = (int64_t)r.r * KQ;
+    int L = (int)((total + G - 1) / G);
+    L = (L + 1) & ~1;
+    const int lmin = tune.lmin < 2 ? 2 : (tune.lmin & ~1);
+    if (L < lmin) L = lmin;
+    if (L > KQ) L = KQ;
+    r.skL = L;
+    r.skJ = (int)((total + L - 1) / L);
+    slab_bytes = (size_t)G * 4 * S2W_WSL;
+  }
+  // scratch: [slabs][4 KB of flags][transformed weights] — the weights are transformed per launch from the packed operand's plain layout
+  float* scratch = ksplit_scratch(slab_bytes + 4096 + (size_t)up_elems * 4, st, what);
+  if (!scratch) return CAGC_ERR_LAUNCH;
+  r.slab = scratch;
+  r.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + slab_bytes);
+  float* up = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + slab_bytes + 4096);
+  r.up = up;
+  if (r.r > 0) {
+    r.err = up4_err_word_ptr();
+    if (!r.err) { set_error("%s: cannot allocate the error word", what); return CAGC_ERR_LAUNCH; }
+    const int zrc = zero_fill(r.flags, 4096, st);
+    if (zrc) return zrc;
+  }
+  hipLaunchKernelGGL(k_s2w_pack, dim3((unsigned)cdiv(up_elems, 256)), dim3(256), 0, st, up, a.wp, KQ, nblk, mt, up_elems);
+  {
+    static const bool dbg = getenv("CAGC_CONV_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[cagc] %s: S2W styled %d G %d mt %d ttiles %d q %d r %d L %d J %d K %d M %d\n", what, (int)(a.epi == CAGC_EPI_STYLED),
+                     G, mt, ttiles, r.q, r.r, r.skL, r.skJ, a.Kp, a.Mp);
+  }
+  ++g_s2w_launches;
+  const dim3 grid((unsigned)G), block(256);
+  if (a.epi == CAGC_EPI_STYLED) hipLaunchKernelGGL((k_conv_s2w<true>), grid, block, 0, st, r);
+  else hipLaunchKernelGGL((k_conv_s2w<false>), grid, block, 0, st, r);
+  return check_launch(what);
+}
+
+}  // namespace cagc
+
+extern "C" int cagc_s2_plan(int B, int K, int M, int Hout, int Wout) { return cagc::s2w_for_launch(B, K, M, Hout, Wout) ? 25 : 36; }

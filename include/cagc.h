@@ -367,6 +367,9 @@ int cagc_wino_plan(int B, int K, int M, int H, int W);
  * produced channels, H x W = the INPUT plane of the transposed convolution) executes under the current tuning: 25 = the Winograd-domain
  * fused-phase kernel (csrc/conv_up25.hip), 36 = the direct kernels (conv_up4.hip / conv_rd.hip).  Benchmarks attribute executed FLOPs with it. */
 int cagc_up_plan(int B, int K, int M, int H, int W);
+/* The same for a launch of cagc_conv3x3s2_fwd / cagc_conv3x3s2_act_fwd (K = input channels, M = output channels, Hout x Wout = the OUTPUT
+ * plane): 25 = the Winograd-domain kernel (csrc/conv_s2w.hip), 36 = the direct kernels (conv_rd.hip). */
+int cagc_s2_plan(int B, int K, int M, int Hout, int Wout);
 /* Diagnostic (benchmarks): while `acc` is non-null, every 64th workgroup of every F(4x4) Winograd and register-direct
  * convolution launch adds the shader clock it measured over its own lifetime (MHz: s_memtime ticks per 100 MHz s_memrealtime
  * tick) to acc[0] and 1 to acc[1] — two device floats the caller owns and zeroes; acc[0] / acc[1] is the clock averaged over

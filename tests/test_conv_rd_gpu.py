@@ -110,7 +110,7 @@ def test_stride2_forward_vector_operand_kernel(shape, act):
     outs = {}
     for s2v in (1, 0):     # the general register-direct kernel computes the same launch: both against float64, and against each other
         out = torch.full((B, cout, ho, ho), float("nan"), device=DEV)
-        with _lib.tuning(rd_s2v=s2v):
+        with _lib.tuning(rd_s2v=s2v, s2w=0):
             if act:
                 _lib.call("cagc_conv3x3s2_act_fwd", _lib.ptr(out), _lib.ptr(x), _lib.ptr(wp_fwd), _lib.ptr(bias), B, cin, cout, hb, hb, pitch, 0.2, math.sqrt(2.0))
             else:
