@@ -51,6 +51,12 @@ def up_macs(k_ch, m_ch, B, H, W):
     return 9.0 * _lib.query("cagc_up_plan", int(B), int(k_ch), int(m_ch), int(H), int(W)) / 36.0
 
 
+def s2_macs(k_ch, m_ch, B, Ho, Wo):
+    """MACs per output pixel and channel pair that a 3x3 stride-2 conv EXECUTES: 9 direct, 6.25 on csrc/conv_s2w.hip (cagc_s2_plan)."""
+    from cagc import _lib
+    return 9.0 * _lib.query("cagc_s2_plan", int(B), int(k_ch), int(m_ch), int(Ho), int(Wo)) / 36.0
+
+
 def conv_flops(name, a):
     """Algorithmic FLOPs (2 * MACs, the repo's own MAC convention of Util/Calculators.py) of one MFMA launch."""
     if name == "cagc_modconv_fwd":       # (out,x,wp,s,B,Cin,Cout,H,W,k,...)
@@ -79,14 +85,16 @@ def conv_flops(name, a):
         return 2.0 * B * cin * cout * wino_macs(cout, cin, B, H, W) * H * W     # data gradient: GEMM K = Cout, M = Cin
     if name == "cagc_conv3x3s2_fwd":     # (out,x,wp,B,Cin,Cout,Hin,Win,pitch)
         B, cin, cout, hin, win = a[3:8]
-        return 2.0 * B * cin * cout * 9 * ((hin - 3) // 2 + 1) * ((win - 3) // 2 + 1)
+        ho, wo = (hin - 3) // 2 + 1, (win - 3) // 2 + 1
+        return 2.0 * B * cin * cout * s2_macs(cin, cout, B, ho, wo) * ho * wo
     if name == "cagc_conv3x3s2_dgrad":   # same arguments; a transposed conv of the (ho x wo) gradient: GEMM K = Cout, M = Cin
         B, cin, cout, hin, win = a[3:8]
         ho, wo = (hin - 3) // 2 + 1, (win - 3) // 2 + 1
         return 2.0 * B * cin * cout * up_macs(cout, cin, B, ho, wo) * ho * wo
     if name == "cagc_conv3x3s2_act_fwd":     # (out,x,wp,bias,B,Cin,Cout,Hin,Win,pitch,...)
         B, cin, cout, hin, win = a[4:9]
-        return 2.0 * B * cin * cout * 9 * ((hin - 3) // 2 + 1) * ((win - 3) // 2 + 1)
+        ho, wo = (hin - 3) // 2 + 1, (win - 3) // 2 + 1
+        return 2.0 * B * cin * cout * s2_macs(cin, cout, B, ho, wo) * ho * wo
     return 0.0
 
 
@@ -122,7 +130,7 @@ KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false, false", "c
              "cagc_wino_conv3x3[k_wino4<false>]": "k_wino4<false,", "cagc_wino_conv3x3_act_dgrad[k_wino4<true>]": "k_wino4<true,",   # both SCALE variants
              "cagc_modconv_fwd": "k_conv_rd<4, true, true, false>",
              "cagc_modconv_up_fwd": "k_conv_up25<true, 0",
-             "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_act_fwd": "k_conv_s2v", "cagc_conv3x3s2_dgrad": "k_conv_up25<false, 1",
+             "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_act_fwd": "k_conv_s2w<true>", "cagc_conv3x3s2_dgrad": "k_conv_up25<false, 1",
              "cagc_modconv_dgrad": "k_conv_rd<5, true, false, true>",
              "cagc_modconv_up_dgrad": "k_conv_rd<5, true, false, true>", "cagc_modconv_wgrad": "k_wgrad_rd<4, 1, false, 9>",
              "cagc_modconv_wgrad_demod": "k_wgrad_rd<3, 1, false, 9>"}

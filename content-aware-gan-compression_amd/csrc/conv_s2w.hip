@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_s2w_pack(float* __restrict__ up, const 
 
 struct S2wTuning { int on, min_ksteps, lmin; };
 static S2wTuning& s2w_tuning() {
-  static S2wTuning t = {getenv("CAGC_S2W") ? atoi(getenv("CAGC_S2W")) : 1, getenv("CAGC_S2W_MIN_KSTEPS") ? atoi(getenv("CAGC_S2W_MIN_KSTEPS")) : 110,
+  static S2wTuning t = {getenv("CAGC_S2W") ? atoi(getenv("CAGC_S2W")) : 1, getenv("CAGC_S2W_MIN_KSTEPS") ? atoi(getenv("CAGC_S2W_MIN_KSTEPS")) : 48,
                         getenv("CAGC_S2W_LMIN") ? atoi(getenv("CAGC_S2W_LMIN")) : 8};
   return t;
 }
@@ -358,7 +358,8 @@ static int s2w_grid() {
 }
 
 // shape part of the launch decision (cagc_s2_plan): M = produced channels in whole 64-channel tiles that divide the grid's workgroups per
-// XCD, output rows of whole 16-byte stores, and at least `s2w_min_ksteps` K-steps (256 outputs x 64 channels each) per workgroup
+// XCD, output rows of whole 16-byte stores, and at least `s2w_min_ksteps` K-steps (256 outputs x 64 channels each) per workgroup (measured
+// per layer at batch 4 / 8 / 16, profiles/r05_time_s2w_bs.log: wins from 64 up, ties at 32, loses at 16)
 bool s2w_for_launch(int B, int K, int M, int Hout, int Wout) {
   const S2wTuning& tune = s2w_tuning();
   if (!tune.on || M % 64 != 0 || Wout % 4 != 0 || K < 1 || Hout < 1) return false;

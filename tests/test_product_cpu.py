@@ -138,7 +138,7 @@ def test_tuning_getters_and_wino_plan_are_host_side():
     lib = _lib.load()
     for key in ("rd", "rd_min_wgs", "rd_min_wgs_long", "rd_mb", "rd_kw", "rd_split", "rd_atomic_below", "rd_split_wgs", "rd_s2v", "deterministic", "wgrad_rd",
                 "wgrad_rd_wgs", "wino4_hv", "wino4_min_wgs", "up4", "up4_min_ksteps", "up4_nb", "up4_lmin", "up4_rotate",
-                "up25", "up25_min_ksteps", "up25_lmin"):
+                "up25", "up25_min_ksteps", "up25_lmin", "s2w", "s2w_min_ksteps", "s2w_lmin"):
         v = _lib.get_tuning(key)
         assert _lib.set_tuning(key, v) == v and _lib.get_tuning(key) == v
     # setting one knob never rewrites another (advisor r4: "rd_min_wgs" used to overwrite "rd_min_wgs_long")
@@ -165,6 +165,10 @@ def test_tuning_getters_and_wino_plan_are_host_side():
     assert _lib.query("cagc_up_plan", 2, 512, 512, 16, 16) == 36          # too few K-steps per workgroup
     with _lib.tuning(up25=0):
         assert _lib.query("cagc_up_plan", 16, 256, 128, 128, 128) == 36
+    assert _lib.query("cagc_s2_plan", 16, 128, 256, 128, 128) == 25         # the stride-2 forward's choice (csrc/conv_s2w.hip)
+    assert _lib.query("cagc_s2_plan", 16, 77, 39, 128, 128) == 36 and _lib.query("cagc_s2_plan", 2, 512, 512, 8, 8) == 36
+    with _lib.tuning(s2w=0):
+        assert _lib.query("cagc_s2_plan", 16, 128, 256, 128, 128) == 36
     assert _lib.get_tuning("wino4_min_wgs") in (256, int(__import__("os").environ.get("CAGC_WINO4_MIN_WGS", "256")))
 
 
@@ -224,18 +228,19 @@ def test_fused_phase_kernel_keeps_its_accumulators_in_the_accumulator_file():
         assert body.count("v_mfma_f32_16x16x4_f32") >= 288, name
         for bad in ("v_accvgpr_write", "v_accvgpr_mov", "scratch_"):
             assert bad not in body, (name, bad)
-    # the Winograd-domain variant (csrc/conv_up25.hip): 200 accumulators, same rule
-    src = os.path.join(ROOT, "content-aware-gan-compression_amd", "csrc", "conv_up25.hip")
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "up25.s")
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-S", "--cuda-device-only", src, "-o", out],
-                       check=True, capture_output=True, timeout=600)
-        text = open(out).read()
-    kernels = [blk for blk in text.split("\n_ZN4cagc11k_conv_up25")[1:]]
-    assert len(kernels) >= 8, "eight variants: SCALE x MODE x patch-load width"
-    for blk in kernels:
-        body = blk.split("s_endpgm")[0]
-        name = "k_conv_up25" + body.split(":")[0]
-        assert body.count("v_mfma_f32_16x16x4_f32") >= 200, name
-        for bad in ("v_accvgpr_write", "v_accvgpr_mov", "scratch_"):
-            assert bad not in body, (name, bad)
+    # the Winograd-domain variants (csrc/conv_up25.hip: 200 accumulators; csrc/conv_s2w.hip: 144), same rule
+    for fname, sym, nvar, nmfma in (("conv_up25.hip", "_ZN4cagc11k_conv_up25", 8, 200), ("conv_s2w.hip", "_ZN4cagc10k_conv_s2w", 2, 400)):
+        src = os.path.join(ROOT, "content-aware-gan-compression_amd", "csrc", fname)
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "k.s")
+            subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-S", "--cuda-device-only", src, "-o", out],
+                           check=True, capture_output=True, timeout=600)
+            text = open(out).read()
+        kernels = [blk for blk in text.split("\n" + sym)[1:]]
+        assert len(kernels) >= nvar, (fname, len(kernels))
+        for blk in kernels:
+            body = blk.split("s_endpgm")[0]
+            name = sym + body.split(":")[0]
+            assert body.count("v_mfma_f32_16x16x4_f32") >= nmfma, name
+            for bad in ("v_accvgpr_write", "v_accvgpr_mov", "scratch_"):
+                assert bad not in body, (name, bad)
