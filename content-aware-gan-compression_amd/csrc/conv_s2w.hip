@@ -308,7 +308,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_s2w(const S2wArgs A) {
 }
 
 // transformed weights from the plain MFMA-order layout [tap][KQ][Mp/16][lane]: idx over [16][KQ][mt][64][4]
-__global__ __launch_bounds__(256) void k_s2w_pack(float* __restrict__ up, const float* __restrict__ wp, int KQ, int nblk, int mt, int64_t n) {
+__global__ __launch_bounds__(256) void k_s2w_pack(float* __restrict__ up, const float* __restrict__ wp, int KQ, int nblk, int mt, int64_t n, int* __restrict__ flags) {
+  if (flags && blockIdx.x == 0)      // the stream-K flag block of the launch that follows (4 KB)
+    for (int i = threadIdx.x; i < 1024; i += 256) flags[i] = 0;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
   const int comp = (int)(idx & 3), ln = (int)((idx >> 2) & 63);
@@ -428,10 +430,8 @@ int run_conv_s2w(const ConvArgs& a, hipStream_t st, const char* what) {
   if (r.r > 0) {
     r.err = up4_err_word_ptr();
     if (!r.err) { set_error("%s: cannot allocate the error word", what); return CAGC_ERR_LAUNCH; }
-    const int zrc = zero_fill(r.flags, 4096, st);
-    if (zrc) return zrc;
   }
-  hipLaunchKernelGGL(k_s2w_pack, dim3((unsigned)cdiv(up_elems, 256)), dim3(256), 0, st, up, a.wp, KQ, nblk, mt, up_elems);
+  hipLaunchKernelGGL(k_s2w_pack, dim3((unsigned)cdiv(up_elems, 256)), dim3(256), 0, st, up, a.wp, KQ, nblk, mt, up_elems, r.r > 0 ? r.flags : nullptr);
   {
     static const bool dbg = getenv("CAGC_CONV_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[cagc] %s: S2W styled %d G %d mt %d ttiles %d q %d r %d L %d J %d K %d M %d\n", what, (int)(a.epi == CAGC_EPI_STYLED),
