@@ -23,8 +23,9 @@
  *           workgroups writes one partial-sum slab per slice and an ordered reduce adds them (bit-reproducible
  *           activations; no fp32 atomics in any forward pass); >= 4 MB, the largest split output x its slices
  *           (< 32 MB on this path; a launch that would need > 256 MB falls back to not splitting).  The same scratch holds the
-           partial-sum slabs (128 MB + a 4 KB flag block) of the persistent stream-K kernel behind cagc_modconv_up_fwd /
-           cagc_conv3x3s2_dgrad on their large launches (csrc/conv_up4.hip);  the LDS-staged fallback kernel (CAGC_RD=0, or tensors
+           partial-sum slabs (<= 128 MB + a 4 KB flag block) and the per-launch transformed weights (<= 16 MB) of the persistent
+           stream-K kernels behind cagc_modconv_up_fwd / cagc_conv3x3s2_dgrad (csrc/conv_up25.hip, conv_up4.hip) and
+           cagc_conv3x3s2_fwd / _act_fwd (csrc/conv_s2w.hip) on their large launches;  the LDS-staged fallback kernel (CAGC_RD=0, or tensors
            beyond the register-direct kernels' 32-bit offsets) still splits a small forward layer's K with fp32 atomics in the
            default mode — the "no fp32 atomics in a forward pass" statement holds for the kernels a launch takes by default;
  *       (b) deterministic mode (cagc_set_tuning("deterministic", 1) / CAGC_DETERMINISTIC=1): the order-independent
@@ -71,7 +72,9 @@ const char* cagc_last_error(void);
  * differ by ~1e-5 of the output scale).  Keys: "rd" (0 = LDS-staged kernel only), "rd_min_wgs", "rd_mb", "rd_kw",
  * "rd_split", "rd_atomic_below", "rd_split_wgs", "rd_min_wgs_long" (-1 = derived from rd_min_wgs at plan time; setting one key never rewrites another), "rd_s2v" (0 = the stride-2 forward's big launches on the general kernel) — see csrc/conv_rd.hip;
  * "up4" (0 = the transposed convs / stride-2 data gradients stay on conv_rd.hip's per-parity launches), "up4_min_ksteps", "up4_nb", "up4_lmin", "up4_rotate" (launch shape of the
- * persistent stream-K kernel) and the read-only "up4_error" (1 after one of its bounded spins gave up; reading it synchronises the device) — csrc/conv_up4.hip; "wgrad_rd" (0 = LDS-staged weight-gradient kernels
+ * persistent stream-K kernel) and the read-only "up4_error" (1 after a bounded stream-K spin of any of these kernels gave up; reading it synchronises the device) and "up4_launches" — csrc/conv_up4.hip;
+ * "up25" (0 = no Winograd-domain transposed conv: cagc_modconv_up_fwd / cagc_conv3x3s2_dgrad fall to "up4" / conv_rd.hip), "up25_min_ksteps", "up25_lmin", read-only "up25_launches" — csrc/conv_up25.hip;
+ * "s2w" (0 = cagc_conv3x3s2_fwd / _act_fwd stay on conv_rd.hip), "s2w_min_ksteps", "s2w_lmin", read-only "s2w_launches" — csrc/conv_s2w.hip (both differ from the direct kernels by fp32 rounding only: transforms with coefficients 0 / +-1); "wgrad_rd" (0 = LDS-staged weight-gradient kernels
  * only), "wgrad_rd_wgs" (workgroups a weight-gradient launch aims at; 0 = its launch model picks the K split, the default) — csrc/conv_wgrad_rd.hip; "wino4_hv" (0 per launch, 1 / 2: 64- / 128-channel workgroup shape of the F(4x4) kernel),
  * "wino4_min_wgs" (64-channel workgroups below which a launch takes the layer's F(2x2) packing; default 256) — csrc/conv_wino4.hip;
  * "deterministic" (also CAGC_DETERMINISTIC=1): forward passes are bit-reproducible run to run in EVERY mode (K splits through
