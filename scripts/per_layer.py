@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "content-aware-gan-compression_amd")]
 import bench
 from cagc import _lib, kd
+if os.environ.get("LIB"):      # a timing-only build variant (scripts/build_variant.sh)
+    _lib.LIB_PATH = os.path.join(ROOT, "content-aware-gan-compression_amd", "cagc", os.environ["LIB"])
 dev = torch.device("cuda")
 student, teacher, disc = kd.build_synthetic_workload(256, dev, seed=0)
 BS = int(os.environ.get("BS", "16"))
