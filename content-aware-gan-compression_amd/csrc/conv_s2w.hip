@@ -21,6 +21,7 @@
 #include "prep_device.h"
 #include "conv_plan.h"
 #include "conv_up4.h"
+#include "conv_streamk.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -43,13 +44,11 @@ struct S2wArgs {
   int TR, Tq;             // tile grid: ceil(Hout/2) rows of Tq = round_up(ceil(Wout/2), 2) tiles
   int u_bytes;            // stride between operands in `up`
   unsigned up_bytes, out_bytes;
-  int mt;                 // channel tiles of 64
-  int q, r, skL, skJ;
+  SkPlan sk;              // channel tiles of 64 per position tile, rounds, stream-K jobs (conv_streamk.h)
   float alpha, act_scale;
 };
 
 constexpr unsigned S2W_OOR = 0x80000000u;
-constexpr int S2W_SPIN_MAX = 1 << 22;
 constexpr int S2W_WSL = 36 * 1024;       // bytes of one wave's slab slot
 
 #ifdef CAGC_S2W_ABL       // debug builds only (wrong results, timing only): 1 no stores, 2 no x loads, 4 no weight loads
@@ -75,7 +74,7 @@ __device__ __forceinline__ void s2w_kloop(const S2wArgs& A, f32x4 (&acc)[9][4], 
   const int64_t step_bytes = (int64_t)16 * cs;
   const float* in_ptr = A.in + ((int64_t)b0 * A.K + (int64_t)4 * kq_lo) * cs;
   int64_t in_left = (((int64_t)(A.B - b0) * A.K - 4 * kq_lo) * cs) * 4;
-  int ao = (kq_lo * A.mt + mtile) * 1024;
+  int ao = (kq_lo * A.sk.mt + mtile) * 1024;
   float4 uv[2][16];
   float4 xq[2][5];      // patch row r: columns 0 .. 3
   float xe[2][5];       //              column 4
@@ -86,7 +85,7 @@ __device__ __forceinline__ void s2w_kloop(const S2wArgs& A, f32x4 (&acc)[9][4], 
     ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_ptr), 0, in_left > 0x7fffffff ? 0x7fffffff : (in_left > 0 ? (int)in_left : 0), 0x00020000);
   };
   auto advance_x = [&](const bool fwd) __attribute__((always_inline)) { if (fwd) { in_ptr += 4 * (int64_t)cs; in_left -= step_bytes; } };
-  auto advance_u = [&](const bool fwd) __attribute__((always_inline)) { if (fwd) ao += A.mt * 1024; };
+  auto advance_u = [&](const bool fwd) __attribute__((always_inline)) { if (fwd) ao += A.sk.mt * 1024; };
   auto load_x = [&](const int slot, const int n) __attribute__((always_inline)) {
     if (S2W_ABL(2)) return;
     if (n & 1) xe[slot][n >> 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, voff[n >> 1] + 16u, 0, 0));
@@ -201,28 +200,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_s2w(const S2wArgs A) {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[p][blk]), rs, (unsigned)lane * 16u, sb + (p * 4 + blk) * 1024, 0);
           if (blk == 3) __builtin_amdgcn_sched_barrier(0);
         }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(A.flags + pub_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      sk_publish(A.flags, pub_slot, tid);
       return;
     }
-    if (nc > 0) {
-      if (tid == 0) {
-        for (int c = first_slot; c < first_slot + nc; ++c) {
-          int spins = 0;
-          while (__hip_atomic_load(A.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __builtin_amdgcn_s_sleep(32);
-            if (++spins > S2W_SPIN_MAX) { atomicExch(A.err, 1); break; }
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      __syncthreads();
-    }
+    if (nc > 0) sk_wait(A.flags, first_slot, nc, A.err, tid);
     if (S2W_ABL(1)) return;
     // ---- epilogue: lane holds tiles t0 + 4g .. + 3 (two row-aligned pairs: Tq is even) of channels mtile*64 + blk*16 + lm ----------
     unsigned ooff[2][2];      // [pair][output row u]
@@ -278,32 +259,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_s2w(const S2wArgs A) {
     }
   };
 
-  // work list: the stream-K job first, then the q whole units (conv_up4.hip)
-  const int per = G / A.mt;
-  const int s8 = w / 8, xcd = w - s8 * 8;
-  const int dp_mtile = s8 % A.mt;
-  const int dp_pl = (s8 / A.mt) * 8 + xcd;
-  int64_t sk_a = (int64_t)w * A.skL;
-  const int64_t sk_total = (int64_t)A.r * A.KQ;
-  const int64_t sk_b = (w < A.skJ) ? (sk_a + A.skL < sk_total ? sk_a + A.skL : sk_total) : sk_a;
-  int rd = 0;
-  for (;;) {
-    int ttile, mtile, k_lo, k_hi, first = 0, nc = 0;
-    if (sk_a < sk_b) {
-      const int u_lin = (int)(sk_a / A.KQ);
-      k_lo = (int)(sk_a - (int64_t)u_lin * A.KQ);
-      const int64_t rest = sk_b - (int64_t)u_lin * A.KQ;
-      k_hi = rest < A.KQ ? (int)rest : A.KQ;
-      ttile = A.q * per + u_lin / A.mt; mtile = u_lin % A.mt;
-      if (k_lo == 0 && k_hi < A.KQ) { first = w + 1; nc = (int)(((int64_t)(u_lin + 1) * A.KQ - 1) / A.skL) - w; }
-      sk_a += k_hi - k_lo;
-    } else if (rd < A.q) {
-      k_lo = 0; k_hi = A.KQ;
-      ttile = rd * per + dp_pl; mtile = dp_mtile;
-      ++rd;
-    } else break;
-    run(ttile, mtile, k_lo, k_hi, w, first, nc);
-  }
+  sk_for_each_job(A.sk, A.KQ, G, w, run);      // its stream-K job first, then its whole units (conv_streamk.h)
   clock_probe_end(A.clk, c0, w0);
 }
 
@@ -403,23 +359,9 @@ int run_conv_s2w(const ConvArgs& a, hipStream_t st, const char* what) {
   r.u_bytes = KQ * mt * 1024;
   r.B = a.B; r.K = a.Cin; r.KQ = KQ; r.Cout = a.Cout;
   r.Hin = a.Hin; r.Win = a.Win; r.Wpitch = a.Wpitch; r.Hout = a.Hout; r.Wout = a.Wout; r.TR = TR; r.Tq = Tq;
-  r.mt = mt;
-  const int per = G / mt;
-  r.q = ttiles / per;
-  r.r = (ttiles - r.q * per) * mt;
+  sk_plan(r.sk, ttiles, mt, G, KQ, tune.lmin);
   r.clk = clock_probe_ptr();
-  size_t slab_bytes = 0;
-  if (r.r > 0) {
-    const int64_t total = (int64_t)r.r * KQ;
-    int L = (int)((total + G - 1) / G);
-    L = (L + 1) & ~1;
-    const int lmin = tune.lmin < 2 ? 2 : (tune.lmin & ~1);
-    if (L < lmin) L = lmin;
-    if (L > KQ) L = KQ;
-    r.skL = L;
-    r.skJ = (int)((total + L - 1) / L);
-    slab_bytes = (size_t)G * 4 * S2W_WSL;
-  }
+  const size_t slab_bytes = r.sk.r > 0 ? (size_t)G * 4 * S2W_WSL : 0;
   // scratch: [slabs][4 KB of flags][transformed weights] — the weights are transformed per launch from the packed operand's plain layout
   float* scratch = ksplit_scratch(slab_bytes + 4096 + (size_t)up_elems * 4, st, what);
   if (!scratch) return CAGC_ERR_LAUNCH;
@@ -427,15 +369,15 @@ int run_conv_s2w(const ConvArgs& a, hipStream_t st, const char* what) {
   r.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + slab_bytes);
   float* up = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + slab_bytes + 4096);
   r.up = up;
-  if (r.r > 0) {
+  if (r.sk.r > 0) {
     r.err = up4_err_word_ptr();
     if (!r.err) { set_error("%s: cannot allocate the error word", what); return CAGC_ERR_LAUNCH; }
   }
-  hipLaunchKernelGGL(k_s2w_pack, dim3((unsigned)cdiv(up_elems, 256)), dim3(256), 0, st, up, a.wp, KQ, nblk, mt, up_elems, r.r > 0 ? r.flags : nullptr);
+  hipLaunchKernelGGL(k_s2w_pack, dim3((unsigned)cdiv(up_elems, 256)), dim3(256), 0, st, up, a.wp, KQ, nblk, mt, up_elems, r.sk.r > 0 ? r.flags : nullptr);
   {
     static const bool dbg = getenv("CAGC_CONV_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[cagc] %s: S2W styled %d G %d mt %d ttiles %d q %d r %d L %d J %d K %d M %d\n", what, (int)(a.epi == CAGC_EPI_STYLED),
-                     G, mt, ttiles, r.q, r.r, r.skL, r.skJ, a.Kp, a.Mp);
+                     G, mt, ttiles, r.sk.q, r.sk.r, r.sk.skL, r.sk.skJ, a.Kp, a.Mp);
   }
   ++g_s2w_launches;
   const dim3 grid((unsigned)G), block(256);
