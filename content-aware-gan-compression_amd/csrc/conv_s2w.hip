@@ -389,3 +389,20 @@ int run_conv_s2w(const ConvArgs& a, hipStream_t st, const char* what) {
 }  // namespace cagc
 
 extern "C" int cagc_s2_plan(int B, int K, int M, int Hout, int Wout) { return cagc::s2w_for_launch(B, K, M, Hout, Wout) ? 25 : 36; }
+
+/* Test hook (host only): the work list conv_streamk.h deals to the G persistent workgroups of a launch with `tiles` position tiles x mt
+ * channel tiles and KQ K-steps — jobs[n] = {workgroup, tile, mtile, k_lo, k_hi, first slot to gather, slots to gather}; returns the number
+ * of jobs (<= cap), or a negative code.  tests/test_product_cpu.py checks that every unit's K range is covered exactly once and that each
+ * owner gathers exactly the slots its unit's other segments publish. */
+extern "C" int cagc_streamk_jobs(int tiles, int mt, int G, int KQ, int lmin, int* jobs, int cap) {
+  if (tiles < 1 || mt < 1 || G < 8 || G % 8 != 0 || (G / 8) % mt != 0 || KQ < 2 || KQ % 2 != 0 || !jobs) return CAGC_ERR_INVALID;
+  cagc::SkPlan p;
+  cagc::sk_plan(p, tiles, mt, G, KQ, lmin);
+  int n = 0;
+  for (int w = 0; w < G; ++w)
+    cagc::sk_for_each_job(p, KQ, G, w, [&](int tile, int mtile, int k_lo, int k_hi, int pub, int first, int nc) {
+      if (n < cap) { int* j = jobs + 7 * n; j[0] = pub; j[1] = tile; j[2] = mtile; j[3] = k_lo; j[4] = k_hi; j[5] = first; j[6] = nc; }
+      ++n;
+    });
+  return n;
+}

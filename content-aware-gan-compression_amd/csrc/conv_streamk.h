@@ -40,7 +40,7 @@ inline void sk_plan(SkPlan& p, int tiles, int mt, int G, int KQ, int lmin) {
 
 // device: the work list of workgroup w — run(tile, mtile, k_lo, k_hi, publish slot, first slot to gather, slots to gather)
 template <class Run>
-__device__ __forceinline__ void sk_for_each_job(const SkPlan& P, const int KQ, const int G, const int w, Run&& run) {
+__host__ __device__ __forceinline__ void sk_for_each_job(const SkPlan& P, const int KQ, const int G, const int w, Run&& run) {
   const int per = G / P.mt;
   const int s8 = w / 8, xcd = w - s8 * 8;
   const int dp_mtile = s8 % P.mt;

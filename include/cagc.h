@@ -373,6 +373,10 @@ int cagc_up_plan(int B, int K, int M, int H, int W);
 /* The same for a launch of cagc_conv3x3s2_fwd / cagc_conv3x3s2_act_fwd (K = input channels, M = output channels, Hout x Wout = the OUTPUT
  * plane): 25 = the Winograd-domain kernel (csrc/conv_s2w.hip), 36 = the direct kernels (conv_rd.hip). */
 int cagc_s2_plan(int B, int K, int M, int Hout, int Wout);
+/* Test hook (host only, no GPU): the work list the persistent stream-K kernels deal to their G workgroups for `tiles` position tiles x
+ * mt channel tiles and KQ K-steps (csrc/conv_streamk.h) — jobs[7 n ..] = {workgroup = publish slot, tile, mtile, k_lo, k_hi, first slot
+ * to gather, slots to gather}; returns the number of jobs (may exceed cap: only cap are written). */
+int cagc_streamk_jobs(int tiles, int mt, int G, int KQ, int lmin, int* jobs, int cap);
 /* Diagnostic (benchmarks): while `acc` is non-null, every 64th workgroup of every F(4x4) Winograd and register-direct
  * convolution launch adds the shader clock it measured over its own lifetime (MHz: s_memtime ticks per 100 MHz s_memrealtime
  * tick) to acc[0] and 1 to acc[1] — two device floats the caller owns and zeroes; acc[0] / acc[1] is the clock averaged over

@@ -244,3 +244,50 @@ def test_fused_phase_kernel_keeps_its_accumulators_in_the_accumulator_file():
             assert body.count("v_mfma_f32_16x16x4_f32") >= nmfma, name
             for bad in ("v_accvgpr_write", "v_accvgpr_mov", "scratch_"):
                 assert bad not in body, (name, bad)
+
+
+def test_stream_k_work_list_covers_every_unit_exactly_once():
+    """csrc/conv_streamk.h deals the units of a persistent launch as whole rounds + a stream-K split of the left-over units.  Host-side
+    replay of the device work list (cagc_streamk_jobs runs the SAME plan / enumeration code): for random launches every unit's K range is
+    covered exactly once by segments of even length; a unit cut across workgroups has exactly one owner (the segment holding K-step 0),
+    which gathers exactly the slots its other segments publish, in ascending K order; no workgroup publishes twice; all workgroups execute
+    the same number of K-steps to within one stream-K job."""
+    import ctypes
+    import random
+    from cagc import _lib
+    lib = _lib.load()
+    rng = random.Random(5)
+    cases = [(1073, 4, 256, 64, 8), (77, 16, 256, 128, 8), (16, 8, 256, 128, 8), (1, 1, 256, 4, 2), (4, 2, 256, 16, 2), (1024, 4, 256, 32, 8)]
+    for _ in range(60):
+        mt = rng.choice([1, 2, 4, 8, 16, 32])
+        G = rng.choice([256, 64, 8 * mt, 304 // (8 * mt) * 8 * mt or 8 * mt])
+        if (G // 8) % mt:
+            continue
+        cases.append((rng.randint(1, 3000), mt, G, 2 * rng.randint(1, 80), 2 * rng.randint(1, 6)))
+    for tiles, mt, G, KQ, lmin in cases:
+        cap = 4 * (tiles * mt + G) + 64
+        buf = (ctypes.c_int * (7 * cap))()
+        n = lib.cagc_streamk_jobs(tiles, mt, G, KQ, lmin, buf, cap)
+        assert 0 < n <= cap, (tiles, mt, G, KQ, lmin, n)
+        jobs = [tuple(buf[7 * i + k] for k in range(7)) for i in range(n)]
+        cover, segs, publishes, work = {}, {}, {}, [0] * G
+        for w, tile, mtile, k_lo, k_hi, first, nc in jobs:
+            assert 0 <= tile < tiles and 0 <= mtile < mt and 0 <= k_lo < k_hi <= KQ and (k_hi - k_lo) % 2 == 0 and k_lo % 2 == 0
+            work[w] += k_hi - k_lo
+            segs.setdefault((tile, mtile), []).append((k_lo, k_hi, w, first, nc))
+            if k_lo > 0:
+                assert w not in publishes, "a workgroup publishes at most one partial sum (its slab slot is its index)"
+                publishes[w] = (tile, mtile)
+        assert len(segs) == tiles * mt
+        for unit, ss in segs.items():
+            ss.sort()
+            assert ss[0][0] == 0 and ss[-1][1] == KQ and all(a[1] == b[0] for a, b in zip(ss, ss[1:])), (unit, ss)
+            k_lo, k_hi, w, first, nc = ss[0]
+            if len(ss) == 1:
+                assert nc == 0
+            else:       # the owner gathers the other segments' slots, which are consecutive workgroups in ascending K order
+                assert nc == len(ss) - 1 and first == w + 1 and [s[2] for s in ss[1:]] == list(range(first, first + nc)), (unit, ss)
+            assert all(s[4] == 0 for s in ss[1:])
+        assert sum(work) == tiles * mt * KQ
+        assert max(work) - min(work) <= max(lmin, 2 * ((tiles % (G // mt)) * mt * KQ // G // 2 + 1)), (tiles, mt, G, KQ, lmin, min(work), max(work))
+
