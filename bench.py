@@ -68,9 +68,10 @@ def conv_flops(name, a):
     if name == "cagc_modconv_dgrad":     # (gx,gs,gz,wp,s,x,B,Cin,Cout,H,W,k)
         B, cin, cout, H, W, k = a[6:12]
         return 2.0 * B * cin * cout * k * k * H * W
-    if name == "cagc_modconv_up_dgrad":
+    if name == "cagc_modconv_up_dgrad":  # a stride-2 forward conv of the phase-planar gradient: GEMM K = Cout, M = Cin, H x W outputs
         B, cin, cout, H, W = a[6:11]
-        return 2.0 * B * cin * cout * 9 * H * W
+        from cagc import _lib
+        return 2.0 * B * cin * cout * (9.0 * _lib.query("cagc_up_dgrad_plan", int(B), int(cout), int(cin), int(H), int(W)) / 36.0) * H * W
     if name == "cagc_modconv_wgrad":     # (gw,ws,g,x,s,B,Cin,Cout,H,W,k,up,scale)
         B, cin, cout, H, W, k = a[5:11]
         return 2.0 * B * cin * cout * k * k * H * W

@@ -75,6 +75,7 @@ _PROTOS = {
     "cagc_wino_plan": [_i, _i, _i, _i, _i],
     "cagc_up_plan": [_i, _i, _i, _i, _i],
     "cagc_s2_plan": [_i, _i, _i, _i, _i],
+    "cagc_up_dgrad_plan": [_i, _i, _i, _i, _i],
     "cagc_streamk_jobs": [_i, _i, _i, _i, _i, _p, _i],
     "cagc_set_clock_probe": [_p],
     "cagc_wino_packed_elems": [_i, _i],

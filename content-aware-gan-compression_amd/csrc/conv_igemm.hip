@@ -897,7 +897,11 @@ extern "C" int cagc_modconv_up_dgrad(float* gx, float* gs, const float* gt, cons
   RawItem it{n, taps, 0, 0, 0, H, W};
   { const int drc = det_begin(a.det_gs, gs, (int64_t)B * Cin, as_stream(stream), what); if (drc) return drc; }
   const DetSink det = a.det_gs;
-  { const int rc = run_conv(a, &it, 1, as_stream(stream), what); if (rc) return rc; }
+  {   // large launches: the Winograd-domain persistent kernel on the phase-planar gradient (conv_s2w.hip)
+    int rc = run_conv_s2w(a, 1, as_stream(stream), what);
+    if (rc == CAGC_RD_DECLINED) rc = run_conv(a, &it, 1, as_stream(stream), what);
+    if (rc) return rc;
+  }
   return det_end(det, gs, (int64_t)B * Cin, as_stream(stream), what);
 }
 
@@ -927,7 +931,7 @@ static int conv3x3s2_fwd_impl(float* out, const float* x, const float* wp, const
   RawItem it{n, taps, 0, 0, 0, Ho, Wo};
   if (bias) { a.epi = CAGC_EPI_STYLED; a.bias = bias; a.alpha = alpha; a.act_scale = act_scale; }   // + bias, LeakyReLU in the MFMA epilogue
   {   // large launches: the Winograd-domain persistent kernel (conv_s2w.hip)
-    const int sw = run_conv_s2w(a, as_stream(stream), what);
+    const int sw = run_conv_s2w(a, 0, as_stream(stream), what);
     if (sw != CAGC_RD_DECLINED) return sw;
   }
   return run_conv(a, &it, 1, as_stream(stream), what);

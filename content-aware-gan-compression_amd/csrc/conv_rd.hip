@@ -841,6 +841,7 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "s2w")) cagc::s2w_tuning_on() = value;
   else if (!strcmp(key, "s2w_min_ksteps")) cagc::s2w_tuning_min_ksteps() = value;
   else if (!strcmp(key, "s2w_lmin")) cagc::s2w_tuning_lmin() = value;
+  else if (!strcmp(key, "s2w_planar")) cagc::s2w_tuning_planar() = value;
   else if (!strcmp(key, "deterministic")) cagc::deterministic_mode() = value;
   else if (!strcmp(key, "wgrad_rd")) cagc::wgrad_rd_set_tuning(value, -1);
   else if (!strcmp(key, "wgrad_rd_wgs")) cagc::wgrad_rd_set_tuning(-1, value);
@@ -876,6 +877,7 @@ extern "C" int cagc_get_tuning(const char* key, int* value) {
   else if (!strcmp(key, "s2w")) *value = cagc::s2w_tuning_on();
   else if (!strcmp(key, "s2w_min_ksteps")) *value = cagc::s2w_tuning_min_ksteps();
   else if (!strcmp(key, "s2w_lmin")) *value = cagc::s2w_tuning_lmin();
+  else if (!strcmp(key, "s2w_planar")) *value = cagc::s2w_tuning_planar();
   else if (!strcmp(key, "s2w_launches")) *value = cagc::s2w_launch_count();
   else if (!strcmp(key, "up4_error")) *value = cagc::up4_error_word();
   else if (!strcmp(key, "up4_launches")) *value = cagc::up4_launch_count();

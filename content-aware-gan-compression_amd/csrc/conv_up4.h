@@ -23,10 +23,11 @@ int up25_launch_count();      // cagc_get_tuning("up25_launches"): launches this
 int& up25_tuning_lmin();       // cagc_set_tuning("up25_lmin"), CAGC_UP25_LMIN
 // Winograd-domain 3x3 stride-2 forward convolution (conv_s2w.hip): 25 products into 9 sums per 2x2 output tile, behind
 // cagc_conv3x3s2_fwd / cagc_conv3x3s2_act_fwd on their large launches; CAGC_RD_DECLINED when it does not take the launch
-int run_conv_s2w(const ConvArgs& a, hipStream_t st, const char* what);
-bool s2w_for_launch(int B, int K, int M, int Hout, int Wout);   // the shape part of its launch decision (include/cagc.h cagc_s2_plan)
+int run_conv_s2w(const ConvArgs& a, int planar, hipStream_t st, const char* what);   // planar = 1: cagc_modconv_up_dgrad (phase-planar input, style-gradient epilogue)
+bool s2w_for_launch(int B, int K, int M, int Hout, int Wout, int planar);   // the shape part of its launch decision (include/cagc.h cagc_s2_plan)
 int& s2w_tuning_on();          // cagc_set_tuning("s2w"), CAGC_S2W
 int& s2w_tuning_min_ksteps();  // cagc_set_tuning("s2w_min_ksteps"), CAGC_S2W_MIN_KSTEPS
 int& s2w_tuning_lmin();        // cagc_set_tuning("s2w_lmin"), CAGC_S2W_LMIN
+int& s2w_tuning_planar();      // cagc_set_tuning("s2w_planar"), CAGC_S2W_PLANAR: 0 = cagc_modconv_up_dgrad stays on conv_rd.hip
 int s2w_launch_count();        // cagc_get_tuning("s2w_launches")
 }  // namespace cagc

@@ -74,7 +74,7 @@ const char* cagc_last_error(void);
  * "up4" (0 = the transposed convs / stride-2 data gradients stay on conv_rd.hip's per-parity launches), "up4_min_ksteps", "up4_nb", "up4_lmin", "up4_rotate" (launch shape of the
  * persistent stream-K kernel) and the read-only "up4_error" (1 after a bounded stream-K spin of any of these kernels gave up; reading it synchronises the device) and "up4_launches" — csrc/conv_up4.hip;
  * "up25" (0 = no Winograd-domain transposed conv: cagc_modconv_up_fwd / cagc_conv3x3s2_dgrad fall to "up4" / conv_rd.hip), "up25_min_ksteps", "up25_lmin", read-only "up25_launches" — csrc/conv_up25.hip;
- * "s2w" (0 = cagc_conv3x3s2_fwd / _act_fwd stay on conv_rd.hip), "s2w_min_ksteps", "s2w_lmin", read-only "s2w_launches" — csrc/conv_s2w.hip (both differ from the direct kernels by fp32 rounding only: transforms with coefficients 0 / +-1); "wgrad_rd" (0 = LDS-staged weight-gradient kernels
+ * "s2w" (0 = cagc_conv3x3s2_fwd / _act_fwd / cagc_modconv_up_dgrad stay on conv_rd.hip), "s2w_planar" (0 = only cagc_modconv_up_dgrad stays there), "s2w_min_ksteps", "s2w_lmin", read-only "s2w_launches" — csrc/conv_s2w.hip (both differ from the direct kernels by fp32 rounding only: transforms with coefficients 0 / +-1); "wgrad_rd" (0 = LDS-staged weight-gradient kernels
  * only), "wgrad_rd_wgs" (workgroups a weight-gradient launch aims at; 0 = its launch model picks the K split, the default) — csrc/conv_wgrad_rd.hip; "wino4_hv" (0 per launch, 1 / 2: 64- / 128-channel workgroup shape of the F(4x4) kernel),
  * "wino4_min_wgs" (64-channel workgroups below which a launch takes the layer's F(2x2) packing; default 256) — csrc/conv_wino4.hip;
  * "deterministic" (also CAGC_DETERMINISTIC=1): forward passes are bit-reproducible run to run in EVERY mode (K splits through
@@ -373,6 +373,8 @@ int cagc_up_plan(int B, int K, int M, int H, int W);
 /* The same for a launch of cagc_conv3x3s2_fwd / cagc_conv3x3s2_act_fwd (K = input channels, M = output channels, Hout x Wout = the OUTPUT
  * plane): 25 = the Winograd-domain kernel (csrc/conv_s2w.hip), 36 = the direct kernels (conv_rd.hip). */
 int cagc_s2_plan(int B, int K, int M, int Hout, int Wout);
+/* ... and of cagc_modconv_up_dgrad (K = the layer's Cout, M = its Cin, H x W = its input plane): the planar form of the same kernel. */
+int cagc_up_dgrad_plan(int B, int K, int M, int H, int W);
 /* Test hook (host only, no GPU): the work list the persistent stream-K kernels deal to their G workgroups for `tiles` position tiles x
  * mt channel tiles and KQ K-steps (csrc/conv_streamk.h) — jobs[7 n ..] = {workgroup = publish slot, tile, mtile, k_lo, k_hi, first slot
  * to gather, slots to gather}; returns the number of jobs (may exceed cap: only cap are written). */

@@ -38,4 +38,19 @@ for (cin, cout, H) in [(128, 256, 256), (256, 512, 128), (512, 512, 64), (512, 5
         tot[name] += dt
         row += f"   {name} {dt*1e6:8.1f} us {fl/dt/1e12:6.1f} TF @{c:.0f} MHz"
     print(row, flush=True)
+# the student's up-layer data gradients (cagc_modconv_up_dgrad: the planar form of the same kernel, with the style-gradient reduction)
+for (cin, cout, H) in [(77, 39, 128), (154, 77, 64), (154, 154, 32), (154, 154, 16)]:
+    wt = torch.randn(1, cout, cin, 3, 3, device="cuda")
+    _, wp_bwd, _ = mc.pack_weights(wt, True)
+    P = _lib.query("cagc_phase_pitch", H)
+    gt = torch.randn(B, cout, 4, H + 1, P, device="cuda"); x = torch.randn(B, cin, H, H, device="cuda"); sc = torch.rand(B, cin, device="cuda") + 0.5
+    gx = torch.empty(B, cin, H, H, device="cuda"); gs = torch.zeros(B, cin, device="cuda")
+    fl = 2.0 * B * cin * cout * 9 * H * H
+    row = f"up dgrad {cin}<-{cout} @{H}^2:"
+    for name, kn in MODES:
+        with _lib.tuning(**kn):
+            dt, c = timeit(lambda: _lib.call("cagc_modconv_up_dgrad", _lib.ptr(gx), _lib.ptr(gs), _lib.ptr(gt), _lib.ptr(wp_bwd), _lib.ptr(sc), _lib.ptr(x), B, cin, cout, H, H))
+        tot[name] += dt
+        row += f"   {name} {dt*1e6:8.1f} us {fl/dt/1e12:6.1f} TF @{c:.0f} MHz"
+    print(row, flush=True)
 print("sum: " + "   ".join(f"{m} {v*1e3:.3f} ms" for m, v in tot.items()) + f"   error word {_lib.get_tuning('up4_error')}   s2w launches {_lib.get_tuning('s2w_launches')}")

