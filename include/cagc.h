@@ -56,7 +56,8 @@ extern "C" {
 #define CAGC_ERR_LAUNCH (-2)   /* hipGetLastError() after a launch */
 #define CAGC_ERR_UNSUPPORTED (-3)
 
-#define CAGC_ABI_VERSION 2 /* 2: round-4 signature / buffer-size changes (cagc_torgb_bwd_finish, cagc_torgb_bwd's gws, the F(4x4) packed layout) + cagc_gan_kd_loss_tail */
+#define CAGC_ABI_VERSION 2 /* 2: round-4 signature / buffer-size changes (cagc_torgb_bwd_finish, cagc_torgb_bwd's gws, the F(4x4) packed layout) + cagc_gan_kd_loss_tail;
+                             later additions that change no existing signature keep the number: cagc_up_plan, cagc_s2_plan, cagc_up_dgrad_plan, cagc_streamk_jobs */
 
 typedef void* cagc_stream_t; /* hipStream_t */
 
