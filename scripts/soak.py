@@ -12,3 +12,6 @@ for i in range(301):
         torch.cuda.synchronize()
         pn = sum(p.detach().float().norm().item() ** 2 for p in student.parameters()) ** 0.5
         print(i, "g %.4f kd_l1 %.4f |params| %.3f finite %s" % (l["g"].item(), l["kd_l1_loss"].item(), pn, all(torch.isfinite(p).all().item() for p in student.parameters())), flush=True)
+from cagc import _lib
+torch.cuda.synchronize()
+print("stream-K error word", _lib.get_tuning("up4_error"))
