@@ -448,7 +448,25 @@ int run_conv_up25(const ConvArgs& a, int mode, hipStream_t st, const char* what)
     if (a.Wopitch % 4 != 0 || a.Wopitch < 4 * Tq - 4 || a.Wopitch < 2 * W + 2 || ((uintptr_t)a.out % 16) != 0) return CAGC_RD_DECLINED;
     out_bytes = (int64_t)a.B * a.Cout * a.Hout * a.Wopitch * 4;
   }
-  if (out_bytes > 0x7fffffff) return CAGC_RD_DECLINED;
+  if (out_bytes > 0x7fffffff) {
+    // an output beyond the 32-bit buffer offsets (batch 64 at 256^2: 2.2 GB): the launch is cut into equal batch chunks, each its own
+    // persistent launch on the same stream (they share the scratch: serialised) — if every chunk still passes the launch rule
+    const int64_t per_img = out_bytes / a.B;
+    const int bmax = (int)(0x7fffffff / per_img);
+    if (bmax < 1) return CAGC_RD_DECLINED;
+    const int nparts = cdiv(a.B, bmax), chunk = cdiv(a.B, nparts);
+    if (!up25_for_launch(a.B - (nparts - 1) * chunk, a.Cin, a.Cout, H, W)) return CAGC_RD_DECLINED;
+    for (int b0 = 0; b0 < a.B; b0 += chunk) {
+      ConvArgs c = a;
+      c.B = a.B - b0 < chunk ? a.B - b0 : chunk;
+      c.in = a.in + (int64_t)b0 * a.Cin * H * a.Wpitch;
+      c.out = a.out + (int64_t)b0 * (per_img / 4);
+      if (a.in_scale) c.in_scale = a.in_scale + (int64_t)b0 * a.Cin;
+      const int rc = run_conv_up25(c, mode, st, what);
+      if (rc) return rc == CAGC_RD_DECLINED ? CAGC_ERR_LAUNCH : rc;      // (cannot decline any more: the other chunks are already in flight)
+    }
+    return CAGC_OK;
+  }
   const int G = up25_grid();
   const int ttiles = cdiv((int64_t)a.B * region, 64);
 

@@ -93,3 +93,28 @@ def test_stream_k_handoff_is_bit_reproducible():
                     assert torch.equal(v, first), (B, cin, cout, H, it)
         torch.cuda.synchronize()
     no_spin_timeout()
+
+
+def test_output_beyond_two_gigabytes_is_cut_into_batch_chunks():
+    """batch 64 at 256^2 (the saliency sweep's largest up layer): the phase-planar output is 2.2 GB, beyond the kernel's 32-bit buffer
+    offsets — the launch runs as two batch chunks; every image must equal the same image computed in a small batch"""
+    torch.manual_seed(34)
+    B, cin, cout, H = 64, 16, 128, 128
+    wt = torch.randn(1, cout, cin, 3, 3, device=DEV)
+    wp_fwd, _, _ = mc.pack_weights(wt, True)
+    x, s = torch.randn(B, cin, H, H, device=DEV), torch.rand(B, cin, device=DEV) + 0.5
+    P = _lib.query("cagc_phase_pitch", H)
+    t = torch.full((B, cout, 4, H + 1, P), float("nan"), device=DEV)
+    assert t.numel() * 4 > 2 ** 31
+    n0 = _lib.get_tuning("up25_launches")
+    with _lib.tuning(up25=1, up25_min_ksteps=0):
+        _lib.call("cagc_modconv_up_fwd", _lib.ptr(t), _lib.ptr(x), _lib.ptr(wp_fwd), _lib.ptr(s), B, cin, cout, H, H)
+        assert _lib.get_tuning("up25_launches") == n0 + 2
+        for b0 in (0, 31, 32, 63):
+            tb = torch.full((1, cout, 4, H + 1, P), float("nan"), device=DEV)
+            xb, sb = x[b0:b0 + 1].contiguous(), s[b0:b0 + 1].contiguous()
+            _lib.call("cagc_modconv_up_fwd", _lib.ptr(tb), _lib.ptr(xb), _lib.ptr(wp_fwd), _lib.ptr(sb), 1, cin, cout, H, H)
+            assert rel(t[b0:b0 + 1, ..., :H + 1], tb[..., :H + 1]) <= 1e-6, b0
+    torch.cuda.synchronize()
+    no_spin_timeout()
+
