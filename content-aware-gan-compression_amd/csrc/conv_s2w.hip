@@ -30,6 +30,7 @@
 #include "conv_up4.h"
 #include "conv_streamk.h"
 #include <stdlib.h>
+#include <atomic>
 #include <string.h>
 
 namespace cagc {
@@ -400,7 +401,7 @@ int& s2w_tuning_on() { return s2w_tuning().on; }
 int& s2w_tuning_min_ksteps() { return s2w_tuning().min_ksteps; }
 int& s2w_tuning_lmin() { return s2w_tuning().lmin; }
 int& s2w_tuning_planar() { return s2w_tuning().planar; }
-static int g_s2w_launches = 0;
+static std::atomic<int> g_s2w_launches{0};
 int s2w_launch_count() { return g_s2w_launches; }
 
 static int s2w_grid() {

@@ -23,6 +23,7 @@
 #include "conv_up4.h"
 #include "conv_streamk.h"
 #include <stdlib.h>
+#include <atomic>
 #include <string.h>
 
 namespace cagc {
@@ -392,7 +393,7 @@ static Up25Tuning& up25_tuning() {
 int& up25_tuning_on() { return up25_tuning().on; }
 int& up25_tuning_min_ksteps() { return up25_tuning().min_ksteps; }
 int& up25_tuning_lmin() { return up25_tuning().lmin; }
-static int g_up25_launches = 0;
+static std::atomic<int> g_up25_launches{0};
 int up25_launch_count() { return g_up25_launches; }
 
 static int up25_grid() {
@@ -463,7 +464,8 @@ int run_conv_up25(const ConvArgs& a, int mode, hipStream_t st, const char* what)
       c.out = a.out + (int64_t)b0 * (per_img / 4);
       if (a.in_scale) c.in_scale = a.in_scale + (int64_t)b0 * a.Cin;
       const int rc = run_conv_up25(c, mode, st, what);
-      if (rc) return rc == CAGC_RD_DECLINED ? CAGC_ERR_LAUNCH : rc;      // (cannot decline any more: the other chunks are already in flight)
+      if (rc == CAGC_RD_DECLINED) { set_error("%s: a batch chunk of a > 2 GB launch was declined after earlier chunks were launched", what); return CAGC_ERR_LAUNCH; }
+      if (rc) return rc;
     }
     return CAGC_OK;
   }

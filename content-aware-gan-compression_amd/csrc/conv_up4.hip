@@ -28,6 +28,7 @@
 #include "conv_plan.h"
 #include "conv_up4.h"
 #include <stdlib.h>
+#include <atomic>
 #include <string.h>
 
 namespace cagc {
@@ -409,7 +410,7 @@ static int* up4_err_word() {
 }
 
 int* up4_err_word_ptr() { return up4_err_word(); }
-static int g_up4_launches = 0;
+static std::atomic<int> g_up4_launches{0};
 int up4_launch_count() { return g_up4_launches; }
 
 int up4_error_word() {      // 1 after a bounded spin gave up (a contributor never published): the outputs of that launch are garbage

@@ -24,7 +24,8 @@ def rel(a, b):
 # (B, cin, cout, Ho, Wo, lmin): everything stream-K (fewer units than workgroups), a whole round + a left-over, K not a multiple of 8
 # channels, odd tile rows (Ho odd), non-square planes, a tile row shorter than a wave's 16 tiles
 SHAPES = [(2, 128, 256, 32, 32, 8), (1, 512, 512, 16, 16, 8), (3, 20, 64, 4, 4, 2), (16, 64, 64, 8, 8, 4), (5, 24, 128, 20, 20, 2),
-          (3, 36, 64, 7, 12, 2), (9, 64, 64, 63, 64, 8), (2, 256, 512, 64, 64, 8)]
+          (3, 36, 64, 7, 12, 2), (9, 64, 64, 63, 64, 8), (2, 256, 512, 64, 64, 8),
+          (2, 32, 77, 8, 8, 2), (2, 32, 48, 8, 8, 2), (3, 24, 154, 12, 12, 2)]      # 5 / 3 channel blocks per wave, ragged last block
 
 
 @pytest.mark.parametrize("act", [False, True])
