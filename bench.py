@@ -30,6 +30,7 @@ import torch.distributed as dist  # noqa: E402
 GLOBAL_BATCH = 16
 SIZE = 256
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
+DIRECT_GFLOP_PER_IMG = 301.0  # teacher fwd 45.1 + student fwd 4.12 + bwd 8.24 + D fwd 46.5 + dgrad 46.5 GMAC per image, x 2
 PEAK_HBM_GBS = 8000.0
 
 
@@ -96,6 +97,9 @@ def conv_flops(name, a):
         B, cin, cout, hin, win = a[4:9]
         ho, wo = (hin - 3) // 2 + 1, (win - 3) // 2 + 1
         return 2.0 * B * cin * cout * s2_macs(cin, cout, B, ho, wo) * ho * wo
+    if name == "cagc_gemm1x1":           # (out,x,ap,residual,B,K,M,P,alpha,beta): the ResBlock skip's 1x1 conv, one GEMM per image
+        B, K, M, P = a[4:8]
+        return 2.0 * B * K * M * P
     return 0.0
 
 
@@ -118,6 +122,58 @@ def stream_bytes(name, a):
     if name == "cagc_blur_up_fwd":            # (out,t,fir,d,noise,nb,nw,bias,B,C,H,W,...): 4 phase planes in, 2Hx2W out
         B, C, H, W = a[8:12]
         return 4.0 * B * C * (4 * (H + 1) * (W + 1) + 4 * H * W)
+    if name == "cagc_blur_up_bwd":            # (gt,gz,fir,B,C,H,W): 2Hx2W gradient in, 4 phase planes out
+        B, C, H, W = a[3:7]
+        return 4.0 * B * C * (4 * (H + 1) * (W + 1) + 4 * H * W)
+    if name == "cagc_torgb_fwd":              # (out,x,w,s,bias,skip,fir,B,C,H,W,scale): read x (+ skip at half size), write 3 channels
+        B, C, H, W = a[7:11]
+        return 4.0 * B * H * W * (C + 3 + (0.75 if a[5] is not None else 0.0))
+    if name == "cagc_torgb_bwd":              # (gx,gws,g,x,w,s,B,C,H,W,scale): read g (3 ch) + x, write gx
+        B, C, H, W = a[6:10]
+        return 4.0 * B * H * W * (2 * C + 3)
+    if name == "cagc_torgb_bwd_finish":       # (gw,gs,gbias,gws,s,w,B,C,scale): [B,3,C+1] sums in, [3,C] + [B,C] out
+        B, C = a[6:8]
+        return 4.0 * (B * 3 * (C + 1) + 2 * B * C + 6 * C)
+    if name == "cagc_styled_act_bwd":         # (gz,red,gout,out,d,noise,nb,B,C,HW,...): read gout + out (+ noise), write gz
+        nb, B, C, HW = a[6:10]
+        return 4.0 * HW * (3 * B * C + nb)
+    if name == "cagc_scale_reduce":           # (gx,x,s,gs,B,C,HW): read gx + x, write gx
+        return 12.0 * a[4] * a[5] * a[6]
+    if name == "cagc_maplin_fwd":             # (y,x,w,b,R,in,out,...): the weight matrix is the traffic (R <= 256 rows)
+        R, D, O = a[4:7]
+        return 4.0 * (D * O + R * D + R * O)
+    if name == "cagc_maplin_bwd":             # (gx,gw,gb,gy,y,x,w,R,in,out,...): read w, write gw
+        R, D, O = a[7:10]
+        return 4.0 * (2 * D * O + 2 * R * D + 2 * R * O)
+    if name == "cagc_modbank_fwd":            # (out,latent,wptrs,bptrs,meta,L,Ctot,B,n_latent,style_dim,scale): every modulation matrix once
+        L, Ctot, B, nl, D = a[5:10]
+        return 4.0 * (Ctot * D + B * nl * D + B * Ctot)
+    if name == "cagc_modbank_bwd":            # (gw,gb,g_latent,gs,latent,wptrs,meta,L,Ctot,B,n_latent,style_dim,scale)
+        L, Ctot, B, nl, D = a[7:12]
+        return 4.0 * (2 * Ctot * D + 2 * B * nl * D + B * Ctot)
+    if name == "cagc_styled_bwd_tail":        # (gbias,gnw,gs,gwsq,red,bias,nw,d,s,wsq,B,Cin,Cout,has_noise): wsq in, gwsq out
+        B, cin, cout = a[10:13]
+        return 4.0 * (2 * cin * cout + 5 * B * cout + 2 * B * cin)
+    if name == "cagc_gan_kd_loss_tail":       # (out3,gs,gpred,pred,P,t,s,mask,B,C,HW,...): read teacher + student + mask, write gs
+        B, C, HW = a[8:11]
+        return 4.0 * B * HW * (3 * C + 1)
+    if name == "cagc_pixelnorm_fwd":          # (y,x,rows,dim)
+        return 8.0 * a[2] * a[3]
+    if name == "cagc_add_scale":              # (out,a,b,n,scale)
+        return 12.0 * a[3]
+    if name == "cagc_mix_latent_fwd":         # (latent,w0,w1,inject,B,n_latent,D)
+        return 4.0 * a[4] * (a[5] + 2) * a[6]
+    if name == "cagc_mix_latent_bwd":         # (gw0,gw1,g,inject,B,n_latent,D)
+        return 4.0 * a[4] * (a[5] + 2) * a[6]
+    if name == "cagc_modconv_prep_bank":      # (jobs,njobs): weights in; packed fwd / bwd operands, wsq and Winograd-domain weights out
+        tot = 0.0
+        for j in a[0][:a[1]]:
+            w = float(j.Cout) * j.Cin * j.ksize * j.ksize
+            tot += 4.0 * w * (1 + (1 if j.wp_fwd else 0) + (1 if j.wp_bwd else 0)) + 4.0 * j.Cout * j.Cin * (
+                (1 if j.wsq else 0) + (16 if j.up_fwd else 0) + (16 if j.up_bwd else 0))
+        return tot
+    if name == "cagc_demod_bank":             # (jobs,njobs,B): wsq [Cout,Cin] + s [B,Cin] in, d [B,Cout] out, per layer
+        return sum(4.0 * (j.Cout * j.Cin + a[2] * (j.Cin + j.Cout)) for j in a[0][:a[1]])
     return 0.0
 
 
@@ -248,6 +304,8 @@ def cpu_baseline(steps=3, batch=16, budget_s=120.0, threads=None):
         times.append(one(batch))
     med = sorted(times)[len(times) // 2]
     return {"value": round(batch / med, 4), "unit": "images/s", "cores": cores, "host_logical_cpus": os.cpu_count(), "kind": "port",
+            "cores_note": "intra-op threads = min(os.cpu_count(), 32): the grouped-conv CPU kernels stop scaling there and oversubscribe beyond it "
+                          "(measured 5x SLOWER with all 256 hardware threads of a 2 x EPYC 9575F host: 0.0134 img/s; --cpu-all-cores times that too)",
             "sample": f"{len(times)} timed KD generator step(s) at batch {batch} of the 256px bs16 workload after a batch-2 warm-up; "
                       f"median {med:.1f} s/step (all: {', '.join(f'{t:.1f}' for t in times)} s)",
             "cpu_model": _cpu_model()}
@@ -486,8 +544,16 @@ def main():
             for _ in range(3):
                 prof_step.sample_and_step(bs, mask, rng, None)
         agg = kt.summary()
-        _lib.load().cagc_set_clock_probe(None)
         clk_mhz = float(clk_acc[0] / clk_acc[1]) if float(clk_acc[1]) > 0 else None
+        # the dominant kernel's OWN clock: the probe restricted to the F(4x4) Winograd launches (cagc_set_tuning("clock_probe_family", 1)).
+        # The all-kernel mean above mixes in the register-direct convs, which hold 2.3-2.4 GHz; k_wino4 itself runs lower.
+        clk_acc.zero_()
+        with _lib.tuning(clock_probe_family=1):
+            for _ in range(2):
+                prof_step.sample_and_step(bs, mask, rng, None)
+            torch.cuda.synchronize()
+        _lib.load().cagc_set_clock_probe(None)
+        clk_w4 = float(clk_acc[0] / clk_acc[1]) if float(clk_acc[1]) > 0 else None
         kd.OVERLAP_TEACHER = overlap_saved
         _mc._SIDE_LIMIT = side_saved
         if rank == 0:
@@ -516,9 +582,14 @@ def main():
                     # `peak` is the guide's figure at 2.4 GHz; under real operands the F(4x4) kernel runs at the board's power limit (back to
                     # back: 2.0 GHz; 2.35 GHz on all-zero operands, same instruction stream: DESIGN.md §5).  The probe averages every 64th
                     # workgroup of every probed launch (F(4x4) and register-direct convs) of these eagerly launched steps:
+                    "leg": "eager launches on ONE stream (HIP events need individual launches; teacher / weight-gradient / ToRGB side streams off) — the "
+                           "timed region replays the same step from a HIP graph with those streams on",
                     "shader_clock_mhz": None if clk_mhz is None else round(clk_mhz),
-                    "shader_clock_note": "mean over every 64th workgroup of every F(4x4) Winograd and register-direct conv launch of these eagerly launched steps (cagc_set_clock_probe)",
-                    "frac_at_measured_clock": None if clk_mhz is None else round(ach / (PEAK_F32_MFMA_TFLOPS * clk_mhz / 2400.0), 4),
+                    "shader_clock_note": "mean over every 64th workgroup of every F(4x4) Winograd and register-direct / stream-K conv launch of these eagerly launched steps (cagc_set_clock_probe)",
+                    "dominant_kernel_clock_mhz": None if clk_w4 is None else round(clk_w4),
+                    "dominant_kernel_clock_note": "the same probe restricted to the k_wino4 launches (cagc_set_tuning('clock_probe_family', 1)): the clock the dominant kernel itself runs at inside the step",
+                    "frac_at_measured_clock": None if (clk_w4 or clk_mhz) is None else round(ach / (PEAK_F32_MFMA_TFLOPS * (clk_w4 or clk_mhz) / 2400.0), 4),
+                    "frac_at_measured_clock_note": "achieved / (peak x dominant_kernel_clock / 2400 MHz): the share of the matrix pipe's cycles at the clock the kernel ran at",
                     "achieved_direct_conv_equivalent": round(ach * (4.0 if "k_wino4" in name else (2.25 if name.startswith("cagc_wino_conv3x3") else 1.0)), 2),
                     "flops_note": ("MFMA flops executed (Winograd F(4x4,3x3): 2.25 MACs/output/channel-pair; its direct-conv equivalent "
                                    "rate is 4x 'achieved')" if "k_wino4" in name else
@@ -527,6 +598,20 @@ def main():
                     "all_mfma_entry_points": {k: {"ms_per_step": round(v[1] / 3, 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
                                               for k, v in sorted(mfma.items(), key=lambda kv: -kv[1][1])},
                     "cagc_kernel_ms_per_step": {k: round(v[1] / 3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+            # step-level figures: what the TFLOP/s in this line mean.  `executed` = MFMA flops the kernels issue (Winograd F(4x4): 2.25,
+            # F(2x2): 4, parity-domain stride-2: 6.25 of the direct conv's 9 MACs per output and channel pair); `direct_equivalent` = the
+            # analytic count of SURVEY 8-d (301 GFLOP per image: what a direct-convolution implementation would execute) — it may exceed
+            # the 157.3 TFLOP/s fp32-MFMA peak and is NOT a utilisation figure.
+            k_ms = sum(v[1] for v in agg.values()) / 3
+            k_attr = sum(v[1] for v in agg.values() if v[2] > 0 or v[3] > 0) / 3
+            exec_flops = sum(v[2] for v in agg.values()) / 3
+            roof["step_kernel_ms_one_stream"] = round(k_ms, 3)
+            roof["frac_of_step_attributed"] = round(k_attr / k_ms, 4) if k_ms > 0 else None
+            roof["step_executed_tflops"] = round(exec_flops / (ms * 1e-3) / 1e12, 1)
+            roof["step_direct_equivalent_tflops"] = round(DIRECT_GFLOP_PER_IMG * 1e9 * bs / (ms * 1e-3) / 1e12, 1) if SIZE == 256 else None
+            roof["step_tflops_note"] = ("per rank, over the TIMED ms_per_step: executed = MFMA flops issued by the libcagc launches of one step; direct_equivalent = "
+                                        "301 GFLOP/img (SURVEY 8-d, every conv counted as a direct convolution) — not a utilisation figure, may exceed the peak")
+            roof["unattributed_entry_points"] = {k: round(v[1] / 3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]) if v[2] == 0 and v[3] == 0}
             hbm = {k: v for k, v in agg.items() if v[3] > 0}
             if hbm:   # secondary: the HBM-bound streaming kernels against the 8 TB/s HBM3E peak (SURVEY 8-d "report both")
                 big = {}     # the largest launch of each entry point on its own (small launches are latency-bound)
@@ -683,7 +768,17 @@ def main():
                  "median_batch_ms": round(med_b * 1e3, 1), "unit": "images/s", "batches": nb, "batch_size": 64,
                  "shader_clock_mhz": round(float(sw_clk[0] / sw_clk[1])) if float(sw_clk[1]) > 0 else None,
                  "what": "content-aware saliency sweep, full 256px generator fwd+bwd (271 GFLOP/img), on-device mask/noise/score",
-                 "tflops": round(64 * nb / dts * 271e9 / 1e12, 1), "score_layers": len(sc)}
+                 "direct_equivalent_tflops": round(64 * nb / dts * 271e9 / 1e12, 1),
+                 "tflops_note": "direct_equivalent = 271 GFLOP/img (every conv as a direct convolution) x images/s: NOT a utilisation figure, it may exceed "
+                                "the 157.3 TFLOP/s fp32-MFMA peak; executed = the MFMA flops the launches of one more (untimed) batch issue, over the median batch time",
+                 "score_layers": len(sc)}
+        try:      # executed flops of one batch (HIP-event-free: only the launch arguments are read)
+            with KernelTimer(_lib) as kts:
+                prune.content_aware_scores(teacher, 64, 64, 0.05, mfn, dev)
+            sweep["executed_tflops"] = round(sum(r[3] for r in kts.records) / med_b / 1e12, 1)
+        except Exception as e:  # noqa: BLE001
+            sweep["executed_tflops"] = None
+            print(f"[bench] sweep executed-flops pass failed ({type(e).__name__}: {e})", file=sys.stderr)
         teacher.eval()
         kd.requires_grad(teacher, False)
     cpu = None

@@ -95,9 +95,15 @@ class KDStep:
         # and under HIP-graph capture (fork / join become graph dependencies).
         overlap = zs[0].is_cuda and OVERLAP_TEACHER
 
+        # only the 'Intermediate' distillation term reads the lower-resolution RGB outputs: without them the generators keep their
+        # ToRGB chain private (its backward then runs beside the styled convs' backward, mc._ToRGB)
+        want_list = self.kd_mode == "Intermediate"
+
         def run_teacher():
             with torch.no_grad():
-                t_list = self.teacher(zs, return_rgb_list=True, inject_index=inject_index, noise=teacher_noise)
+                t_list = self.teacher(zs, return_rgb_list=want_list, inject_index=inject_index, noise=teacher_noise)
+                if not want_list:
+                    t_list = [t_list]
                 m = mask
                 if self.parsing_net is not None:     # on-device content mask from the teacher's image (train.py:155-158)
                     m = content_mask.teacher_content_mask(t_list[-1], self.parsing_net)
@@ -112,7 +118,9 @@ class KDStep:
             with torch.cuda.stream(side):
                 teacher_list, mask = run_teacher()
         self._mark()
-        fake_list = self.student(zs, return_rgb_list=True, inject_index=inject_index, noise=student_noise)
+        fake_list = self.student(zs, return_rgb_list=want_list, inject_index=inject_index, noise=student_noise)
+        if not want_list:
+            fake_list = [fake_list]
         self._mark("train_G_g_forward")
         fake_pred = self.disc_frozen(fake_list[-1])
         if overlap:
@@ -153,15 +161,19 @@ class KDStep:
         fake_pred, fake_list, teacher_list, mask = self._forward_all(zs, inject_index, mask, student_noise, teacher_noise)
         return g_nonsaturating_loss(fake_pred), self._kd_term(fake_list, teacher_list, mask), fake_list[-1]
 
-    def g_total(self, zs, inject_index, mask, student_noise=None, teacher_noise=None, grad_scale=1.0):
-        """(total, g_loss, kd_l1): `total` = g_loss + kd_l1 is the tensor to differentiate WITH THE IMPLICIT UNIT GRADIENT (its
-        gradients come out multiplied by grad_scale — the 1 / world_size of a data-parallel mean); the other two are detached values.
+    def g_total(self, zs, inject_index, mask, student_noise=None, teacher_noise=None, grad_scale=1.0, unit_seed=False):
+        """(total, g_loss, kd_l1): `total` = g_loss + kd_l1 is the tensor to differentiate (its gradients come out multiplied by
+        grad_scale — the 1 / world_size of a data-parallel mean); the other two are detached values.
         On the GPU in the measured configuration (Output_Only, content mask, no LPIPS) the three losses and both backward seeds are ONE
-        launch (cagc_gan_kd_loss_tail) instead of a chain of ~14 aten kernels; anything else composes the reference's terms."""
+        launch (cagc_gan_kd_loss_tail) instead of a chain of ~14 aten kernels; anything else composes the reference's terms.
+        unit_seed=True (only `g_step` / `_fwd_bwd`, which own the `backward()` call) lets that launch write the seeds for the IMPLICIT
+        unit upstream gradient and skips the multiply by it; the default honours whatever the caller backpropagates — a scaled
+        loss (`(total / accum).backward()`, a GradScaler, `autograd.grad(grad_outputs=...)`) scales the gradients on both paths."""
         fake_pred, fake_list, teacher_list, mask = self._forward_all(zs, inject_index, mask, student_noise, teacher_noise)
         if (self.kd_mode == "Output_Only" and self.percept_loss is None and mask is not None
                 and mc.gan_kd_loss_tail_ok(fake_pred, fake_list[-1], teacher_list[-1], mask)):
-            return mc.gan_kd_loss_tail(fake_pred, fake_list[-1], teacher_list[-1], mask, self.kd_l1_lambda, grad_scale, unit_seed=True)
+            return mc.gan_kd_loss_tail(fake_pred, fake_list[-1], teacher_list[-1], mask, self.kd_l1_lambda, grad_scale,
+                                       unit_seed=unit_seed)
         g_loss, kd_l1 = g_nonsaturating_loss(fake_pred), self._kd_term(fake_list, teacher_list, mask)
         total = g_loss + kd_l1
         if grad_scale != 1.0:
@@ -171,12 +183,14 @@ class KDStep:
     def g_step(self, zs, inject_index, mask, student_noise=None, teacher_noise=None):
         requires_grad(self.student, True)
         requires_grad(self.disc, False)
-        total, g_loss, kd_l1 = self.g_total(zs, inject_index, mask, student_noise, teacher_noise)
+        total, g_loss, kd_l1 = self.g_total(zs, inject_index, mask, student_noise, teacher_noise, unit_seed=True)
         self._mark("train_G_d_forward")      # as in the reference's profiler: D forward + teacher forward + the KD loss
         self.optim.zero_grad(set_to_none=True)
         total.backward()
         self.optim.step()
         self._mark("train_G_g_backward")
+        if total.is_cuda:
+            mc.check_streamk_error(total.device)      # host-mapped word, no synchronisation (csrc/conv_streamk.h)
         if self.percept_loss is not None:
             lp = self.last_kd_lpips.detach()
             return {"g": g_loss, "kd_l1_loss": kd_l1 - lp, "kd_lpips_loss": lp}
@@ -325,6 +339,10 @@ class TrainIteration(KDStep):
         return out
 
 
+class _CaptureFailed(RuntimeError):
+    """The HIP-graph capture of a step failed (its __cause__ says why); raised only from inside the capture proper."""
+
+
 class GraphedKDStep(KDStep):
     """The same step replayed from a HIP graph (torch.cuda.CUDAGraph): latent sampling, student / teacher / D forward, the loss
     tail, the whole backward, the gradient all-reduce and Adam.  This removes the ~1400 per-step host launches (the step is
@@ -393,15 +411,25 @@ class GraphedKDStep(KDStep):
             import torch.distributed as dist
             if dist.get_backend() != "nccl":  # only RCCL collectives are stream-ordered device work that a HIP graph can hold
                 modes = ["host"]
+        # The eager warm-up (allocator pools, lazy initialisation, Adam state) runs ONCE, outside any fallback: an out-of-memory or a
+        # kernel error there is a real error and propagates.  Only a failure of the stream capture itself selects the next mode, and
+        # CAGC_STRICT_COMM=1 turns even that into an error (the first multi-GPU run should fail loudly rather than change mode).
+        strict = os.environ.get("CAGC_STRICT_COMM", "0") == "1"
+        self.comm_reason = ("no collective (world size 1)" if not self._reduce else
+                            f"requested comm={comm!r}" if len(modes) == 1 and comm != "auto" else
+                            "backend is not nccl/RCCL: collectives cannot be captured" if modes == ["host"] else
+                            "collectives captured inside the step graph")
+        self._warm_up()
         err = None
         for m in modes:
             ok = 1.0
             try:
                 self._capture(m)
-            except Exception as e:  # noqa: BLE001 — a collective that cannot be captured is a supported outcome
-                if m == modes[-1]:
-                    raise
-                err, ok = e, 0.0
+            except _CaptureFailed as e:      # the collective (or anything else) could not be captured: a supported outcome
+                if m == modes[-1] or strict:
+                    raise RuntimeError(f"GraphedKDStep: capturing the step with comm={m!r} failed"
+                                       + (" (CAGC_STRICT_COMM=1: no fallback)" if strict and m != modes[-1] else "")) from e.__cause__
+                err, ok = e.__cause__, 0.0
             if world_size > 1:                # every rank must take the same branch: the modes issue different collectives
                 import torch.distributed as dist
                 okt = torch.tensor([ok], device=dev)
@@ -410,10 +438,28 @@ class GraphedKDStep(KDStep):
             if ok > 0:
                 self.comm = m
                 break
+            why = f"{type(err).__name__}: {err}" if err else "failed on another rank"
+            if strict:
+                raise RuntimeError(f"GraphedKDStep: capturing the step with comm={m!r} failed on some rank ({why}); CAGC_STRICT_COMM=1: no fallback")
+            self.comm_reason = f"fallback: capturing the collectives inside the graph failed ({why})"
             import sys
-            print(f"[cagc] GraphedKDStep: capturing the collectives inside the graph failed ({type(err).__name__ if err else 'on another rank'}: {err}); "
+            print(f"[cagc] GraphedKDStep: capturing the collectives inside the graph failed ({why}); "
                   "falling back to one flat all-reduce between two graphs", file=sys.stderr)
         assert self.comm is not None
+
+    def close(self):
+        """Detach this step from the student: remove the bucket hooks (they hold `self`, i.e. the graphs and the flat buffers).
+        Call before building another GraphedKDStep on the same student (the 'construct after loading and re-capture' resume path)."""
+        for h in getattr(self, "_hooks", []):
+            h.remove()
+        self._hooks = []
+        self._armed = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 — interpreter shutdown
+            pass
 
     # ---- gradient layout ------------------------------------------------------------------------------------------------------
     def _probe_grad_order(self, params):
@@ -428,7 +474,7 @@ class GraphedKDStep(KDStep):
         try:
             z = [torch.randn_like(self.z[0]), torch.randn_like(self.z[1])]
             inj = torch.full_like(self.inj, max(1, self.n_latent // 2))      # with style mixing: both passes through the mapping network
-            total, _, _ = self.g_total(z, inj, self.mask, self.s_noise, self.t_noise)
+            total, _, _ = self.g_total(z, inj, self.mask, self.s_noise, self.t_noise, unit_seed=True)
             total.backward()
         finally:
             for h in hooks:
@@ -456,7 +502,23 @@ class GraphedKDStep(KDStep):
         for k, bk in enumerate(self._buckets):
             for q in self._params[bk[2]:bk[3]]:
                 self._bucket_of[id(q)] = k
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params]
+        # The hooks hold only a weak reference to this step, and a step that is re-built on the same student first removes its
+        # predecessor's hooks: an abandoned step (and its graphs / flat buffers) is then free to be collected, and an eager backward
+        # pays one Python call per parameter, not one per step ever constructed.
+        import weakref
+        base = self.student.module if hasattr(self.student, "module") else self.student
+        prev = base.__dict__.get("_cagc_graphed_step")
+        prev = prev() if prev is not None else None
+        if prev is not None and prev is not self:
+            prev.close()
+        base.__dict__["_cagc_graphed_step"] = weakref.ref(self)
+        me = weakref.ref(self)
+
+        def hook(p):
+            step = me()
+            if step is not None:
+                step._on_grad(p)
+        self._hooks = [p.register_post_accumulate_grad_hook(hook) for p in self._params]
         self._armed = False
 
     def _on_grad(self, p):
@@ -516,7 +578,8 @@ class GraphedKDStep(KDStep):
     def _fwd_bwd(self):
         if self.random_noise:
             self.z.normal_()
-        total, g_loss, kd_l1 = self.g_total([self.z[0], self.z[1]], self.inj, self.mask, self.s_noise, self.t_noise, grad_scale=self._grad_scale)
+        total, g_loss, kd_l1 = self.g_total([self.z[0], self.z[1]], self.inj, self.mask, self.s_noise, self.t_noise,
+                                            grad_scale=self._grad_scale, unit_seed=True)
         # Gradients are produced into fresh tensors (grad = None: autograd assigns instead of launching one accumulate-add per
         # parameter into a pre-zeroed buffer); each bucket is gathered into the flat all-reduce / Adam buffer by ONE concatenation as
         # soon as its last gradient exists (_on_grad).
@@ -540,7 +603,7 @@ class GraphedKDStep(KDStep):
             p.grad = v
         return torch.stack([g_loss, kd_l1])
 
-    def _capture(self, mode):
+    def _warm_up(self):
         requires_grad(self.student, True)
         requires_grad(self.disc, False)
         # The warm-up (allocator pools, lazy inits, Adam state creation) takes real optimiser steps: snapshot the
@@ -568,6 +631,11 @@ class GraphedKDStep(KDStep):
         if self.world > 1:                            # belt and braces: every replica starts from rank 0's weights
             import torch.distributed as dist
             dist.broadcast(self._flat_param.data, src=0)
+
+    def _capture(self, mode):
+        """Capture the step under `mode`; a failure INSIDE the stream capture raises _CaptureFailed (the caller may fall back)."""
+        requires_grad(self.student, True)
+        requires_grad(self.disc, False)
         self.graph_fb = self.graph_opt = None
         if mode == "graph":       # ONE graph: forward, backward with the bucket collectives inside it, Adam
             self._in_graph_comm = self._reduce
@@ -580,22 +648,27 @@ class GraphedKDStep(KDStep):
                 with torch.cuda.graph(g, capture_error_mode="thread_local" if self._in_graph_comm else "global"):
                     self.losses = self._fwd_bwd()
                     self._flat_optim.step()
-            except Exception:
+            except Exception as e:      # noqa: BLE001 — whatever invalidated the capture (RCCL refusing to be captured, ...)
                 self._in_graph_comm = False
                 torch.cuda.synchronize()
-                raise
+                raise _CaptureFailed(mode) from e
             self.graph_fb = g
         else:                     # two graphs around one host-issued flat all-reduce
             self._in_graph_comm = False
-            self.graph_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_fb):
-                self.losses = self._fwd_bwd()
-            self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt):
-                self._flat_optim.step()
+            try:
+                self.graph_fb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_fb):
+                    self.losses = self._fwd_bwd()
+                self.graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_opt):
+                    self._flat_optim.step()
+            except Exception as e:      # noqa: BLE001
+                torch.cuda.synchronize()
+                raise _CaptureFailed(mode) from e
 
     def replay(self, inject_index=None):
         """One step on whatever the static buffers hold.  inject_index: int in 1..n_latent-1, or None = no mixing."""
+        mc.check_streamk_error(self.inj.device)      # what earlier replays left in the host-mapped error word (no synchronisation)
         self._inj_host[0] = self.n_latent if inject_index is None else int(inject_index)
         self.inj.copy_(self._inj_host, non_blocking=True)
         self.graph_fb.replay()

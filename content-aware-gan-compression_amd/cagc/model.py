@@ -389,7 +389,7 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, input, style, skip=None, return_style_scalars=False, _s=None):
+    def forward(self, input, style, skip=None, return_style_scalars=False, _s=None, _chain=(-1, False)):
         conv = self.conv
         up = getattr(self, "upsample", None)
         fused = (mc.use_hip(input) and input.dtype == torch.float32
@@ -397,9 +397,11 @@ class ToRGB(nn.Module):
                                        and up.pad == (2, 1) and skip.shape[2] * 2 == input.shape[2])))
         if fused:
             s = _s if _s is not None else conv.modulation(style)
-            out = mc._ToRGB.apply(input, conv.weight, s, self.bias, skip, up.kernel if skip is not None else None)
+            out = mc._ToRGB.apply(input, conv.weight, s, self.bias, skip, up.kernel if skip is not None else None, _chain[0], _chain[1])
             styles = s.view(input.shape[0], 1, input.shape[1], 1, 1)
         else:
+            if skip is not None:
+                mc.torgb_join(skip, _chain[0])      # an earlier ToRGB of this chain may have produced `skip` on the side stream
             out, styles = conv(input, style, True)
             out = out + self.bias
             if skip is not None:
@@ -612,7 +614,21 @@ class Generator(nn.Module):
         if rss:
             out, sc = out
             styles_list.append(sc)
-        skip = self.to_rgb1(out, latent[:, 1], _s=bs(1))
+        # The ToRGB chain (1x1 modulated conv + bias + up-sampled skip per resolution: reference model.py:380-395) only reads the
+        # layer outputs: on the GPU its launches go to a side stream beside the styled convs (mc._ToRGB, mc.FORK_TORGB); the caller's
+        # stream joins below.  `private`: the intermediate RGB outputs do not leave this function, so in backward each ToRGB's
+        # skip gradient can stay on the side stream (only the next ToRGB's backward reads it).
+        private = not return_rgb_list and not rss and not want_latent
+        slot = -1
+        fork_mode = mc.FORK_TORGB_MODE      # 1 every generator, 2 only under autograd (the student), 3 only without (teacher / EMA)
+        if (mc.FORK_TORGB and out.is_cuda and not want_latent and out.shape[0] >= mc.FORK_TORGB_MIN_BATCH
+                and (fork_mode == 1 or (fork_mode == 2) == torch.is_grad_enabled())):
+            slot = self.__dict__.get("_fork_slot")
+            if slot is None:
+                slot = mc.new_fork_slot()
+                object.__setattr__(self, "_fork_slot", slot)      # (replicas made by nn.DataParallel inherit it: same slot, their own device)
+        chain = (slot, private)
+        skip = self.to_rgb1(out, latent[:, 1], _s=bs(1), _chain=chain)
         rgb_img_list = [skip]
         i = 1
         for blk, to_rgb in enumerate(self.to_rgbs):
@@ -623,12 +639,13 @@ class Generator(nn.Module):
                     out, sc = out
                     styles_list.append(sc)
             if rss and (i + 3) == latent.shape[1]:   # only the last ToRGB reports its scalars (ref :637-639)
-                skip, sc = to_rgb(out, latent[:, i + 2], skip, True, _s=bs(4 + 3 * blk))
+                skip, sc = to_rgb(out, latent[:, i + 2], skip, True, _s=bs(4 + 3 * blk), _chain=chain)
                 styles_list.append(sc)
             else:
-                skip = to_rgb(out, latent[:, i + 2], skip, _s=bs(4 + 3 * blk))
+                skip = to_rgb(out, latent[:, i + 2], skip, _s=bs(4 + 3 * blk), _chain=chain)
             rgb_img_list.append(skip)
             i += 2
+        mc.torgb_join(skip, slot)      # the caller's stream sees every RGB output
         image = skip
         if want_latent:
             return image, latent

@@ -112,6 +112,68 @@ def _side_stream(dev):
     return st
 
 
+# The student's ToRGB chain on a side stream (round 6).  ToRGB (1x1 modulated conv + skip up-sampling: small, HBM-bound launches that
+# only READ the layer outputs) runs beside the styled-conv chain, forward and backward, through explicit fork / join events INSIDE the
+# op (_ToRGB): autograd sees a one-stream graph.  Measured on the replayed KD step (profiles/r06_ab_fork.log, same box, two pairs):
+# batch 16: 27.67 / 27.62 -> 27.29 / 27.46 ms; batch 8 and 4: equal; batch 2: 6.13 / 6.21 -> 6.33 / 6.37 ms (a cross-stream edge of a HIP
+# graph costs more than a 10 us launch that it lets overlap) — hence FORK_TORGB_MIN_BATCH.  Modes (CAGC_FORK_TORGB): 0 off, 2 only
+# under autograd (the student; default), 3 only without (teacher / EMA), 1 both.  Modes 1 / 3 are for eager use only: the teacher's
+# forward already runs on its own forked stream, and a fork nested inside a forked stream crashes hipStreamEndCapture on ROCm 7.2
+# (segmentation fault in capture_end, scripts/debug_fork.py).  The same experiment on the ResBlock skip's decimating FIR (beside
+# conv1 -> blur -> conv2) gave nothing at batch 4-16 and 6.21 -> 6.53 ms at batch 2: not kept.
+FORK_TORGB_MODE = int(os.environ.get("CAGC_FORK_TORGB", "2"))
+FORK_TORGB = FORK_TORGB_MODE > 0
+FORK_TORGB_MIN_BATCH = int(os.environ.get("CAGC_FORK_TORGB_MIN_BATCH", "8"))
+_fork_streams = {}
+
+
+def fork_stream(dev, slot=0):
+    """The side stream of fork slot `slot` on `dev` (generators take their slot from `new_fork_slot`).
+    One stream per (device, slot) for the life of the process — NOT per caller stream: the eager warm-up and a later HIP-graph capture
+    then fork into the SAME stream, so everything that is set up per stream at first use (the library's per-stream scratch, torch's
+    allocator pool) already exists when the capture begins.  Returns (current stream, side stream); the side stream already waits for
+    everything queued on the current one."""
+    dev = torch.device(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    main = torch.cuda.current_stream(dev)
+    key = (dev.index, slot)
+    st = _fork_streams.get(key)
+    if st is None:
+        with _side_lock:
+            st = _fork_streams.get(key)
+            if st is None:
+                st = _fork_streams[key] = torch.cuda.Stream(device=dev)
+    st.wait_stream(main)
+    return main, st
+
+
+_fork_slots = [16]
+
+
+def new_fork_slot():
+    """a process-unique fork slot (one per Generator instance: the teacher's forward runs on its own stream beside the student's,
+    so their ToRGB chains must not share a side stream)"""
+    with _side_lock:
+        _fork_slots[0] += 1
+        return _fork_slots[0]
+
+
+def check_streamk_error(dev=None, sync=False):
+    """Raise if a persistent stream-K kernel (csrc/conv_streamk.h) gave up a bounded spin on `dev` since the process started: the
+    launch returned CAGC_OK and wrote garbage (a contributor workgroup was never scheduled — a pre-empted or shared GPU, a
+    profiler that serialises workgroups).  sync=False reads the host-mapped word without synchronising (every step: launches still
+    in flight are seen at the next poll); sync=True synchronises the device first (checkpoint time, smoke())."""
+    if dev is not None and torch.device(dev).type != "cuda":
+        return
+    with (torch.cuda.device(dev) if dev is not None else _nullctx()):
+        v = _lib.get_tuning("up4_error" if sync else "streamk_error_nosync")
+    if v != 0:
+        raise RuntimeError("libcagc: a persistent stream-K convolution launch gave up waiting for a contributor workgroup "
+                           f"(error word {v}): activations / gradients computed since the last check are not trustworthy. "
+                           "Do not share the GPU with other work (or set cagc_set_tuning('up25', 0), ('s2w', 0), ('up4', 0)).")
+
+
 _stock_conv_warned = set()
 
 
@@ -981,8 +1043,18 @@ def mix_latent_ok(w0, w1, inject):
 # ToRGB
 # ---------------------------------------------------------------------------------------------------
 class _ToRGB(Function):
+    """ToRGB (reference model.py:380-395) as one forward launch (1x1 modulated conv without demodulation + bias + the up-sampled
+    skip) and two or three backward launches.  With FORK_TORGB its launches go to the side stream that belongs to the caller's
+    stream — explicit fork / join events inside this node, so autograd sees a one-stream graph:
+      forward : side waits for the caller's stream (the layer output x), nothing joins here — the next ToRGB reads `out` on the same
+                side stream and Generator._synthesize joins once at the end (torgb_join);
+      backward: gx and the parameter / style gradients join the caller's stream (an event behind the first two launches); the skip
+                gradient stays on the side stream when the chain is `private` (only the previous ToRGB's backward reads it — it is
+                tagged, and that node then skips its wait for the caller's stream, so the whole RGB backward chain runs beside the
+                styled convs' backward), otherwise the node joins completely."""
+
     @staticmethod
-    def forward(ctx, x, weight, s, bias, skip, fir):
+    def forward(ctx, x, weight, s, bias, skip, fir, slot=-1, private=False):
         x = x.contiguous()
         s = s.contiguous()
         B, C, H, W = x.shape
@@ -991,11 +1063,20 @@ class _ToRGB(Function):
         sk = skip.contiguous() if skip is not None else None
         out = torch.empty(B, 3, H, W, dtype=x.dtype, device=x.device)
         scale = 1.0 / math.sqrt(C)
+        side = None
+        if FORK_TORGB and slot >= 0 and not composed_active():
+            main, side = fork_stream(x.device, slot)
         with _lib.on_device(x):
-            _lib.call("cagc_torgb_fwd", _lib.ptr(out), _lib.ptr(x), _lib.ptr(w2), _lib.ptr(s), _lib.ptr(b1), _lib.ptr(sk),
-                      _lib.ptr(fir) if sk is not None else None, B, C, H, W, scale)
+            with (torch.cuda.stream(side) if side is not None else _nullctx()):
+                _lib.call("cagc_torgb_fwd", _lib.ptr(out), _lib.ptr(x), _lib.ptr(w2), _lib.ptr(s), _lib.ptr(b1), _lib.ptr(sk),
+                          _lib.ptr(fir) if sk is not None else None, B, C, H, W, scale)
+        if side is not None:
+            for t_ in (out, x, w2, s, b1, sk):      # allocated on the caller's stream, used on the side stream
+                if t_ is not None:
+                    t_.record_stream(side)
         ctx.save_for_backward(x, w2, s, fir)
         ctx.has_skip = skip is not None
+        ctx.slot, ctx.private = (slot if side is not None else -1), bool(private)
         return out
 
     @staticmethod
@@ -1010,15 +1091,44 @@ class _ToRGB(Function):
         gweight = torch.empty(1, 3, C, 1, 1, dtype=x.dtype, device=x.device)
         gs = torch.empty(B, C, dtype=x.dtype, device=x.device)
         gbias = torch.empty(1, 3, 1, 1, dtype=x.dtype, device=x.device)
+        gskip = torch.empty(B, 3, H // 2, W // 2, dtype=x.dtype, device=x.device) if ctx.has_skip else None
+        side = None
+        if ctx.slot >= 0:
+            main = torch.cuda.current_stream(x.device)
+            side = _fork_streams[(x.device.index, ctx.slot)]
+            if getattr(gout, "_cagc_on_stream", None) is not side:     # gout was produced on the caller's stream
+                side.wait_stream(main)
+        partial = side is not None and ctx.private and ctx.has_skip
         with _lib.on_device(x):
-            _lib.call("cagc_torgb_bwd", _lib.ptr(gx), _lib.ptr(gws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(w2), _lib.ptr(s), B, C,
-                      H, W, scale)
-            _lib.call("cagc_torgb_bwd_finish", _lib.ptr(gweight), _lib.ptr(gs), _lib.ptr(gbias), _lib.ptr(gws), _lib.ptr(s), _lib.ptr(w2), B, C, scale)
-        gskip = None
-        if ctx.has_skip:
-            # adjoint of upfirdn2d(up=2, pad=(2,1)): flipped FIR, down=2, pad=(1,1)  (reference op/upfirdn2d.py:111-116)
-            gskip = _upfirdn_launch(g, _flipped(fir), (1, 1), (2, 2), (1, 1, 1, 1), (H // 2, W // 2))
-        return gx, gweight, gs, gbias, gskip, None
+            with (torch.cuda.stream(side) if side is not None else _nullctx()):
+                _lib.call("cagc_torgb_bwd", _lib.ptr(gx), _lib.ptr(gws), _lib.ptr(g), _lib.ptr(x), _lib.ptr(w2), _lib.ptr(s), B, C,
+                          H, W, scale)
+                _lib.call("cagc_torgb_bwd_finish", _lib.ptr(gweight), _lib.ptr(gs), _lib.ptr(gbias), _lib.ptr(gws), _lib.ptr(s), _lib.ptr(w2), B, C, scale)
+                if partial:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    main.wait_event(ev)              # the caller's stream continues behind gx / gweight / gs / gbias ...
+                if ctx.has_skip:
+                    # adjoint of upfirdn2d(up=2, pad=(2,1)): flipped FIR, down=2, pad=(1,1)  (reference op/upfirdn2d.py:111-116)
+                    _upfirdn_launch(g, _flipped(fir), (1, 1), (2, 2), (1, 1, 1, 1), (H // 2, W // 2), out=gskip)
+        if side is not None:
+            if partial:
+                gskip._cagc_on_stream = side          # ... and the skip gradient stays on the side stream for the previous ToRGB
+            else:
+                main.wait_stream(side)
+            for t_ in (g, x, w2, s, gx, gws, gweight, gs, gbias, gskip):
+                if t_ is not None:
+                    t_.record_stream(side)
+        return gx, gweight, gs, gbias, gskip, None, None, None
+
+
+def torgb_join(image, slot):
+    """Generator._synthesize, after the last ToRGB: the caller's stream waits for the RGB side stream (no-op when nothing forked)."""
+    if not (FORK_TORGB and slot >= 0 and torch.is_tensor(image) and image.is_cuda):
+        return
+    side = _fork_streams.get((image.device.index, slot))
+    if side is not None:
+        torch.cuda.current_stream(image.device).wait_stream(side)
 
 
 # ---------------------------------------------------------------------------------------------------

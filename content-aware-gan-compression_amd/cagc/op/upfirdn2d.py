@@ -14,12 +14,14 @@ def _out_size(n, up, p0, p1, k, down):
     return (n * up + p0 + p1 - k) // down + 1
 
 
-def _launch(x4, kernel, up, down, pad, out_hw):
-    """x4 [N,C,H,W] contiguous -> [N,C,oh,ow]."""
+def _launch(x4, kernel, up, down, pad, out_hw, out=None):
+    """x4 [N,C,H,W] contiguous -> [N,C,oh,ow] (`out`: a caller-allocated contiguous result, e.g. one allocated on another stream)."""
     n, c, h, w = x4.shape
     kh, kw = kernel.shape
     oh, ow = out_hw
-    out = torch.empty(n, c, oh, ow, dtype=x4.dtype, device=x4.device)
+    if out is None:
+        out = torch.empty(n, c, oh, ow, dtype=x4.dtype, device=x4.device)
+    assert tuple(out.shape) == (n, c, oh, ow) and out.dtype == x4.dtype and out.is_contiguous()
     if x4.dtype != torch.float32:     # fp16 / fp64: generic any-dtype kernel, FIR taps in the tensors' element type
         k = kernel.to(x4.dtype).contiguous()
         with _lib.on_device(x4):

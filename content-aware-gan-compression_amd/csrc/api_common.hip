@@ -130,7 +130,10 @@ extern "C" const char* cagc_arch(void) { return "gfx950"; }
 
 namespace cagc {
 static float* g_clock_probe = nullptr;     // diagnostic; process-wide (include/cagc.h cagc_set_clock_probe)
+static int g_clock_probe_family = 0;       // cagc_set_tuning("clock_probe_family"): 0 every probed kernel, 1 only the F(4x4) Winograd kernel
 float* clock_probe_ptr() { return g_clock_probe; }
+float* clock_probe_ptr_other() { return g_clock_probe_family == 0 ? g_clock_probe : nullptr; }
+int& clock_probe_family() { return g_clock_probe_family; }
 }  // namespace cagc
 
 extern "C" int cagc_set_clock_probe(float* acc) {

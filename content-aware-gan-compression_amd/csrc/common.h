@@ -85,6 +85,8 @@ __device__ __forceinline__ float group16_sum(float v) {
 // that every 64th workgroup measured over its own lifetime (MHz) to [0] and 1 to [1]: samples spread over the grid are spread over the
 // launch's duration ([0] / [1] = the launch-averaged clock; sampling only workgroup 0 measured the same — there is no start-of-launch bias).
 float* clock_probe_ptr();
+float* clock_probe_ptr_other();   // the kernels other than k_wino4: null while cagc_set_tuning("clock_probe_family", 1) restricts the probe to F(4x4)
+int& clock_probe_family();
 __device__ __forceinline__ bool clock_probe_on(const float* acc) { return acc != nullptr && (blockIdx.x & 63) == 0; }
 __device__ __forceinline__ void clock_probe_begin(const float* acc, long long& c0, long long& w0) {
   if (clock_probe_on(acc)) { c0 = clock64(); w0 = wall_clock64(); }

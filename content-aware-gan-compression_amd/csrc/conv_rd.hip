@@ -631,7 +631,7 @@ int run_conv_rd(ConvArgs& a, const RawItem* raw, int nitems, hipStream_t st, con
   r.NPin = a.NPin; r.Hin = a.Hin; r.Win = a.Win; r.Wpitch = a.Wpitch; r.isy = a.isy; r.isx = a.isx;
   r.NPout = a.NPout; r.Hout = a.Hout; r.Wout = a.Wout; r.Wopitch = a.Wopitch; r.osy = a.osy; r.osx = a.osx;
   r.nitems = nitems; r.epi = a.epi; r.noise_bstride_on = a.noise_bstride_on; r.alpha = a.alpha; r.act_scale = a.act_scale;
-  r.clk = clock_probe_ptr();
+  r.clk = clock_probe_ptr_other();
   // register-direct weight layout: behind the LDS kernel's layout in the same packed buffer (prep_device.h)
   const RdTile T = rd_tile(nblk);
   const int ntile_p = cdiv(nblk, T.rb);
@@ -846,6 +846,7 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "wgrad_rd")) cagc::wgrad_rd_set_tuning(value, -1);
   else if (!strcmp(key, "wgrad_rd_wgs")) cagc::wgrad_rd_set_tuning(-1, value);
   else if (!strcmp(key, "wino4_hv")) cagc::wino4_hv_tuning() = value;
+  else if (!strcmp(key, "clock_probe_family")) cagc::clock_probe_family() = value;
   else if (!strcmp(key, "wino4_min_wgs")) cagc::wino4_min_wgs() = value;
   else { cagc::set_error("cagc_set_tuning: unknown key '%s'", key); return CAGC_ERR_INVALID; }
   return CAGC_OK;
@@ -880,11 +881,13 @@ extern "C" int cagc_get_tuning(const char* key, int* value) {
   else if (!strcmp(key, "s2w_planar")) *value = cagc::s2w_tuning_planar();
   else if (!strcmp(key, "s2w_launches")) *value = cagc::s2w_launch_count();
   else if (!strcmp(key, "up4_error")) *value = cagc::up4_error_word();
+  else if (!strcmp(key, "streamk_error_nosync")) *value = cagc::up4_error_word_nosync();
   else if (!strcmp(key, "up4_launches")) *value = cagc::up4_launch_count();
   else if (!strcmp(key, "deterministic")) *value = cagc::deterministic_mode();
   else if (!strcmp(key, "wgrad_rd")) *value = wm;
   else if (!strcmp(key, "wgrad_rd_wgs")) *value = wt;
   else if (!strcmp(key, "wino4_hv")) *value = cagc::wino4_hv_tuning();
+  else if (!strcmp(key, "clock_probe_family")) *value = cagc::clock_probe_family();
   else if (!strcmp(key, "wino4_min_wgs")) *value = cagc::wino4_min_wgs();
   else { cagc::set_error("cagc_get_tuning: unknown key '%s'", key); return CAGC_ERR_INVALID; }
   return CAGC_OK;

@@ -491,7 +491,7 @@ int run_conv_s2w(const ConvArgs& a, int planar, hipStream_t st, const char* what
   r.B = a.B; r.K = a.Cin; r.KQ = KQ; r.Cout = a.Cout;
   r.Hin = a.Hin; r.Win = a.Win; r.Wpitch = a.Wpitch; r.Hout = a.Hout; r.Wout = a.Wout; r.TR = TR; r.Tq = Tq;
   sk_plan(r.sk, ttiles, mt, G, KQ, tune.lmin);
-  r.clk = clock_probe_ptr();
+  r.clk = clock_probe_ptr_other();
   const size_t slab_bytes = r.sk.r > 0 ? (size_t)G * 4 * 9 * nch * 1024 : 0;
   // scratch: [slabs][4 KB of flags][transformed weights] — the weights are transformed per launch from the packed operand's plain layout
   float* scratch = ksplit_scratch(slab_bytes + 4096 + (size_t)up_elems * 4, st, what);

@@ -86,7 +86,7 @@ __device__ __forceinline__ void sk_wait(int* flags, const int first, const int n
       int spins = 0;
       while (__hip_atomic_load(flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         __builtin_amdgcn_s_sleep(32);
-        if (++spins > SK_SPIN_MAX) { atomicExch(err, 1); break; }
+        if (++spins > SK_SPIN_MAX) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

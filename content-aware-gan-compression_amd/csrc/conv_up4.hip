@@ -24,6 +24,7 @@
 // (bit-reproducible: no atomics, fixed order) and runs the epilogue.  Contributors never wait before publishing, so the
 // protocol needs no co-residency guarantee beyond "every workgroup is eventually scheduled"; every spin is bounded.
 #include "common.h"
+#include <mutex>
 #include "prep_device.h"
 #include "conv_plan.h"
 #include "conv_up4.h"
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256, NB == 4 ? 1 : 2) void k_conv_up4(const Up4Args
           int spins = 0;
           while (__hip_atomic_load(A.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             __builtin_amdgcn_s_sleep(32);
-            if (++spins > UP4_SPIN_MAX) { atomicExch(A.err, 1); break; }
+            if (++spins > UP4_SPIN_MAX) { __hip_atomic_store(A.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -398,26 +399,46 @@ int& up4_tuning_lmin() { return up4_tuning().lmin; }
 int& up4_tuning_rotate() { return up4_tuning().rotate; }
 int& up4_tuning_nb() { return up4_tuning().nb; }
 
-static int* up4_err_word() {
+// The stream-K error words: ONE int per device in pinned, mapped, coherent HOST memory (portable: every device of the process can write
+// its own word).  A bounded spin that gives up stores 1 at system scope, so the host reads the word with a plain load — no device
+// synchronisation, no API call on the step's path (cagc_get_tuning("streamk_error_nosync"): cagc/kd.py polls it every step and raises;
+// round 5 kept the word in device memory, where only smoke() and scripts/soak.py ever read it).
+static int* up4_err_base() {
   static int* p = nullptr;
-  if (!p) {
+  static std::once_flag once;
+  std::call_once(once, [] {
     hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
     (void)hipThreadExchangeStreamCaptureMode(&mode);
-    if (hipMalloc(reinterpret_cast<void**>(&p), 16) == hipSuccess) (void)hipMemset(p, 0, 16); else p = nullptr;
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64 * sizeof(int), hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) == hipSuccess) {
+      memset(h, 0, 64 * sizeof(int));
+      p = static_cast<int*>(h);
+    } else {
+      (void)hipGetLastError();
+    }
     (void)hipThreadExchangeStreamCaptureMode(&mode);
-  }
+  });
   return p;
+}
+static int* up4_err_word() {
+  int* p = up4_err_base();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return p ? p + (dev >= 0 && dev < 64 ? dev : 0) : nullptr;
 }
 
 int* up4_err_word_ptr() { return up4_err_word(); }
 static std::atomic<int> g_up4_launches{0};
 int up4_launch_count() { return g_up4_launches; }
 
-int up4_error_word() {      // 1 after a bounded spin gave up (a contributor never published): the outputs of that launch are garbage
+int up4_error_word_nosync() {      // the current device's word as the host sees it NOW (launches still running may yet set it)
   int* p = up4_err_word();
-  int v = 0;
-  if (p && hipMemcpy(&v, p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
-  return v;
+  return p ? __atomic_load_n(p, __ATOMIC_RELAXED) : -1;
+}
+
+int up4_error_word() {      // 1 after a bounded spin gave up (a contributor never published): the outputs of that launch are garbage
+  if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return up4_error_word_nosync();
 }
 
 int run_conv_up4(const ConvArgs& a, int mode, hipStream_t st, const char* what) {
@@ -487,7 +508,7 @@ int run_conv_up4(const ConvArgs& a, int mode, hipStream_t st, const char* what) 
   r.q = ptiles / per;
   r.r = (ptiles - r.q * per) * mt;
   r.skL = 0; r.skJ = 0;
-  r.clk = clock_probe_ptr();
+  r.clk = clock_probe_ptr_other();
   r.rotate = tune.rotate;
   if (r.r > 0 || (r.q > 0 && r.rotate > 1)) {
     const int64_t total = (int64_t)r.r * r.KQ;

@@ -73,7 +73,8 @@ const char* cagc_last_error(void);
  * differ by ~1e-5 of the output scale).  Keys: "rd" (0 = LDS-staged kernel only), "rd_min_wgs", "rd_mb", "rd_kw",
  * "rd_split", "rd_atomic_below", "rd_split_wgs", "rd_min_wgs_long" (-1 = derived from rd_min_wgs at plan time; setting one key never rewrites another), "rd_s2v" (0 = the stride-2 forward's big launches on the general kernel) — see csrc/conv_rd.hip;
  * "up4" (0 = the transposed convs / stride-2 data gradients stay on conv_rd.hip's per-parity launches), "up4_min_ksteps", "up4_nb", "up4_lmin", "up4_rotate" (launch shape of the
- * persistent stream-K kernel) and the read-only "up4_error" (1 after a bounded stream-K spin of any of these kernels gave up; reading it synchronises the device) and "up4_launches" — csrc/conv_up4.hip;
+ * persistent stream-K kernel) the read-only "up4_error" (1 after a bounded stream-K spin of any of these kernels gave up: that launch's outputs are garbage; per device, in host-mapped memory; reading it synchronises the device),
+ * "streamk_error_nosync" (the same word read WITHOUT synchronising: a plain host load, cheap enough for every training step — cagc/kd.py polls it and raises) and "up4_launches" — csrc/conv_up4.hip;
  * "up25" (0 = no Winograd-domain transposed conv: cagc_modconv_up_fwd / cagc_conv3x3s2_dgrad fall to "up4" / conv_rd.hip), "up25_min_ksteps", "up25_lmin", read-only "up25_launches" — csrc/conv_up25.hip;
  * "s2w" (0 = cagc_conv3x3s2_fwd / _act_fwd / cagc_modconv_up_dgrad stay on conv_rd.hip), "s2w_planar" (0 = only cagc_modconv_up_dgrad stays there), "s2w_min_ksteps", "s2w_lmin", read-only "s2w_launches" — csrc/conv_s2w.hip (both differ from the direct kernels by fp32 rounding only: transforms with coefficients 0 / +-1); "wgrad_rd" (0 = LDS-staged weight-gradient kernels
  * only), "wgrad_rd_wgs" (workgroups a weight-gradient launch aims at; 0 = its launch model picks the K split, the default) — csrc/conv_wgrad_rd.hip; "wino4_hv" (0 per launch, 1 / 2: 64- / 128-channel workgroup shape of the F(4x4) kernel),

@@ -264,6 +264,60 @@ def gold_generator():
 
 
 # ----------------------------------------------------------------------------------------------
+# 4b. tiny Generator with the REAL latent width (style_dim = 512, model.py:137-171,421-430): the fixture that reaches the product's
+#     one-launch mapping / modulation kernels (csrc/mapping.hip, modbank.hip serve in_dim % 512 == 0 only).  The weights come from
+#     the seeded recipe oracle/ref_model.regenerate_generator_state_dict (the mapping network alone is 2 MB); large gradients are
+#     stored as (sum, abs-sum) + a strided sample.
+# ----------------------------------------------------------------------------------------------
+G512 = dict(size=32, style_dim=512, n_mlp=2, shape=[8, 8, 6, 6, 4, 4, 3, 3], seed=210, sample_stride=97, full_below=4097)
+
+
+def sampled(t, cfg=G512):
+    """what the fixture keeps of a tensor: everything when small, else a strided sample (+ checksums stored beside it)"""
+    flat = t.detach().reshape(-1)
+    return flat if flat.numel() < cfg["full_below"] else flat[::cfg["sample_stride"]].clone()
+
+
+def gold_generator512():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle.ref_model import regenerate_generator_state_dict
+    torch.manual_seed(G512["seed"])
+    gnet = ref_model.Generator(G512["size"], G512["style_dim"], G512["n_mlp"], generator_net_shape=G512["shape"])
+    keys = [[k, list(v.shape)] for k, v in gnet.state_dict().items()]
+    missing, unexpected = gnet.load_state_dict(regenerate_generator_state_dict(keys, G512["seed"]), strict=False)
+    assert not unexpected and all(k.endswith("kernel") for k in missing), (missing, unexpected)
+    sd = gnet.state_dict()
+    with open(os.path.join(OUT, "generator512_keys.json"), "w") as f:
+        json.dump(dict(config=G512, keys=keys, n_latent=gnet.n_latent, num_layers=gnet.num_layers), f, indent=1)
+    out = {"sd_checksum": np.array([float(v.double().sum()) for v in sd.values()]),
+           "sd_abs_checksum": np.array([float(v.double().abs().sum()) for v in sd.values()])}
+    gtor = torch.Generator().manual_seed(G512["seed"] + 1)
+    B = 2
+    z0 = torch.randn(B, G512["style_dim"], generator=gtor)
+    z1 = torch.randn(B, G512["style_dim"], generator=gtor)
+    out["z0"], out["z1"] = z0, z1
+    # (a) mapping network alone, rgb list + style scalars
+    out["a_w0"] = gnet.get_latent(z0)
+    rgbs, styles = gnet([z0], randomize_noise=False, return_rgb_list=True, return_style_scalars=True)
+    for i, r in enumerate(rgbs):
+        out[f"a_rgb{i}"] = r
+    for i, s_ in enumerate(styles):
+        out[f"a_style{i}"] = s_
+    out["a_n_styles"] = np.int64(len(styles))
+    # (b) style mixing at inject_index = 3, every parameter gradient of L = |img|.mean()
+    gnet.zero_grad()
+    img = gnet([z0, z1], inject_index=3, randomize_noise=False)
+    loss = img.abs().mean()
+    loss.backward()
+    out["b_img"], out["b_loss"] = img, loss
+    for n, p in gnet.named_parameters():
+        gr = p.grad if p.grad is not None else torch.zeros_like(p)
+        out["b_grad/" + n] = sampled(gr)
+        out["b_gsum/" + n] = np.array([float(gr.double().sum()), float(gr.double().abs().sum()), float(gr.abs().max())])
+    save("generator512", **out)
+
+
+# ----------------------------------------------------------------------------------------------
 # 5. KD generator step  (train.py:280-308 via AST-lifted functions)
 # ----------------------------------------------------------------------------------------------
 def lift_train_functions(names, namespace):
@@ -839,7 +893,7 @@ def _get_masked_tensor_any_dtype(img_tensor, batch_parsing, device, mask_grad=Fa
 
 if __name__ == "__main__":
     # float64 / kd_modes READ kd_step_tiny.npz and the other fixtures: they come last so that a from-scratch regeneration works in one go
-    which = sys.argv[1:] or ["fused_act", "upfirdn2d", "modconv", "generator", "kd_step", "discriminator", "contract", "train_iter", "saliency", "content_mask", "float64", "kd_modes"]
+    which = sys.argv[1:] or ["fused_act", "upfirdn2d", "modconv", "generator", "generator512", "kd_step", "discriminator", "contract", "train_iter", "saliency", "content_mask", "float64", "kd_modes"]
     for w in which:
         print("==", w)
         globals()["gold_" + w]()

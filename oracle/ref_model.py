@@ -156,3 +156,28 @@ def regenerate_state_dict(keys_shapes, seed):
         else:
             sd[key] = torch.zeros(*shape)
     return sd
+
+
+def regenerate_generator_state_dict(keys_shapes, seed, lr_mlp=0.01):
+    """A seeded recipe for a Generator's parameters and noise buffers, walking the keys in registration order (FIR `kernel`
+    buffers are skipped: the constructor builds them, and the fixture's checksums pin them).  Used for the style_dim = 512 tiny
+    generator (`tests/golden/generator512*`): its mapping network alone is 2 MB, too large to commit, so gen_golden.py loads THIS
+    recipe into the reference's Generator and the tests load it into the product's / hand it to the oracle.  Values: mapping
+    weights ~ N(0,1) / lr_mlp (as EqualLinear initialises them, reference model.py:143), modulation bias 1 + 0.1 N, noise weights
+    0.1 + 0.05 N (the reference's zero init would hide the noise path), other biases 0.1 N, everything else N(0,1)."""
+    g = torch.Generator().manual_seed(int(seed))
+    sd = {}
+    for key, shape in keys_shapes:
+        if key.endswith("kernel"):
+            continue
+        t = torch.randn(*shape, generator=g)
+        if key.endswith("modulation.bias"):
+            t = 1.0 + 0.1 * t
+        elif key.endswith("noise.weight"):
+            t = 0.1 + 0.05 * t
+        elif key.startswith("style.") and key.endswith("weight"):
+            t = t / lr_mlp
+        elif key.endswith("bias"):
+            t = 0.1 * t
+        sd[key] = t
+    return sd

@@ -21,6 +21,25 @@ def sub(d, prefix):
     return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
 
 
+def sampled(t, cfg):
+    """what tests/golden/generator512.npz keeps of a tensor (oracle/gen_golden.py `sampled`): all of it when small, else a strided sample"""
+    flat = t.detach().reshape(-1)
+    return flat if flat.numel() < cfg["full_below"] else flat[::cfg["sample_stride"]]
+
+
+def assert_grad_matches_sample(gr, sample, sums, cfg, tol, what):
+    """a gradient against its fixture entry: the kept elements at `tol` of the gradient's max, and — for tensors kept only as a
+    sample — the (sum, abs-sum) checksums at 10 x tol of the abs-sum (a sum of n rounded terms)"""
+    gmax = float(sums[2])
+    got = sampled(gr, cfg).double().cpu()
+    err = (got - sample.double()).abs().max().item() / (gmax if gmax > 0 else 1.0)
+    assert err <= tol, f"{what}: sampled rel err {err:.3e} > {tol:.1e}"
+    if gr.numel() >= cfg["full_below"] and float(sums[1]) > 0:
+        e_sum = abs(float(gr.double().sum()) - float(sums[0])) / float(sums[1])
+        e_abs = abs(float(gr.double().abs().sum()) - float(sums[1])) / float(sums[1])
+        assert max(e_sum, e_abs) <= 10 * tol, f"{what}: checksum rel err {max(e_sum, e_abs):.3e}"
+
+
 def rel_err(a, b):
     """max|a-b| / max|b| — the parity metric of SURVEY.md §8(d)."""
     a = a.detach().double().cpu()

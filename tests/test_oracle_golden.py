@@ -4,7 +4,7 @@ op order differs); the parity gate for the HIP path is 1e-3 (BASELINE.json north
 import torch
 
 from oracle import ref_kd, ref_model, ref_ops
-from _util import assert_close, load_json, load_npz, sub
+from _util import assert_close, assert_grad_matches_sample, load_json, load_npz, sub
 
 TOL = 1e-5
 
@@ -100,6 +100,32 @@ def test_generator_mixing_truncation_noise():
     n_layers = load_json("generator_tiny_keys")["num_layers"]
     noise = [g[f"e_noise{i}"] for i in range(n_layers)]
     assert_close(ref_model.generator_forward_ref(sd, [g["z0"]], noise=noise), g["e_img"], TOL, "explicit noise")
+
+
+def test_generator512_mapping_modulation_at_the_real_latent_width():
+    """style_dim = 512 (reference model.py:137-171,421-430): weights from the seeded recipe the fixture was generated with."""
+    g = load_npz("generator512")
+    meta = load_json("generator512_keys")
+    cfg = meta["config"]
+    sd = ref_model.regenerate_generator_state_dict(meta["keys"], cfg["seed"])
+    chk = {k: i for i, (k, _) in enumerate(meta["keys"])}
+    for k, v in sd.items():      # the recipe reproduces what gen_golden.py loaded into the reference
+        assert abs(float(v.double().sum()) - float(g["sd_checksum"][chk[k]])) <= 1e-6 * max(1.0, float(g["sd_abs_checksum"][chk[k]])), k
+    assert_close(ref_model.mapping_ref(sd, g["z0"]), g["a_w0"], TOL, "mapping")
+    rgbs, scal = ref_model.generator_forward_ref(sd, [g["z0"]], randomize_noise=False, return_rgb_list=True, return_style_scalars=True)
+    assert len(scal) == g["a_n_styles"]
+    for i, r in enumerate(rgbs):
+        assert_close(r, g[f"a_rgb{i}"], TOL, f"rgb{i}")
+    for i, s_ in enumerate(scal):
+        assert_close(s_, g[f"a_style{i}"], TOL, f"style{i}")
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    img = ref_model.generator_forward_ref(leaves, [g["z0"], g["z1"]], inject_index=3, randomize_noise=False)
+    assert_close(img, g["b_img"], TOL, "mixing image")
+    names = list(sub(g, "b_grad/"))
+    grads = torch.autograd.grad(img.abs().mean(), [leaves[k] for k in names], allow_unused=True)
+    for k, gr in zip(names, grads):
+        gr = torch.zeros_like(leaves[k]) if gr is None else gr
+        assert_grad_matches_sample(gr, g["b_grad/" + k], g["b_gsum/" + k], cfg, 5e-5, "grad " + k)
 
 
 def test_generator_path_length_double_backward():
