@@ -528,6 +528,32 @@ def main():
     ms = dt / args.steps * 1e3
     value = bs * world * args.steps / dt
 
+    # The gradient all-reduce by itself (N > 1): every bucket of the flat gradient reduced on its own, HIP events on the collective's stream,
+    # median of 5 — what the step's timeline has to hide (scripts/scale.sh prints it next to the step time).
+    bucket_ms = bucket_bytes = None
+    if world > 1:
+        flat = getattr(step, "flat_grad", None)
+        spans = [(lo, hi) for lo, hi, _, _ in getattr(step, "_buckets", [])] if flat is not None else []
+        if flat is None:      # eager DDP: one flat buffer of the gradient's size, cut like DDP's 4 MB buckets
+            flat = torch.zeros(n_params, device=dev)
+            per = (4 << 20) // 4
+            spans = [(i, min(i + per, n_params)) for i in range(0, n_params, per)]
+        probe = flat.clone()
+        bucket_ms, bucket_bytes = [], []
+        for lo, hi in spans:
+            ts = []
+            for _ in range(6):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                cd.barrier()
+                e0.record()
+                dist.all_reduce(probe[lo:hi])
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            bucket_ms.append(round(sorted(ts[1:])[2], 4))
+            bucket_bytes.append(4 * (hi - lo))
+        del probe
+
     roof = None
     if not args.no_roofline:
         # per-kernel HIP-event timing needs individual launches: same models, eager launches (no graph), no DDP
@@ -832,7 +858,11 @@ def main():
                           # graph mode: "graph" = bucketed RCCL all-reduces captured inside the one step graph, launched from the backward
                           # as each gradient bucket completes; "host" = one flat all-reduce between two graphs (fallback); eager: DDP buckets
                           "grad_collective": (getattr(step, "comm", None) if mode == "graph" else "ddp_buckets") if world > 1 else None,
-                          "grad_buckets": len(getattr(step, "_buckets", [])) if (mode == "graph" and world > 1) else None},
+                          "grad_collective_reason": getattr(step, "comm_reason", None) if (mode == "graph" and world > 1) else None,
+                          "grad_buckets": len(getattr(step, "_buckets", [])) if (mode == "graph" and world > 1) else None,
+                          "grad_bucket_bytes": bucket_bytes, "grad_bucket_allreduce_ms": bucket_ms,
+                          "grad_allreduce_ms_sum": None if bucket_ms is None else round(sum(bucket_ms), 4),
+                          "strict_comm": os.environ.get("CAGC_STRICT_COMM", "0") == "1"},
                "roofline": roof, "cpu_baseline": cpu, "full_iteration": full, "saliency_sweep": sweep,
                "strong_scaling_proxy_1gpu": proxy, "deterministic_mode": det, "config3_1024": c3, "configs0_cpu_forward": c0}
         print(json.dumps(out))

@@ -37,6 +37,15 @@ def init_from_env(backend=None):
         torch.cuda.set_device(local)
     if os.environ.get("CAGC_SINGLE_DEVICE") == "1":
         local = 0
+        if world > 1 and torch.cuda.is_available():
+            # Several processes on ONE GPU: the persistent stream-K kernels (csrc/conv_streamk.h) launch one workgroup per CU and an
+            # owner polls for its contributors.  Two processes' persistent launches can each hold CUs while their contributors wait
+            # for the other's — the bounded spin then gives up and the launch writes garbage (round 6 found exactly that in
+            # tests/test_bench_multirank_gpu.py once the host-mapped error word was polled: cagc.op.modconv.check_streamk_error).
+            # One process per GPU — the product's configuration — cannot get there; this test mode takes the finer-grained kernels.
+            from . import _lib
+            for key in ("up25", "s2w", "up4"):
+                _lib.set_tuning(key, 0)
     return rank, world, local
 
 

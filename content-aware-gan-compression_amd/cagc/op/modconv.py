@@ -1086,18 +1086,25 @@ class _ToRGB(Function):
         B, C, H, W = x.shape
         g = gout.contiguous()
         scale = 1.0 / math.sqrt(C)
-        gx = torch.empty_like(x)
-        gws = torch.empty(B * 3 * (C + 1), dtype=x.dtype, device=x.device)     # [B,3,C] weight sums + [B,3] sums of g (bias gradient)
-        gweight = torch.empty(1, 3, C, 1, 1, dtype=x.dtype, device=x.device)
-        gs = torch.empty(B, C, dtype=x.dtype, device=x.device)
-        gbias = torch.empty(1, 3, 1, 1, dtype=x.dtype, device=x.device)
-        gskip = torch.empty(B, 3, H // 2, W // 2, dtype=x.dtype, device=x.device) if ctx.has_skip else None
-        side = None
+        side = main = None
+        tagged = False
         if ctx.slot >= 0:
             main = torch.cuda.current_stream(x.device)
             side = _fork_streams[(x.device.index, ctx.slot)]
-            if getattr(gout, "_cagc_on_stream", None) is not side:     # gout was produced on the caller's stream
+            tagged = getattr(gout, "_cagc_on_stream", None) is side      # gout was produced on the side stream by the next ToRGB's backward
+            if not tagged:
                 side.wait_stream(main)
+        # Results are allocated where they are FIRST WRITTEN.  Behind a fork event (un-tagged) the caller's pool is safe: whatever last
+        # used a recycled block ran on the caller's stream before the event.  The tagged node skips that event — a block recycled from
+        # the caller's pool may still be in use by a kernel queued there — so it allocates from the side stream's own pool and hands the
+        # results that the caller's stream consumes over with record_stream.
+        with (torch.cuda.stream(side) if tagged else _nullctx()):
+            gx = torch.empty_like(x)
+            gws = torch.empty(B * 3 * (C + 1), dtype=x.dtype, device=x.device)     # [B,3,C] weight sums + [B,3] sums of g (bias gradient)
+            gweight = torch.empty(1, 3, C, 1, 1, dtype=x.dtype, device=x.device)
+            gs = torch.empty(B, C, dtype=x.dtype, device=x.device)
+            gbias = torch.empty(1, 3, 1, 1, dtype=x.dtype, device=x.device)
+            gskip = torch.empty(B, 3, H // 2, W // 2, dtype=x.dtype, device=x.device) if ctx.has_skip else None
         partial = side is not None and ctx.private and ctx.has_skip
         with _lib.on_device(x):
             with (torch.cuda.stream(side) if side is not None else _nullctx()):
@@ -1116,9 +1123,13 @@ class _ToRGB(Function):
                 gskip._cagc_on_stream = side          # ... and the skip gradient stays on the side stream for the previous ToRGB
             else:
                 main.wait_stream(side)
-            for t_ in (g, x, w2, s, gx, gws, gweight, gs, gbias, gskip):
+            for t_ in (x, w2, s) + (() if tagged else (g, gx, gws, gweight, gs, gbias, gskip)):      # caller's pool, used on the side stream
                 if t_ is not None:
                     t_.record_stream(side)
+            if tagged:
+                for t_ in (gx, gweight, gs, gbias) + (() if partial else (gskip,)):      # side pool, consumed on the caller's stream
+                    if t_ is not None:
+                        t_.record_stream(main)
         return gx, gweight, gs, gbias, gskip, None, None, None
 
 

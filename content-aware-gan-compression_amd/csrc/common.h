@@ -63,6 +63,11 @@ int det_end(const DetSink& k, float* base, int64_t n, hipStream_t st, const char
 // library-owned scratch of the deterministic forward K split (api_common.hip): one buffer per (device, stream), grown by allocating a
 // new block and never freed (earlier launches / captured graphs may reference the old one); nullptr + error set on failure
 float* ksplit_scratch(size_t bytes, hipStream_t st, const char* what);
+// ordered reduce of ks output slabs + the deferred (styled) epilogue, un-pitched [B, C, HW] (conv_rd.hip k_ksplit_reduce)
+int launch_ksplit_reduce(float* out, const float* slab, int ks, int64_t out_elems, int styled, const float* d, const float* noise,
+                         int noise_bstride_on, const float* noise_w, const float* bias, int C, int HW, float alpha, float act_scale,
+                         hipStream_t st, const char* what);
+int wino4_ks_launch_count();      // conv_wino4.hip: K-split F(4x4) launches so far (cagc_get_tuning("wino4_ks_launches"))
 
 inline hipStream_t as_stream(cagc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

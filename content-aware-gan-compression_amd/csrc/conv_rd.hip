@@ -563,6 +563,15 @@ __global__ __launch_bounds__(256) void k_ksplit_reduce(float* __restrict__ out, 
   out[idx] = v;
 }
 
+// the same reduce for other kernels' K splits (conv_wino4.hip): un-pitched [B, C, HW] outputs
+int launch_ksplit_reduce(float* out, const float* slab, int ks, int64_t out_elems, int styled, const float* d, const float* noise,
+                         int noise_bstride_on, const float* noise_w, const float* bias, int C, int HW, float alpha, float act_scale,
+                         hipStream_t st, const char* what) {
+  hipLaunchKernelGGL(k_ksplit_reduce, dim3((unsigned)cdiv(out_elems, 256)), dim3(256), 0, st, out, slab, ks, out_elems, out_elems, HW, HW, styled, d,
+                     noise, noise_bstride_on, noise_w, bias, C, HW, alpha, act_scale);
+  return check_launch(what);
+}
+
 template <int MB, bool PAD, bool SCALE, bool GS>
 static int launch_rd3(const RdArgs& a, dim3 grid, hipStream_t st, const char* what) {
   const size_t smem = a.kw > 1 ? (size_t)4 * MB * NBW * 64 * 16 : 0;
@@ -846,6 +855,8 @@ extern "C" int cagc_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "wgrad_rd")) cagc::wgrad_rd_set_tuning(value, -1);
   else if (!strcmp(key, "wgrad_rd_wgs")) cagc::wgrad_rd_set_tuning(-1, value);
   else if (!strcmp(key, "wino4_hv")) cagc::wino4_hv_tuning() = value;
+  else if (!strcmp(key, "wino4_ks")) cagc::wino4_ks_tuning() = value;
+  else if (!strcmp(key, "streamk_error_test")) cagc::up4_error_word_set(value);
   else if (!strcmp(key, "clock_probe_family")) cagc::clock_probe_family() = value;
   else if (!strcmp(key, "wino4_min_wgs")) cagc::wino4_min_wgs() = value;
   else { cagc::set_error("cagc_set_tuning: unknown key '%s'", key); return CAGC_ERR_INVALID; }
@@ -881,12 +892,14 @@ extern "C" int cagc_get_tuning(const char* key, int* value) {
   else if (!strcmp(key, "s2w_planar")) *value = cagc::s2w_tuning_planar();
   else if (!strcmp(key, "s2w_launches")) *value = cagc::s2w_launch_count();
   else if (!strcmp(key, "up4_error")) *value = cagc::up4_error_word();
-  else if (!strcmp(key, "streamk_error_nosync")) *value = cagc::up4_error_word_nosync();
+  else if (!strcmp(key, "streamk_error_nosync") || !strcmp(key, "streamk_error_test")) *value = cagc::up4_error_word_nosync();
   else if (!strcmp(key, "up4_launches")) *value = cagc::up4_launch_count();
   else if (!strcmp(key, "deterministic")) *value = cagc::deterministic_mode();
   else if (!strcmp(key, "wgrad_rd")) *value = wm;
   else if (!strcmp(key, "wgrad_rd_wgs")) *value = wt;
   else if (!strcmp(key, "wino4_hv")) *value = cagc::wino4_hv_tuning();
+  else if (!strcmp(key, "wino4_ks")) *value = cagc::wino4_ks_tuning();
+  else if (!strcmp(key, "wino4_ks_launches")) *value = cagc::wino4_ks_launch_count();
   else if (!strcmp(key, "clock_probe_family")) *value = cagc::clock_probe_family();
   else if (!strcmp(key, "wino4_min_wgs")) *value = cagc::wino4_min_wgs();
   else { cagc::set_error("cagc_get_tuning: unknown key '%s'", key); return CAGC_ERR_INVALID; }

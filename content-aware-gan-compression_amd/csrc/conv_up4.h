@@ -14,6 +14,7 @@ int& up4_tuning_nb();          // cagc_set_tuning("up4_nb"), CAGC_UP4_NB: 4 (def
 int up4_error_word();          // cagc_get_tuning("up4_error"): 1 after a bounded stream-K spin gave up (synchronises the device)
 int up4_launch_count();        // cagc_get_tuning("up4_launches"): launches this process sent to the kernel (tests)
 int up4_error_word_nosync();   // cagc_get_tuning("streamk_error_nosync"): the same word read without synchronising (host-mapped memory)
+void up4_error_word_set(int v);  // cagc_set_tuning("streamk_error_test", v): overwrite the current device's word (tests; 0 clears it)
 int* up4_err_word_ptr();       // the library's device error word (shared with conv_up25.hip)
 // Winograd-domain variant (conv_up25.hip): 25 instead of 36 position-GEMMs per 2x2 tile of positions; same contract as run_conv_up4
 int run_conv_up25(const ConvArgs& a, int mode, hipStream_t st, const char* what);

@@ -436,6 +436,11 @@ int up4_error_word_nosync() {      // the current device's word as the host sees
   return p ? __atomic_load_n(p, __ATOMIC_RELAXED) : -1;
 }
 
+void up4_error_word_set(int v) {      // test hook (cagc_set_tuning("streamk_error_test")): what a bounded spin that gave up would leave behind
+  int* p = up4_err_word();
+  if (p) __atomic_store_n(p, v, __ATOMIC_RELAXED);
+}
+
 int up4_error_word() {      // 1 after a bounded spin gave up (a contributor never published): the outputs of that launch are garbage
   if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return -1; }
   return up4_error_word_nosync();

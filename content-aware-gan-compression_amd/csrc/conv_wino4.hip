@@ -30,6 +30,7 @@
 #include "conv_wino.h"
 #include <string.h>
 #include <stdlib.h>
+#include <atomic>
 
 namespace cagc {
 
@@ -58,7 +59,7 @@ __device__ __forceinline__ void w4_at6(const f32x2 m0, const f32x2 m1, const f32
 }
 
 // debug builds only (-DCAGC_W4_ABL=bits, wrong results, timing only): 1 no input transform, 2 no commit / prefetch, 4 no A loads,
-// 8 no B reads, 16 no chunk barrier, 32 no epilogue at all, 64 no output stores
+// 8 no B reads, 16 no chunk barrier, 32 no epilogue at all, 64 no output stores, 128 transform reads without LDS bank conflicts
 #ifdef CAGC_W4_ABL
 #define W4_ABL(bit) ((CAGC_W4_ABL & (bit)) != 0)
 #else
@@ -126,13 +127,15 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
   const int hb = HV == 2 ? wave >> 2 : 0, blk = wave & 3;
   const int lm = lane & 15, g = lane >> 4;
 
-  int pix_id, mtile;
+  int pix_id, mtile, ksi;
   {
     const int w = blockIdx.x, nx = A.nblocks, mt = A.mtiles;
-    const int total = nx * mt, per = total / 8;
+    const int total = nx * mt * A.ks, per = total / 8;
     const int s = w >> 3, xcd = w & 7;
     const int idx = (w < per * 8) ? xcd * per + s : w;
-    mtile = idx / nx; pix_id = idx - mtile * nx;
+    ksi = idx / (nx * mt);                      // K slice (0 when the launch does not split K)
+    const int rem = idx - ksi * nx * mt;
+    mtile = rem / nx; pix_id = rem - mtile * nx;
   }
   const int tx_i = pix_id % A.tiles_x;
   const int ty_i = (pix_id / A.tiles_x) % A.tiles_y;
@@ -140,8 +143,10 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
   const int x0 = tx_i * 32, y0 = ty_i * 8;
   const int m0 = mtile * 64 * HV;
   const int HW = A.H * A.W;
-  const int nch = A.Kp / CK;
+  const int j0 = ksi * A.nch_slice;                                   // this workgroup's chunks [j0, j1) (an even count)
+  const int j1 = min(j0 + A.nch_slice, A.Kp / CK);
   const int KQ = A.Kp / 4;
+  float* const outp = A.out + (int64_t)ksi * A.slab_stride;          // K slices write their partial outputs to their own slab
 
   // ---- raw-tile staging: CK x 10 rows x 10 float4 = 800 units over the workgroup's threads ----------------------------------
   constexpr unsigned OOR = 0x80000000u;
@@ -201,7 +206,9 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
   // both column stages in every lane: VALU issue, which is MFMA time)
   const int wt = tid & 255;
   const int t_h = __builtin_amdgcn_readfirstlane(wt >> 7), t_c = (wt >> 4) & 7, t_t = wt & 15;
-  const int t_src = t_c * W4_RPS + (4 * (t_t >> 3)) * W4_IWP + 3 + 4 * (t_t & 7);   // patch origin: row y0-1+4ty, col x0-1+4tx
+  // (timing-only ablation 128: a conflict-free read pattern — lane-linear pairs — instead of the patch origin, which puts a wave's 64 lanes
+  //  on 8 of the 32 LDS banks (16 tiles at a 4-float pitch x 4 channels at a 400-float pitch): what the transform reads' bank conflicts cost)
+  const int t_src = W4_ABL(128) ? 2 * lane : t_c * W4_RPS + (4 * (t_t >> 3)) * W4_IWP + 3 + 4 * (t_t & 7);   // patch origin: row y0-1+4ty, col x0-1+4tx
   const int t_dst = t_c * W4_CS + t_t * W4_PS + 18 * t_h;                            // V[c][tile][slot(3h + i, .)]
   const f32x2 c4 = {4.f, 4.f}, cm5 = {-5.f, -5.f}, cm4m1 = {-4.f, -1.f}, c2m2 = {2.f, -2.f}, c22 = {2.f, 2.f};
   // The transform of one chunk, in six stages (read a column pair / column stage of the previous pair / row stages).  Measured in
@@ -289,18 +296,18 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
   // ---- pipeline --------------------------------------------------------------------------------------------------------------
   // (issuing the A ring's first loads in front of the raw tile's, so that their L2 latency runs under the first prefetch / commit /
   // transform, was measured in round 4: +-0.5 % on all four discriminator shapes — the prologue is not load-latency bound)
-  prefetch(0);
+  prefetch(j0);
   commit(raw);
-  prefetch(1);
+  prefetch(j0 + 1);
   __syncthreads();
   if (hb == 0) {
 #pragma unroll
     for (int st = 0; st < 6; ++st) xf_stage(st, 4 * 2 * W4_VSZ, 0);
   }
   commit(raw + W4_RSZ);
-  prefetch(2);
+  prefetch(j0 + 2);
 #pragma unroll
-  for (int gi = 0; gi < RING; ++gi) load_a(gi, gi, 0);
+  for (int gi = 0; gi < RING; ++gi) load_a(gi, gi, j0);
   __syncthreads();
 
   // B operand of this wave: V[4s + g][lm][4q .. 4q+3], one 16-byte read per group, two groups ahead; the group's part of the
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
     const int vnext = 4 * (cur ^ 1) * W4_VSZ;                       // byte offsets in LDS
     const int rnext = 4 * (2 * W4_VSZ + (cur ^ 1) * W4_RSZ);        // chunk j+1, transformed during this chunk by the waves of half (j+1)&1
     const bool xf = HV == 1 || hb == 0;                 // uniform per wave: the OLDER wave of each SIMD transforms every chunk (kernel header)
-    const int jn = (j + 1 < nch) ? j + 1 : j;           // last chunk: re-read valid weights instead of branching
+    const int jn = (j + 1 < j1) ? j + 1 : j;            // last chunk: re-read valid weights instead of branching
 #pragma unroll
     for (int gi = 0; gi < 18; ++gi) {
       const int q = gi >> 1, slot = gi % RING;
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
   tlast = clock64();
   tr[6] = tlast - t_entry;
 #endif
-  for (int j = 0; j < nch; j += 2) {     // Kp is a multiple of 16: an even number of chunks
+  for (int j = j0; j < j1; j += 2) {     // Kp is a multiple of 16 and slices hold an even number of chunks
     chunk(j, 0);
     chunk(j + 1, 1);
   }
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(256 * HV, HV == 1 ? 2 : 1) void k_wino4(const WinoA
             o.x = (o.x > 0.f ? o.x : o.x * A.alpha) * A.act_scale; o.y = (o.y > 0.f ? o.y : o.y * A.alpha) * A.act_scale;
             o.z = (o.z > 0.f ? o.z : o.z * A.alpha) * A.act_scale; o.w = (o.w > 0.f ? o.w : o.w * A.alpha) * A.act_scale;
           }
-          *reinterpret_cast<float4*>(A.out + off) = o;
+          *reinterpret_cast<float4*>(outp + off) = o;
         }
       }
     }
@@ -458,6 +465,13 @@ int& wino4_min_wgs() {
   return v;
 }
 
+int& wino4_ks_tuning() {
+  static int v = getenv("CAGC_WINO4_KS") ? atoi(getenv("CAGC_WINO4_KS")) : 0;
+  return v;
+}
+static std::atomic<int> g_w4_ks_launches{0};
+int wino4_ks_launch_count() { return g_w4_ks_launches; }
+
 // workgroup shape: 0 = per launch (below), 1 / 2 = forced (cagc_set_tuning("wino4_hv"), CAGC_WINO4_HV; 2 only where Cout % 128 == 0)
 int& wino4_hv_tuning() {
   static int v = getenv("CAGC_WINO4_HV") ? atoi(getenv("CAGC_WINO4_HV")) : 0;
@@ -476,7 +490,7 @@ static int launch_wino4(const WinoArgs& a, size_t smem, hipStream_t st, const ch
     CAGC_REQUIRE(e == hipSuccess, "%s: cannot reserve %zu bytes of LDS: %s", what, smem, hipGetErrorString(e));
     attr[dev] = true;
   }
-  hipLaunchKernelGGL((k_wino4<GATED, SCALE, HV>), dim3((unsigned)(a.nblocks * a.mtiles)), dim3(256 * HV), smem, st, a);
+  hipLaunchKernelGGL((k_wino4<GATED, SCALE, HV>), dim3((unsigned)(a.nblocks * a.mtiles * a.ks)), dim3(256 * HV), smem, st, a);
   return check_launch(what);
 }
 
@@ -496,18 +510,39 @@ int run_wino4(WinoArgs& a, bool gated, hipStream_t st, const char* what) {
     hv = t1 < t2 ? 1 : 2;
     if (wino4_hv_tuning() == 1 || wino4_hv_tuning() == 2) hv = wino4_hv_tuning();
   }
+  // K slices for under-filled launches (prep_device.h wino4_ksplit): 8-wave workgroups, partial outputs to a slab, ordered reduce below
+  a.ks = 1; a.nch_slice = a.Kp / W4_CK; a.slab_stride = 0;
+  int ks = wino4_ksplit(a.Cin, a.Cout, a.B, a.H, a.W);
+  if (a.residual || (a.epi == CAGC_EPI_LINEAR && a.out_scale)) ks = 1;      // epilogues the shared reduce does not carry (never on the split shapes)
+  while (ks > 1 && (ks - 1) * round_up(cdiv(a.Kp / W4_CK, ks), 2) >= a.Kp / W4_CK) ks >>= 1;      // every slice starts inside the K range
+  const int64_t out_elems = (int64_t)a.B * a.Cout * a.H * a.W;
+  WinoArgs full = a;
+  if (ks > 1) {
+    float* slab = ksplit_scratch(sizeof(float) * (size_t)ks * out_elems, st, what);
+    if (!slab) return CAGC_ERR_LAUNCH;
+    hv = 2;
+    a.ks = ks; a.nch_slice = round_up(cdiv(a.Kp / W4_CK, ks), 2); a.slab_stride = out_elems;
+    a.out = slab; a.epi = CAGC_EPI_LINEAR; a.out_scale = nullptr; a.noise = nullptr; a.noise_w = nullptr; a.bias = nullptr;
+    ++g_w4_ks_launches;
+  }
   a.mtiles = cdiv(a.Cout, 64 * hv);
-  CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles < (1ll << 31), "%s: grid too large", what);
+  CAGC_REQUIRE((int64_t)a.nblocks * a.mtiles * a.ks < (1ll << 31), "%s: grid too large", what);
   CAGC_REQUIRE((int64_t)36 * a.Kp * 64 * 4 * cdiv(a.Cout, 64) < (1ll << 31), "%s: packed weights too large for 32-bit offsets", what);
   const size_t smem = sizeof(float) * (size_t)(2 * W4_VSZ + 2 * W4_RSZ);     // 62.5 KB; the output transform needs no LDS
   const bool sc = a.in_scale != nullptr;
   CAGC_REQUIRE(!(gated && sc), "%s: the gated data gradient takes no input scale", what);   // (never instantiated: its 64-channel shape would spill)
+  int rc;
   if (hv == 2) {
-    if (gated) return launch_wino4<true, false, 2>(a, smem, st, what);
-    return sc ? launch_wino4<false, true, 2>(a, smem, st, what) : launch_wino4<false, false, 2>(a, smem, st, what);
+    if (gated) rc = launch_wino4<true, false, 2>(a, smem, st, what);
+    else rc = sc ? launch_wino4<false, true, 2>(a, smem, st, what) : launch_wino4<false, false, 2>(a, smem, st, what);
+  } else {
+    if (gated) rc = launch_wino4<true, false, 1>(a, smem, st, what);
+    else rc = sc ? launch_wino4<false, true, 1>(a, smem, st, what) : launch_wino4<false, false, 1>(a, smem, st, what);
   }
-  if (gated) return launch_wino4<true, false, 1>(a, smem, st, what);
-  return sc ? launch_wino4<false, true, 1>(a, smem, st, what) : launch_wino4<false, false, 1>(a, smem, st, what);
+  if (rc || a.ks == 1) return rc;
+  const int styled = full.epi == CAGC_EPI_STYLED ? 1 : 0;
+  return launch_ksplit_reduce(full.out, a.out, a.ks, out_elems, styled, styled ? full.out_scale : nullptr, full.noise, full.noise_bstride_on,
+                              full.noise_w, full.bias, full.Cout, full.H * full.W, full.alpha, full.act_scale, st, what);
 }
 
 #ifdef CAGC_W4_TRACE

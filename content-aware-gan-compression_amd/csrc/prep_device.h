@@ -129,6 +129,27 @@ inline int64_t wino4_packed_elems(int K, int M) { return (int64_t)cdiv(M, 64) * 
 // and resolution decide whether the F(4x4) grid — 64 channels x 8x32 pixels per workgroup, K un-split — fills the chip; the
 // F(2x2) kernel has finer tiles for under-filled launches: per-GPU batch 2 / 4, 32^2 layers).
 int& wino4_min_wgs();      // conv_wino4.hip; cagc_set_tuning("wino4_min_wgs"), CAGC_WINO4_MIN_WGS (default 256)
+int& wino4_ks_tuning();    // conv_wino4.hip; cagc_set_tuning("wino4_ks"), CAGC_WINO4_KS
+// K slices of an UNDER-FILLED F(4x4) launch (round 6; per-GPU batch 2 / 4 / 8 of a multi-GPU run).  A launch that takes F(4x4) by the rule
+// below (>= wino4_min_wgs 64-channel workgroups) but has fewer than 256 128-channel workgroups used to run in the 64-channel shape with
+// ONE 4-wave workgroup per CU: one wave per SIMD, whose input transform then stops its own MFMAs (0.41 of the matrix pipe instead of 0.6).
+// Instead the K range is cut into `ks` slices of >= 64 channels, one 8-wave workgroup each: every slice writes its partial output (the
+// output transform is linear) to a library slab and conv_rd.hip's ordered reduce finishes it with the deferred epilogue — bit-reproducible,
+// no atomics.  512 -> 512 @64^2 at batch 2: 132 -> 116 us, @32^2 at batch 8: 131 -> 117 us (profiles/r06_time_wino_ks.log).
+// The F(4x4)-or-F(2x2) choice is NOT changed by it: moving the under-filled 32^2 layers of batch 2 / 4 from F(2x2) to a K-split F(4x4)
+// launch was measured too (56 -> 44 us, 90 -> 69 us) and not taken — it would change the rounding class (4e-7 -> 1e-5 of the output
+// scale) of exactly the D(32)-sized launches the fp32 goldens were captured on, for 0.04 - 0.06 ms per step.  1 = no split.
+inline int wino4_ksplit(int K, int M, int B, int H, int W) {
+  const int forced = wino4_ks_tuning();
+  if (forced == 1 || M % 128 != 0) return 1;
+  const int64_t w2 = (int64_t)B * (H / 8) * (W / 32) * (M / 128);
+  const int kmax = round_up(K, 16) / 64;                 // slices of at least 8 chunks
+  int ks = 1;
+  if (forced > 1) { while (ks * 2 <= forced && ks * 2 <= kmax) ks *= 2; return ks; }
+  if (w2 >= 256) return 1;
+  while (ks * 2 <= kmax && ks * 2 <= 8 && w2 * ks * 2 <= 256) ks *= 2;
+  return ks;
+}
 inline bool wino4_for_launch(int K, int M, int B, int H, int W) {
   return wino_use_f4(K, M) && (int64_t)B * (H / 8) * (W / 32) * cdiv(M, 64) >= wino4_min_wgs();
 }

@@ -14,22 +14,28 @@
  *   - plain C, no torch / ATen types: raw device pointers, sizes, a hipStream_t passed as void*.
  *   - all tensors are fp32, contiguous, NCHW unless stated ("planes" = N*C flattened); the two reference operators also
  *     exist in an any-dtype form (fp32 / fp16 / fp64: cagc_fused_bias_act_any, cagc_upfirdn2d_any).
- *   - OWNERSHIP: the caller allocates every output and workspace (PyTorch caching allocator) and
- *     passes data_ptr(); the library never frees or retains a caller's pointer.  TWO exceptions to "never
- *     allocates", both library-owned scratches kept per (device, stream), obtained with hipMalloc on first use (also
- *     under stream capture, relaxed mode), grown by allocating a new block and never freed before process exit
- *     (earlier launches / captured graphs may still reference the old one), in a mutex-guarded table:
- *       (a) every mode: the K-split slabs of FORWARD convolution launches (deterministic mode: of the data-gradient launches too) — a small layer whose reduction is cut across
- *           workgroups writes one partial-sum slab per slice and an ordered reduce adds them (bit-reproducible
- *           activations; no fp32 atomics in any forward pass); >= 4 MB, the largest split output x its slices
- *           (< 32 MB on this path; a launch that would need > 256 MB falls back to not splitting).  The same scratch holds the
-           partial-sum slabs (<= 128 MB + a 4 KB flag block) and the per-launch transformed weights (<= 16 MB) of the persistent
-           stream-K kernels behind cagc_modconv_up_fwd / cagc_conv3x3s2_dgrad (csrc/conv_up25.hip, conv_up4.hip) and
-           cagc_conv3x3s2_fwd / _act_fwd (csrc/conv_s2w.hip) on their large launches;  the LDS-staged fallback kernel (CAGC_RD=0, or tensors
-           beyond the register-direct kernels' 32-bit offsets) still splits a small forward layer's K with fp32 atomics in the
-           default mode — the "no fp32 atomics in a forward pass" statement holds for the kernels a launch takes by default;
+ *   - OWNERSHIP: the caller allocates every output and workspace (PyTorch caching allocator) and passes data_ptr();
+ *     the library never frees or retains a caller's pointer.  TWO exceptions to "never allocates", both library-owned
+ *     scratches kept per (device, stream), obtained with hipMalloc on first use (also under stream capture, relaxed
+ *     mode), grown by allocating a new block and never freed before process exit (earlier launches / captured graphs
+ *     may still reference the old one), in a mutex-guarded table:
+ *       (a) every mode: the K-split slabs of FORWARD convolution launches (deterministic mode: of the data-gradient
+ *           launches too).  A small layer whose reduction is cut across workgroups writes one partial-sum slab per
+ *           slice and an ordered reduce adds them: bit-reproducible activations, no fp32 atomics in any forward pass.
+ *           Size: >= 4 MB, the largest split output x its slices (< 32 MB on this path; a launch that would need >
+ *           256 MB falls back to not splitting).  Since round 6 the F(4x4) Winograd kernel's K slices
+ *           (csrc/conv_wino4.hip, under-filled launches at per-GPU batch 2-8) use the same slabs and the same reduce.
+ *           The same scratch holds the partial-sum slabs (<= 128 MB + a 4 KB flag block) and the per-launch
+ *           transformed weights (<= 16 MB) of the persistent stream-K kernels behind cagc_modconv_up_fwd /
+ *           cagc_conv3x3s2_dgrad (csrc/conv_up25.hip, conv_up4.hip) and cagc_conv3x3s2_fwd / _act_fwd
+ *           (csrc/conv_s2w.hip) on their large launches.  The LDS-staged fallback kernel (CAGC_RD=0, or tensors
+ *           beyond the register-direct kernels' 32-bit offsets) still splits a small forward layer's K with fp32
+ *           atomics in the default mode: the "no fp32 atomics in a forward pass" statement holds for the kernels a
+ *           launch takes by default;
  *       (b) deterministic mode (cagc_set_tuning("deterministic", 1) / CAGC_DETERMINISTIC=1): the order-independent
  *           reduction sink of the backward pass — 16 bytes per reduced element, < 1 MB on this path.
+ *     One more library-owned allocation, process-wide: 256 bytes of pinned, mapped host memory holding one stream-K
+ *     error word per device (csrc/conv_up4.hip; cagc_get_tuning("up4_error") / ("streamk_error_nosync")).
  *   - ERRORS: every function returns CAGC_OK (0) or a negative code; the message is available from
  *     cagc_last_error() (thread-local).  Nothing throws across the ABI.
  *   - THREADING: the data path is re-entrant — entry points may be called concurrently from several host threads
@@ -74,11 +80,14 @@ const char* cagc_last_error(void);
  * "rd_split", "rd_atomic_below", "rd_split_wgs", "rd_min_wgs_long" (-1 = derived from rd_min_wgs at plan time; setting one key never rewrites another), "rd_s2v" (0 = the stride-2 forward's big launches on the general kernel) — see csrc/conv_rd.hip;
  * "up4" (0 = the transposed convs / stride-2 data gradients stay on conv_rd.hip's per-parity launches), "up4_min_ksteps", "up4_nb", "up4_lmin", "up4_rotate" (launch shape of the
  * persistent stream-K kernel) the read-only "up4_error" (1 after a bounded stream-K spin of any of these kernels gave up: that launch's outputs are garbage; per device, in host-mapped memory; reading it synchronises the device),
- * "streamk_error_nosync" (the same word read WITHOUT synchronising: a plain host load, cheap enough for every training step — cagc/kd.py polls it and raises) and "up4_launches" — csrc/conv_up4.hip;
+ * "streamk_error_nosync" (the same word read WITHOUT synchronising: a plain host load, cheap enough for every training step — cagc/kd.py polls it and raises; write-only "streamk_error_test" overwrites the word, for tests) and "up4_launches" — csrc/conv_up4.hip;
  * "up25" (0 = no Winograd-domain transposed conv: cagc_modconv_up_fwd / cagc_conv3x3s2_dgrad fall to "up4" / conv_rd.hip), "up25_min_ksteps", "up25_lmin", read-only "up25_launches" — csrc/conv_up25.hip;
  * "s2w" (0 = cagc_conv3x3s2_fwd / _act_fwd / cagc_modconv_up_dgrad stay on conv_rd.hip), "s2w_planar" (0 = only cagc_modconv_up_dgrad stays there), "s2w_min_ksteps", "s2w_lmin", read-only "s2w_launches" — csrc/conv_s2w.hip (both differ from the direct kernels by fp32 rounding only: transforms with coefficients 0 / +-1); "wgrad_rd" (0 = LDS-staged weight-gradient kernels
  * only), "wgrad_rd_wgs" (workgroups a weight-gradient launch aims at; 0 = its launch model picks the K split, the default) — csrc/conv_wgrad_rd.hip; "wino4_hv" (0 per launch, 1 / 2: 64- / 128-channel workgroup shape of the F(4x4) kernel),
- * "wino4_min_wgs" (64-channel workgroups below which a launch takes the layer's F(2x2) packing; default 256) — csrc/conv_wino4.hip;
+ * "wino4_min_wgs" (64-channel workgroups below which a launch takes the layer's F(2x2) packing; default 256), "wino4_ks" (K slices of an under-filled F(4x4) launch: 0 = per launch — a launch
+ * with fewer than 256 128-channel workgroups cuts K into 2 / 4 / 8 slices of >= 64 channels, partial outputs through the forward slabs and the ordered reduce, and then stays on F(4x4) below
+ * "wino4_min_wgs" too; 1 = never; 2 / 4 / 8 = forced where legal), read-only "wino4_ks_launches" — csrc/conv_wino4.hip; "clock_probe_family" (0 = every probed kernel feeds cagc_set_clock_probe,
+ * 1 = only the F(4x4) Winograd kernel: the clock of the step's dominant kernel by itself);
  * "deterministic" (also CAGC_DETERMINISTIC=1): forward passes are bit-reproducible run to run in EVERY mode (K splits through
  * ordered slabs); this key additionally moves the data-gradient launches' K split from fp32 atomics to the same slabs and routes the backward
  * reductions (grad-bias / styled-epilogue / style / ToRGB weight sums, L1 loss) through an order-independent fixed-point sink on a

@@ -20,5 +20,6 @@ clk = torch.zeros(2, device="cuda")
 _lib.load().cagc_set_clock_probe(ctypes.c_void_p(clk.data_ptr()))
 for _ in range(5): run()
 torch.cuda.synchronize(); _lib.load().cagc_set_clock_probe(None)
+plan = _lib.query("cagc_wino_plan", B, C, C, H, H)
 print(f"shader clock under this kernel: {float(clk[0] / clk[1].clamp(min=1)):.0f} MHz")
-print(sys.argv[1:] or "default", (B, C, H), f"{dt*1e3:.3f} ms  direct-equiv {fl/dt/1e12:.1f} TF  mfma {fl*4/9/dt/1e12:.1f} TF")
+print(sys.argv[1:] or "default", (B, C, H), f"F({plan}x{plan}) ks_launches {_lib.get_tuning('wino4_ks_launches')}", f"{dt*1e3:.3f} ms  direct-equiv {fl/dt/1e12:.1f} TF  mfma {fl*4/9/dt/1e12:.1f} TF")

@@ -10,7 +10,9 @@ for rep in range(int(os.environ.get("REPS", 2))):
         for lib in sys.argv[1:]:
             env = dict(os.environ, B=str(B), C=str(C), H=str(H))
             out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_wino.py"), lib], env=env, capture_output=True, text=True).stdout
-            ms = float(out.split(") ")[-1].split(" ms")[0]) if " ms" in out else float("nan")
+            import re
+            m_ = re.search(r"([0-9.]+) ms  direct-equiv", out)
+            ms = float(m_.group(1)) if m_ else float("nan")
             mhz = int(out.split("this kernel: ")[1].split(" MHz")[0]) if "this kernel: " in out else 0
             res.setdefault((lib, (B, C, H)), []).append((ms, mhz))
 print("| library | " + " | ".join(f"B{B} C{C} H{H}" for (B, C, H) in shapes) + " |")

@@ -143,7 +143,24 @@ def test_discriminator_256_frozen_f4_forced_vs_float64(f4_everywhere):
     assert e_gx <= 5e-5, f"D(256) input gradient on the common gate pattern: {e_gx:.2e}"
 
 
-def test_kd_step_configs1_f4_forced_vs_float64(f4_everywhere):
+@pytest.fixture(params=["f4_forced", "default_launch_rules"])
+def launch_rules(request):
+    """f4_forced: every eligible layer on the F(4x4) kernel whatever the batch (the bench's bs-16 selection at B = 2);
+    default_launch_rules: the library's own choices at per-GPU batch 2 — F(4x4) with K slices on the 512-channel 64^2 layers
+    (round 6), F(2x2) on the under-filled 32^2 ones, register-direct kernels elsewhere — with NO tuning override."""
+    if request.param == "f4_forced":
+        with _lib.tuning(wino4_min_wgs=0):
+            if _lib.query("cagc_wino_plan", 16, 512, 512, 64, 64) != 4:
+                pytest.skip("F(4x4) Winograd is disabled in this process (CAGC_WINO_F4=0): nothing to force")
+            yield request.param
+    else:
+        yield request.param
+
+
+def test_kd_step_configs1_vs_float64(launch_rules):
+    """One whole KD generator step at the REAL configs[1] shapes (B = 2) against the float64 oracle: on the common gate pattern (tight
+    bars) and — last block — against the oracle on ITS OWN gates with nothing forced, every gradient at the north-star 1e-3."""
+    n_ks0 = _lib.get_tuning("wino4_ks_launches")
     student, teacher, disc = kd.build_synthetic_workload(256, "cpu", seed=0)
     B, inj = 2, 5
     torch.manual_seed(42)
@@ -202,7 +219,9 @@ def test_kd_step_configs1_f4_forced_vs_float64(f4_everywhere):
         e = _rel(grads[k], g64[k])
         if g64[k].numel() > 1 and e > worst:
             worst, worst_k = e, k
-    print(f"configs[1] KD step, F(4x4) forced, B = {B}: {n_dis} of {n_gates} gates disagree with float64; student image vs float64 "
+    if launch_rules == "default_launch_rules" and _lib.get_tuning("wino4_ks") == 0 and _lib.query("cagc_wino_plan", 16, 512, 512, 64, 64) == 4:
+        assert _lib.get_tuning("wino4_ks_launches") > n_ks0, "per-GPU batch 2: the 512-channel 64^2 layers did not take the K-split F(4x4) launch"
+    print(f"configs[1] KD step, {launch_rules}, B = {B}: {n_dis} of {n_gates} gates disagree with float64; student image vs float64 "
           f"{e_img_own:.2e} (common pattern {e_img:.2e}), teacher image {e_t:.2e}, worst student gradient {worst:.2e} ({worst_k}); "
           f"g_loss {float(g_loss.detach()):.6f} vs {float(gl64.detach()):.6f}, kd_l1 {float(kd_l1.detach()):.6f} vs {float(kl64.detach()):.6f}")
     assert e_img_own <= 1e-3 and e_t <= 1e-3, f"images vs float64: student {e_img_own:.2e}, teacher {e_t:.2e}"

@@ -118,3 +118,27 @@ def test_output_beyond_two_gigabytes_is_cut_into_batch_chunks():
     torch.cuda.synchronize()
     no_spin_timeout()
 
+
+
+def test_streamk_error_word_is_polled_by_the_training_step():
+    """a bounded stream-K spin that gives up used to leave a sticky DEVICE word nobody read on the step's path.  The word now
+    lives in host-mapped memory (per device); KDStep.g_step / GraphedKDStep.replay read it every step without synchronising and raise.
+    (tests/test_bench_multirank_gpu.py is where it fired for real: two processes' persistent kernels on one GPU.)"""
+    from cagc import kd
+    from cagc.op import modconv as mc
+    assert _lib.get_tuning("streamk_error_nosync") == 0 and _lib.get_tuning("up4_error") == 0
+    mc.check_streamk_error("cuda")
+    student, teacher, disc = kd.build_synthetic_workload(256, "cuda", seed=1)
+    step = kd.KDStep(student, teacher, disc)
+    mask = kd.ellipse_mask(2, 256, "cuda")
+    step.sample_and_step(2, mask)
+    try:
+        _lib.set_tuning("streamk_error_test", 1)
+        assert _lib.get_tuning("streamk_error_nosync") == 1
+        with pytest.raises(RuntimeError, match="stream-K"):
+            mc.check_streamk_error("cuda", sync=True)
+        with pytest.raises(RuntimeError, match="stream-K"):
+            step.sample_and_step(2, mask)
+    finally:
+        _lib.set_tuning("streamk_error_test", 0)
+    step.sample_and_step(2, mask)

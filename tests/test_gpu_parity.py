@@ -836,9 +836,31 @@ def _graph2_worker(rank, world, port, tmp):
     student, teacher, disc = _graph2_models(g, meta)
     d = _graph2_inputs(g, meta)
     sl = slice(rank, None, world)          # rank r takes samples r::2: keeps D's minibatch-stddev groups identical
+    # this rank's LOCAL gradient of the un-scaled loss, eagerly, on a copy of the student: the captured step's reduced flat gradient
+    # must be the MEAN of these over the ranks (the 1 / world_size lives only in the backward seed — nothing may scale twice)
+    import copy
+    probe = kd.KDStep(copy.deepcopy(student), teacher, disc, latent=24)
+    args = ([cu(z[sl]) for z in d["z"]], 3, cu(d["mask"][sl]), [cu(n[sl]) for n in d["sn"]], [cu(n[sl]) for n in d["tn"]])
+    kd.requires_grad(probe.student, True)
+    kd.requires_grad(disc, False)
+    total, _, _ = probe.g_total(*args)
+    total.backward()
+    local = {k: (p.grad if p.grad is not None else torch.zeros_like(p)).detach().clone() for k, p in probe.student.named_parameters()}
+    mean = {}
+    for k, v in local.items():
+        parts = [torch.empty_like(v) for _ in range(world)]
+        dist.all_gather(parts, v)
+        mean[k] = sum(parts) / world
     step = kd.GraphedKDStep(student, teacher, disc, 4, cu(d["mask"][sl]), random_noise=False, world_size=world, latent=24)
-    for _ in range(2):
-        step.g_step([cu(z[sl]) for z in d["z"]], 3, cu(d["mask"][sl]), [cu(n[sl]) for n in d["sn"]], [cu(n[sl]) for n in d["tn"]])
+    assert step.comm == "host" and "nccl" in step.comm_reason      # gloo: collectives are not capturable; the reason is recorded
+    for it in range(2):
+        step.g_step(*args)
+        if it == 0:
+            torch.cuda.synchronize()
+            names = {id(p): k for k, p in student.named_parameters()}
+            for p_, view in zip(step._params, step._grad_views):
+                k = names[id(p_)]
+                assert_close(view, mean[k], 5e-4 if view.numel() > 1 else 3e-3, f"rank {rank}: reduced flat gradient vs mean of local gradients: {k}")
     torch.cuda.synchronize()
     if rank == 0:
         torch.save({k: v.detach().cpu() for k, v in student.named_parameters()}, tmp)

@@ -112,3 +112,72 @@ def test_clock_probe_reports_the_shader_clock_and_leaves_results_alone():
     wgs = B * (H // 8) * (W // 32) * (C // 64)       # 64-channel workgroups (a 128-channel shape would be half as many): every 64th samples
     assert n in (3.0 * ((wgs + 63) // 64), 3.0 * ((wgs // 2 + 63) // 64)) and 500.0 < mhz < 3000.0, (n, mhz, wgs)
     assert torch.equal(out0, out1)
+
+
+# K split of under-filled launches (round 6, prep_device.h wino4_ksplit): K slices of >= 64 channels on 8-wave workgroups, partial
+# outputs through a library slab, conv_rd.hip's ordered reduce + the deferred styled epilogue.  (B, cin, cout, H, W, forced ks)
+KS_SHAPES = [(2, 512, 512, 32, 32, 8), (2, 512, 512, 32, 32, 2), (1, 256, 384, 24, 32, 4), (2, 136, 128, 16, 32, 2), (1, 528, 256, 8, 32, 8),
+             (2, 128, 128, 8, 32, 2)]
+
+
+@pytest.mark.parametrize("shape", KS_SHAPES)
+def test_wino4_ksplit_forward_and_gated_data_gradient(shape):
+    B, cin, cout, H, W, ks = shape
+    torch.manual_seed(44)
+    x, w = torch.randn(B, cin, H, W), torch.randn(cout, cin, 3, 3)
+    s, d = torch.rand(B, cin) + 0.5, torch.rand(B, cout) + 0.5
+    noise, nw, bias = torch.randn(B, 1, H, W), torch.tensor([0.3]), 0.1 * torch.randn(cout)
+    scale = 1.0 / (cin * 9) ** 0.5
+    xg, sg, dg, ng, nwg, bg = (t.to(DEV) for t in (x, s, d, noise, nw, bias))
+    up = mc.pack_wino(w.to(DEV), scale, False)
+    lin = F.conv2d(x.double() * s.double()[:, :, None, None], w.double() * scale, padding=1) * d.double()[:, :, None, None]
+    ref = F.leaky_relu(lin + 0.3 * noise.double() + bias.double()[None, :, None, None], 0.2) * 2 ** 0.5
+    plain = F.conv2d(x.double(), w.double() * scale, padding=1)
+    outs = {}
+    for k in (1, ks):
+        with _lib.tuning(wino4_ks=k, wino4_min_wgs=0):
+            n0 = _lib.get_tuning("wino4_ks_launches")
+            out = torch.full((B, cout, H, W), float("nan"), device=DEV)
+            _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(xg), _lib.ptr(up), _lib.ptr(sg), B, cin, cout, H, W, 1, _lib.ptr(dg),
+                      _lib.ptr(ng), B, _lib.ptr(nwg), _lib.ptr(bg), 0.2, 2 ** 0.5)
+            assert rel(out, ref) <= BAR, ("styled", k, shape, rel(out, ref))
+            out2 = torch.full((B, cout, H, W), float("nan"), device=DEV)
+            _lib.call("cagc_wino_conv3x3", _lib.ptr(out2), _lib.ptr(xg), _lib.ptr(up), None, B, cin, cout, H, W, 0, None, None, 0, None, None, 0.2, 1.0)
+            assert rel(out2, plain) <= BAR, ("plain", k, shape, rel(out2, plain))
+            n1 = _lib.get_tuning("wino4_ks_launches")
+            expect_split = k > 1 and ((cin + 15) // 16 * 16) // 64 >= 2
+            assert (n1 - n0 == 2) == expect_split, (k, shape, n1 - n0)
+            outs[k] = out.clone()
+            out3 = torch.full((B, cout, H, W), float("nan"), device=DEV)      # bit-reproducible: ordered slabs, no atomics
+            _lib.call("cagc_wino_conv3x3", _lib.ptr(out3), _lib.ptr(xg), _lib.ptr(up), _lib.ptr(sg), B, cin, cout, H, W, 1, _lib.ptr(dg),
+                      _lib.ptr(ng), B, _lib.ptr(nwg), _lib.ptr(bg), 0.2, 2 ** 0.5)
+            assert torch.equal(out, out3)
+    # gated data gradient (GEMM K = this layer's Cout, M = Cin: needs Cin % 128 == 0 to split)
+    if cin % 128 == 0:
+        gout, act = torch.randn(B, cout, H, W), torch.randn(B, cout, H, W)
+        upb = mc.pack_wino(w.to(DEV), scale, True)
+        gin = gout.double() * torch.where(act > 0, 1.0, 0.2).double() * 2 ** 0.5
+        gref = F.conv_transpose2d(gin, w.double() * scale, padding=1)
+        with _lib.tuning(wino4_ks=ks, wino4_min_wgs=0):
+            n0 = _lib.get_tuning("wino4_ks_launches")
+            gx = torch.full((B, cin, H, W), float("nan"), device=DEV)
+            gg, ag = gout.to(DEV), act.to(DEV)
+            _lib.call("cagc_wino_conv3x3_act_dgrad", _lib.ptr(gx), _lib.ptr(gg), _lib.ptr(ag), _lib.ptr(upb), None, B, cin, cout, H, W, 0.2, 2 ** 0.5)
+            assert rel(gx, gref) <= BAR, ("gated dgrad", shape, rel(gx, gref))
+            assert _lib.get_tuning("wino4_ks_launches") - n0 == (1 if ((cout + 15) // 16 * 16) // 64 >= 2 else 0)
+
+
+def test_wino4_ksplit_plan_for_the_small_batch_shapes():
+    """per-GPU batch 2 / 8 of configs[1]: the 512-channel layers that take F(4x4) with fewer than 256 128-channel workgroups split K;
+    the F(4x4)-or-F(2x2) choice itself (cagc_wino_plan) is what it was"""
+    assert _lib.get_tuning("wino4_ks") == 0
+    assert _lib.query("cagc_wino_plan", 2, 512, 512, 64, 64) == 4 and _lib.query("cagc_wino_plan", 8, 512, 512, 32, 32) == 4
+    assert _lib.query("cagc_wino_plan", 2, 512, 512, 32, 32) == 2 and _lib.query("cagc_wino_plan", 4, 512, 512, 32, 32) == 2
+    for B, H, split in ((2, 64, True), (8, 32, True), (4, 64, False), (16, 32, False), (2, 32, False)):
+        x, w = torch.randn(B, 512, H, H, device=DEV), torch.randn(512, 512, 3, 3, device=DEV)
+        up = mc.pack_wino(w, 0.01, False)
+        out = torch.empty_like(x)
+        n0 = _lib.get_tuning("wino4_ks_launches")
+        _lib.call("cagc_wino_conv3x3", _lib.ptr(out), _lib.ptr(x), _lib.ptr(up), None, B, 512, 512, H, H, 0, None, None, 0, None, None, 0.2, 1.0)
+        torch.cuda.synchronize()
+        assert (_lib.get_tuning("wino4_ks_launches") > n0) == split, (B, H)
