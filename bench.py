@@ -561,6 +561,7 @@ def main():
         from cagc.op import modconv as _mc
         overlap_saved, kd.OVERLAP_TEACHER = kd.OVERLAP_TEACHER, False   # one stream: kernels are timed in isolation
         side_saved, _mc._SIDE_LIMIT = _mc._SIDE_LIMIT, 0                # (also the weight gradients / skip GEMMs of the side stream)
+        fork_saved, _mc.FORK_TORGB = _mc.FORK_TORGB, False              # (and the student's ToRGB chain)
         for _ in range(2):
             prof_step.sample_and_step(bs, mask, rng, None)
         import ctypes as _ct
@@ -582,6 +583,7 @@ def main():
         clk_w4 = float(clk_acc[0] / clk_acc[1]) if float(clk_acc[1]) > 0 else None
         kd.OVERLAP_TEACHER = overlap_saved
         _mc._SIDE_LIMIT = side_saved
+        _mc.FORK_TORGB = fork_saved
         if rank == 0:
             mfma = {k: v for k, v in agg.items() if v[2] > 0}
             # the Winograd kernel runs as 4-wave (NH1) or 8-wave (NH2) workgroups of the SAME source kernel, chosen per launch
@@ -677,6 +679,7 @@ def main():
         from cagc.op import modconv as _mc
         overlap_saved, kd.OVERLAP_TEACHER = kd.OVERLAP_TEACHER, False
         side_saved, _mc._SIDE_LIMIT = _mc._SIDE_LIMIT, 0
+        fork_saved, _mc.FORK_TORGB = _mc.FORK_TORGB, False
         it.phase_timer = kd.PhaseTimer()
         for i in range(16):
             it.iteration(i, real, mask, rng, None)
@@ -684,6 +687,7 @@ def main():
         it.phase_timer = None
         kd.OVERLAP_TEACHER = overlap_saved
         _mc._SIDE_LIMIT = side_saved
+        _mc.FORK_TORGB = fork_saved
         full = {"value": round(16 * bs / dtf, 2), "unit": "images/s", "ms_per_iteration": round(dtf / 16 * 1e3, 2),
                 "what": "D step + G/KD step + R1/16 + path-length/4 + EMA, bs16, eager launches (train.py:371-398 equivalent); "
                         "every convolution incl. the second-order passes and D's weight gradients on libcagc (no MIOpen)",

@@ -4,7 +4,7 @@
 # markdown by scripts/rocpd_stats.py / rocpd_pmc.py.  Copy the summaries you keep into profiles/.
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-export CAGC_OVERLAP_TEACHER=0 CAGC_SIDE_WGRAD=0   # one stream: per-kernel durations in isolation, as in bench.py's roofline pass
+export CAGC_OVERLAP_TEACHER=0 CAGC_SIDE_WGRAD=0 CAGC_FORK_TORGB=0   # one stream: per-kernel durations in isolation, as in bench.py's roofline pass
 CMD="python bench.py --no-graph --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-full-iteration --no-proxy --no-config3 --sweep 0 $PROFILE_EXTRA"   # PROFILE_EXTRA="--local-batch 2": the per-GPU batch of an 8-GPU run
 mkdir -p gpurun_out
 rm -rf /tmp/prof_kt

@@ -92,8 +92,53 @@ def _worker(port):
         torch.cuda.synchronize()
         worst2 = max(rel(b.detach(), a.detach()) for (_, a), (_, b) in zip(s2.named_parameters(), s3.named_parameters()))
         assert worst2 <= 1e-6, f"DDP (world 1, RCCL) step differs from the unwrapped step: {worst2:.2e}"
+        # (3) the fallback ladder: a failure INSIDE the capture of comm="graph" selects comm="host" and records why; under
+        #     CAGC_STRICT_COMM=1 it is an error instead; an error in the eager WARM-UP (not a capture problem) always propagates
+        real_capture = kd.GraphedKDStep._capture
+
+        def failing_capture(self, mode):
+            if mode == "graph":
+                raise kd._CaptureFailed(mode) from RuntimeError("injected: RCCL refused to be captured")
+            return real_capture(self, mode)
+
+        kd.GraphedKDStep._capture = failing_capture
+        try:
+            s4, t4, d4 = build()
+            fb = kd.GraphedKDStep(s4, t4, d4, B, cu(g["mask"]), random_noise=False, latent=24, world_size=1, always_reduce=True, comm="auto")
+            assert fb.comm == "host" and fb.graph_opt is not None and "fallback" in fb.comm_reason and "injected" in fb.comm_reason, fb.comm_reason
+            for st in meta["steps"]:
+                lf = fb.g_step(*inputs(st, s4.num_layers))
+            torch.cuda.synchronize()
+            assert float(lf["g"]) == float(lb["g"])           # the fallback computes the same step
+            os.environ["CAGC_STRICT_COMM"] = "1"
+            try:
+                s5, t5, d5 = build()
+                try:
+                    kd.GraphedKDStep(s5, t5, d5, B, cu(g["mask"]), random_noise=False, latent=24, world_size=1, always_reduce=True, comm="auto")
+                    raise AssertionError("CAGC_STRICT_COMM=1 did not turn the capture failure into an error")
+                except RuntimeError as e:
+                    assert "CAGC_STRICT_COMM" in str(e), str(e)
+            finally:
+                del os.environ["CAGC_STRICT_COMM"]
+        finally:
+            kd.GraphedKDStep._capture = real_capture
+        real_warm = kd.GraphedKDStep._warm_up
+
+        def failing_warm(self):
+            raise RuntimeError("injected: out of memory in the warm-up")
+
+        kd.GraphedKDStep._warm_up = failing_warm
+        try:
+            s6, t6, d6 = build()
+            try:
+                kd.GraphedKDStep(s6, t6, d6, B, cu(g["mask"]), random_noise=False, latent=24, world_size=1, always_reduce=True, comm="auto")
+                raise AssertionError("a warm-up error was swallowed by the comm fallback")
+            except RuntimeError as e:
+                assert "warm-up" in str(e)
+        finally:
+            kd.GraphedKDStep._warm_up = real_warm
     dist.destroy_process_group()
-    print(f"RCCL_WORLD1_OK graph bit-equal (in-graph and host collectives) ddp {worst2:.1e}")
+    print(f"RCCL_WORLD1_OK graph bit-equal (in-graph and host collectives) ddp {worst2:.1e}; fallback ladder ok")
 
 
 def test_rccl_world1_graph_allreduce_and_ddp_hooks():

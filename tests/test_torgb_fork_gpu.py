@@ -87,3 +87,4 @@ def test_forked_chain_inside_the_captured_step_equals_eager(monkeypatch):
             assert torch.equal(g0, g1), f"gradient {k} differs by {float((g0 - g1).abs().max()):.3e}"
     worst = max(float((p0[k].detach() - p1[k].detach()).abs().max() / p0[k].detach().abs().max().clamp(min=1e-30)) for k in p0)
     assert worst <= 1e-4, f"updated weights differ between the eager one-stream step and the forked captured step: {worst:.2e}"
+
