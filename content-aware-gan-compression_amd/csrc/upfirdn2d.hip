@@ -442,6 +442,93 @@ static int launch_fir4_rows(float* out, const float* x, const float* kernel, int
 #undef CAGC_FIR_ROWS
   return 0;
 }
+// Row-streaming form of k_fir4_down2 (4x4 FIR + 2x decimation, pad0 = 1: the discriminator's skip path and the adjoint of `Upsample`),
+// round 6: no LDS, no barrier.  A thread owns 4 adjacent output columns of a strip of R output rows: input columns 2*ox - 1 .. 2*ox + 8
+// = four aligned 16-byte buffer loads per input row (columns 2*ox - 4 .. 2*ox + 11; in_w % 4 == 0, so a float4 is inside or outside the
+// image as a whole and the out-of-range offset returns the padding zero), two new input rows per output row, the next pair in flight
+// while the current output row is computed from a 4-row register window.  out[oy,ox] = sum_{i,j} kf[i][j] in[2oy-1+i, 2ox-1+j].
+__global__ __launch_bounds__(256) void k_fir4_down2_rows(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ kern,
+                                                         int64_t planes, int in_h, int in_w, int out_h, int out_w, int ncg, int chunks, int R) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cg = (int)(gid % ncg);
+  const int64_t rest = gid / ncg;
+  const int chunk = (int)(rest % chunks);
+  const int64_t p = rest / chunks;
+  if (p >= planes) return;
+  float kf[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) kf[t] = kern[15 - t];          // flipped: true convolution (uniform address: scalar loads)
+  const int ox = 4 * cg;
+  const int y0 = chunk * R, y1 = min(y0 + R, out_h);
+  const int64_t plane_elems = (int64_t)in_h * in_w;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(planes * plane_elems * 4), 0x00020000);
+  constexpr unsigned OOR = 0x80000000u;
+  unsigned cb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 2 * ox - 4 + 4 * q;
+    cb[q] = (c >= 0 && c < in_w) ? (unsigned)c * 4u : OOR;
+  }
+  const unsigned pbase = (unsigned)(p * plane_elems * 4);
+  struct Row { float v[16]; };
+  auto load_row = [&](Row& Rw, const int iy) {
+    const bool rok = iy >= 0 && iy < in_h;
+    const unsigned rb = pbase + (unsigned)iy * (unsigned)in_w * 4u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned off = (rok && cb[q] != OOR) ? rb + cb[q] : OOR;
+      const float4 f = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+      Rw.v[4 * q] = f.x; Rw.v[4 * q + 1] = f.y; Rw.v[4 * q + 2] = f.z; Rw.v[4 * q + 3] = f.w;
+    }
+  };
+  auto emit = [&](const Row& a, const Row& b, const Row& c, const Row& d, const int oy) {
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    const Row* rows[4] = {&a, &b, &c, &d};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float k = kf[i * 4 + j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += rows[i]->v[3 + 2 * e + j] * k;       // input column 2(ox+e) - 1 + j = window index 3 + 2e + j
+      }
+    float* dst = out + (p * out_h + oy) * (int64_t)out_w + ox;
+    if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+      for (int e = 0; e < 4; ++e) if (ox + e < out_w) dst[e] = o[e];
+  };
+  Row r0, r1, n0, n1, m0, m1;
+  load_row(r0, 2 * y0 - 1); load_row(r1, 2 * y0);
+  load_row(n0, 2 * y0 + 1); load_row(n1, 2 * y0 + 2);
+  for (int oy = y0; oy < y1; ++oy) {
+    load_row(m0, 2 * oy + 3); load_row(m1, 2 * oy + 4);       // the next output row's two new input rows, in flight
+    emit(r0, r1, n0, n1, oy);
+    r0 = n0; r1 = n1; n0 = m0; n1 = m1;
+  }
+}
+
+// strips of ~16 output rows; needs in_w % 4 == 0, out_w % 4 == 0, 16-byte aligned tensors, one descriptor over the whole input
+static bool fir4_down2_rows_launch(float* out, const float* x, const float* kernel, int64_t planes, int in_h, int in_w, int out_h, int out_w,
+                                   hipStream_t st) {
+  if (!(in_w % 4 == 0 && out_w % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) % 16) == 0)) return false;
+  if (out_h < 16 || out_w < 32) return false;
+  if (planes * (int64_t)in_h * in_w * 4 > 0x7fffffffll) return false;
+  // strip height: 16 rows where that still gives the chip >= 256 K threads, down to 4 (a strip re-reads 2 halo rows); launches that stay
+  // below 64 K threads (the ToRGB adjoint: B x 3 planes) keep the tiled kernel, whose 32 x 32 tiles give them more workgroups
+  const int ncg = out_w / 4;
+  int64_t rmax = planes * (int64_t)out_h * ncg / (256 * 1024);
+  int R = rmax >= 16 ? 16 : (rmax >= 4 ? (int)rmax : 4);
+  int chunks = cdiv(out_h, R);
+  R = cdiv(out_h, chunks);
+  chunks = cdiv(out_h, R);
+  if (planes * chunks * ncg < 64 * 1024) return false;
+  const int64_t threads = planes * chunks * ncg;
+  const int64_t nb = (threads + 255) / 256;
+  if (nb >= (1ll << 31)) return false;
+  hipLaunchKernelGGL(k_fir4_down2_rows, dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, planes, in_h, in_w, out_h, out_w, ncg, chunks, R);
+  return true;
+}
+
 static int fir_rows_on() { static const int v = getenv("CAGC_FIR_ROWS") ? atoi(getenv("CAGC_FIR_ROWS")) : 1; return v; }
 
 // ---------------------------------------------------------------------------------------------------
@@ -671,6 +758,9 @@ __global__ __launch_bounds__(256) void k_blur_up_fwd_w64(float* __restrict__ out
   }
 }
 
+// (Round 6 measured a row-streaming form of this kernel too — a thread owning 8 output columns of a strip, one new T_full row = five
+// 16-byte loads from the two planes of its row parity, four rows ahead: bit-identical, 0.70 -> 0.79 ms per step, largest launch 4.16 ->
+// 3.93 TB/s.  Four plane streams per thread do not stream like k_fir4_rows' single one; the LDS-tiled form stays.  profiles/NOTES_r06.md)
 // gT_full[Yt,Xt] = sum_{a,b} kf[a][b] * gz[Yt+1-a, Xt+1-b]  for Yt in [0,2H], Xt in [0,2W]; the phase
 // planes' extra entries (Yt = 2H+1 or Xt = 2W+1) are written as zero.
 __global__ __launch_bounds__(256) void k_blur_up_bwd(float* __restrict__ gt, const float* __restrict__ gz,
@@ -822,7 +912,9 @@ extern "C" int cagc_upfirdn2d(float* out, const float* x, const float* kernel, i
     const int tx = cdiv(out_w, FT), ty = cdiv(out_h, FT);
     const int64_t nb = planes * tx * ty;
     CAGC_REQUIRE(nb < (1ll << 31), "cagc_upfirdn2d: too large");
-    if (up_x == 1 && pad_x0 == 1 && pad_y0 == 1 && in_w % 4 == 0 && ((uintptr_t)x % 16) == 0)
+    if (up_x == 1 && pad_x0 == 1 && pad_y0 == 1 && fir_rows_on() && fir4_down2_rows_launch(out, x, kernel, planes, in_h, in_w, out_h, out_w, st)) {
+      // row-streaming kernel
+    } else if (up_x == 1 && pad_x0 == 1 && pad_y0 == 1 && in_w % 4 == 0 && ((uintptr_t)x % 16) == 0)
       hipLaunchKernelGGL(k_fir4_down2, dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w, tx, ty);
     else if (up_x == 1)
       hipLaunchKernelGGL((k_fir4_updown<1, 2>), dim3((unsigned)nb), dim3(256), 0, st, out, x, kernel, in_h, in_w, out_h, out_w,

@@ -43,3 +43,31 @@ def test_fir4x4_pitched_vs_float64(case):
     assert err <= 2e-6, (case, err)
     if op > ow:
         assert float(got[:, :, ow:].abs().max()) == 0.0, "pitch padding of the output is written as zero"
+
+
+# 4x4 FIR + 2x decimation, pad (1,1) (the ResBlock skip's decimating blur, model.py:726-728 evaluated where the stride-2 1x1 conv samples;
+# and the adjoint of `Upsample`, op/upfirdn2d.py:111-116) through cagc_upfirdn2d: the row-streaming kernel k_fir4_down2_rows (outputs
+# >= 16 x 32 with widths % 4 == 0) and the tiled kernels it falls back to.  (planes, in_h, in_w)
+DOWN2_CASES = [(6, 256, 256), (3, 128, 64), (130, 32, 64), (5, 34, 72), (4, 64, 40), (3, 16, 16), (2, 70, 66), (1, 8, 64)]
+
+
+@pytest.mark.parametrize("case", DOWN2_CASES)
+def test_fir4_down2_vs_float64_streaming_and_tiled(case):
+    planes, ih, iw = case
+    torch.manual_seed(6)
+    k = torch.randn(4, 4)
+    x = torch.randn(planes, ih, iw)
+    oh, ow = (ih + 2 - 4) // 2 + 1, (iw + 2 - 4) // 2 + 1
+    # upfirdn2d(up 1, down 2, pad (1,1)): out[oy,ox] = sum_{i,j} flip(k)[i,j] in[2oy-1+i, 2ox-1+j]
+    ref = F.conv2d(F.pad(x.double().unsqueeze(1), (1, 1, 1, 1)), torch.flip(k, (0, 1)).double().view(1, 1, 4, 4), stride=2)[:, 0]
+    assert tuple(ref.shape) == (planes, oh, ow)
+    xd, kd = x.to(DEV), k.to(DEV)
+    outs = []
+    for rows in (1, 0):      # the default (streaming where eligible) and the tiled kernel: CAGC_FIR_ROWS is read once per process, so the
+        out = torch.full((planes, oh, ow), float("nan"), device=DEV)      # tiled form is reached through a width the streaming form declines
+        if rows == 0 and ow % 4 == 0 and oh >= 16 and ow >= 32:
+            continue
+        _lib.call("cagc_upfirdn2d", _lib.ptr(out), _lib.ptr(xd), _lib.ptr(kd), planes, ih, iw, oh, ow, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1)
+        err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert err <= 2e-6, (case, rows, err)
+        outs.append(out)
