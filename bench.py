@@ -685,13 +685,29 @@ def main():
             it.iteration(i, real, mask, rng, None)
         phases = it.phase_timer.summary()
         it.phase_timer = None
+        # the D step's MFMA entry points by themselves (one-stream, HIP events per launch): where train_D_d_forward / _backward go
+        d_kernels = None
+        try:
+            zs_d = [torch.randn(bs, 512, device=dev)]
+            it.d_step(real, zs_d)
+            with KernelTimer(_lib) as ktd:
+                for _ in range(2):
+                    it.d_step(real, zs_d)
+            aggd = ktd.summary()
+            d_kernels = {k: {"ms_per_d_step": round(v[1] / 2, 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                             "what": ("weight gradient (direct convolution: K = pixels x batch)" if "wgrad" in k else
+                                      "data gradient" if "dgrad" in k else "forward")}
+                         for k, v in sorted(aggd.items(), key=lambda kv: -kv[1][1]) if v[2] > 0 and v[1] / 2 >= 0.3}
+            d_kernels["_all_launches_ms_per_d_step"] = round(sum(v[1] for v in aggd.values()) / 2, 2)
+        except Exception as e:  # noqa: BLE001 — a diagnostic
+            print(f"[bench] D-step kernel pass failed ({type(e).__name__}: {e})", file=sys.stderr)
         kd.OVERLAP_TEACHER = overlap_saved
         _mc._SIDE_LIMIT = side_saved
         _mc.FORK_TORGB = fork_saved
         full = {"value": round(16 * bs / dtf, 2), "unit": "images/s", "ms_per_iteration": round(dtf / 16 * 1e3, 2),
                 "what": "D step + G/KD step + R1/16 + path-length/4 + EMA, bs16, eager launches (train.py:371-398 equivalent); "
                         "every convolution incl. the second-order passes and D's weight gradients on libcagc (no MIOpen)",
-                "phases": phases,
+                "phases": phases, "d_step_mfma_entry_points": d_kernels,
                 "phases_note": "GPU ms per call over 16 iterations (R1 runs in 1, the path-length regulariser in 4 of them); "
                                "train_G_d_forward = frozen-D forward + teacher forward + KD loss, as the reference brackets it"}
         del it, g_ema
