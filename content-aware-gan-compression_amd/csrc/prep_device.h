@@ -122,7 +122,11 @@ inline bool wino_f4_enabled() {
   static const int v = getenv("CAGC_WINO_F4") ? atoi(getenv("CAGC_WINO_F4")) : 1;
   return v != 0;
 }
-inline bool wino_use_f4(int K, int M) { return wino_f4_enabled() && M >= 128 && K >= 128; }
+inline int wino_f4_min_ch() {      // CAGC_WINO_F4_MIN_CH: smallest channel count (both GEMM sides) that takes F(4x4); read once per process
+  static const int v = getenv("CAGC_WINO_F4_MIN_CH") ? atoi(getenv("CAGC_WINO_F4_MIN_CH")) : 128;
+  return v;
+}
+inline bool wino_use_f4(int K, int M) { return wino_f4_enabled() && M >= wino_f4_min_ch() && K >= wino_f4_min_ch(); }
 inline int wino4_kp(int K) { return round_up(K, 16); }     // two chunks of 8 per main-loop iteration
 inline int64_t wino4_packed_elems(int K, int M) { return (int64_t)cdiv(M, 64) * 36 * wino4_kp(K) * 64; }   // 64-channel tiles, zero-padded
 // An F(4x4)-eligible layer carries BOTH packings back to back, [F(4x4) | F(2x2)]: the kernel is chosen per LAUNCH (run-time batch
