@@ -701,6 +701,8 @@ def main():
             d_kernels["_all_launches_ms_per_d_step"] = round(sum(v[1] for v in aggd.values()) / 2, 2)
         except Exception as e:  # noqa: BLE001 — a diagnostic
             print(f"[bench] D-step kernel pass failed ({type(e).__name__}: {e})", file=sys.stderr)
+        kd.requires_grad(student, True)       # d_step froze the student: the later legs build generator steps on copies of it
+        kd.requires_grad(disc, False)
         kd.OVERLAP_TEACHER = overlap_saved
         _mc._SIDE_LIMIT = side_saved
         _mc.FORK_TORGB = fork_saved

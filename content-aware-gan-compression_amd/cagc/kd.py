@@ -467,10 +467,10 @@ class GraphedKDStep(KDStep):
         (parameters that receive none come last).  Leaves weights, gradients and optimiser untouched."""
         order, hooks = [], []
         index = {id(p): i for i, p in enumerate(params)}
+        requires_grad(self.student, True)      # (a preceding D step leaves the student frozen: hooks want leaves that require grad)
+        requires_grad(self.disc, False)
         for p in params:
             hooks.append(p.register_post_accumulate_grad_hook(lambda q: order.append(index[id(q)])))
-        requires_grad(self.student, True)
-        requires_grad(self.disc, False)
         try:
             z = [torch.randn_like(self.z[0]), torch.randn_like(self.z[1])]
             inj = torch.full_like(self.inj, max(1, self.n_latent // 2))      # with style mixing: both passes through the mapping network
@@ -506,6 +506,7 @@ class GraphedKDStep(KDStep):
         # predecessor's hooks: an abandoned step (and its graphs / flat buffers) is then free to be collected, and an eager backward
         # pays one Python call per parameter, not one per step ever constructed.
         import weakref
+        requires_grad(self.student, True)
         base = self.student.module if hasattr(self.student, "module") else self.student
         prev = base.__dict__.get("_cagc_graphed_step")
         prev = prev() if prev is not None else None

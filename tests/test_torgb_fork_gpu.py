@@ -88,3 +88,15 @@ def test_forked_chain_inside_the_captured_step_equals_eager(monkeypatch):
     worst = max(float((p0[k].detach() - p1[k].detach()).abs().max() / p0[k].detach().abs().max().clamp(min=1e-30)) for k in p0)
     assert worst <= 1e-4, f"updated weights differ between the eager one-stream step and the forked captured step: {worst:.2e}"
 
+
+
+def test_graphed_step_builds_on_a_student_left_frozen_by_a_d_step():
+    """bench.py's legs found this: TrainIteration.d_step leaves the student with requires_grad False; a GraphedKDStep built afterwards
+    (on the same student or a deepcopy) must un-freeze it before it registers its gradient hooks."""
+    student, teacher, disc = kd.build_synthetic_workload(256, DEV, seed=5)
+    mask = kd.ellipse_mask(2, 256, DEV)
+    kd.requires_grad(student, False)
+    step = kd.GraphedKDStep(student, teacher, disc, 2, mask)
+    out = step.sample_and_step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["g"]) and all(p.requires_grad for p in student.parameters())
