@@ -863,8 +863,86 @@ __global__ __launch_bounds__(256) void k_blur_up_bwd_v(float* __restrict__ gt, c
   }
 }
 
+// Row-streaming form of k_blur_up_bwd_v (round 6): ONE input stream (gz), no LDS, no barrier.  A thread owns plane columns n0 .. n0+3 of BOTH
+// column parities = T_full columns 2 n0 .. 2 n0 + 7, for a strip of T_full rows Yt; one T_full row needs the gz columns 2 n0 - 2 .. 2 n0 + 8
+// = four aligned 16-byte buffer loads (2W % 4 == 0: a float4 is inside or outside the image as a whole, out of range = the zero), rows
+// Yt - 2 .. Yt + 1: one new gz row per T_full row, requested four rows ahead.  Two 16-byte stores per T_full row (the even-X and the odd-X
+// plane of its row parity).  Same summation order as the tiled kernels: bit-identical.
+__global__ __launch_bounds__(256) void k_blur_up_bwd_rows(float* __restrict__ gt, const float* __restrict__ gz, const float* __restrict__ fir,
+                                                          int64_t planes, int H, int W, int ncg, int chunks, int R) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cg = (int)(gid % ncg);
+  const int64_t rest = gid / ncg;
+  const int chunk = (int)(rest % chunks);
+  const int64_t plane = rest / chunks;
+  if (plane >= planes) return;
+  float kf[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
+  const int OH = 2 * H, OW = 2 * W, PH = H + 1, PWp = (W + 1 + 3) & ~3;
+  const int n0 = 4 * cg;
+  const int NY = 2 * PH;                                       // T_full rows 0 .. 2H + 1 (the last one is the planes' zero padding)
+  const int y0 = chunk * R, y1 = min(y0 + R, NY);
+  const int64_t in_elems = (int64_t)OH * OW;
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gz), 0, (int)(planes * in_elems * 4), 0x00020000);
+  constexpr unsigned OOR = 0x80000000u;
+  unsigned cb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 2 * n0 - 4 + 4 * q;
+    cb[q] = (c >= 0 && c < OW) ? (unsigned)c * 4u : OOR;
+  }
+  const unsigned pbase = (unsigned)(plane * in_elems * 4);
+  struct Row { float v[16]; };                                 // gz columns 2 n0 - 4 .. 2 n0 + 11
+  auto load_row = [&](Row& Rw, const int y) {
+    const bool rok = y >= 0 && y < OH;
+    const unsigned rb = pbase + (unsigned)y * (unsigned)OW * 4u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 f = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rg, (rok && cb[q] != OOR) ? rb + cb[q] : OOR, 0, 0));
+      Rw.v[4 * q] = f.x; Rw.v[4 * q + 1] = f.y; Rw.v[4 * q + 2] = f.z; Rw.v[4 * q + 3] = f.w;
+    }
+  };
+  float* tp = gt + plane * (int64_t)4 * PH * PWp;
+  // rows[a] = gz row Yt + 1 - a
+  auto emit = [&](const Row& ra0, const Row& ra1, const Row& ra2, const Row& ra3, const int Yt) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (Yt <= OH) {
+      const Row* rows[4] = {&ra0, &ra1, &ra2, &ra3};
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const float k = kf[a * 4 + bb];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += rows[a]->v[e + 5 - bb] * k;       // gz column (2 n0 + e) + 1 - bb = window index e + 5 - bb
+        }
+    }
+    const int py = Yt & 1, m = Yt >> 1;
+    const int X = 2 * n0;                                       // T_full column of acc[0]; entries past 2W are the planes' zero padding
+    const float4 ev = make_float4(X <= OW ? acc[0] : 0.f, X + 2 <= OW ? acc[2] : 0.f, X + 4 <= OW ? acc[4] : 0.f, X + 6 <= OW ? acc[6] : 0.f);
+    const float4 od = make_float4(X + 1 <= OW ? acc[1] : 0.f, X + 3 <= OW ? acc[3] : 0.f, X + 5 <= OW ? acc[5] : 0.f, X + 7 <= OW ? acc[7] : 0.f);
+    *reinterpret_cast<float4*>(tp + ((int64_t)(2 * py) * PH + m) * PWp + n0) = ev;
+    *reinterpret_cast<float4*>(tp + ((int64_t)(2 * py + 1) * PH + m) * PWp + n0) = od;
+  };
+  // window: gz rows Yt - 2 .. Yt + 1 for the current Yt; four T_full rows per trip, their four new gz rows requested a trip earlier
+  Row r0, r1, r2, n0r, n1r, n2r, n3r, m0, m1, m2, m3;
+  load_row(r0, y0 - 2); load_row(r1, y0 - 1); load_row(r2, y0);
+  load_row(n0r, y0 + 1); load_row(n1r, y0 + 2); load_row(n2r, y0 + 3); load_row(n3r, y0 + 4);
+  for (int Yt = y0; Yt < y1; Yt += 4) {
+    load_row(m0, Yt + 5); load_row(m1, Yt + 6); load_row(m2, Yt + 7); load_row(m3, Yt + 8);
+    emit(n0r, r2, r1, r0, Yt);                                  // a = 0: gz row Yt + 1, ..., a = 3: gz row Yt - 2
+    if (Yt + 1 < y1) emit(n1r, n0r, r2, r1, Yt + 1);
+    if (Yt + 2 < y1) emit(n2r, n1r, n0r, r2, Yt + 2);
+    if (Yt + 3 < y1) emit(n3r, n2r, n1r, n0r, Yt + 3);
+    r0 = n1r; r1 = n2r; r2 = n3r;
+    n0r = m0; n1r = m1; n2r = m2; n3r = m3;
+  }
+}
+
 // CAGC_BLUR_W64=0: 32-wide tiles everywhere; 1 (default): 64-wide tiles for the blur behind the transposed conv (0.85 -> 0.70
 // ms/step); 2: also for the plain 4x4 FIR (k_fir4_vec<64>: 18 staged float4 per 64 columns instead of 10 per 32 — no gain measured)
+static int blur_bwd_rows_on() { static const int v = getenv("CAGC_BLUR_BWD_ROWS") ? atoi(getenv("CAGC_BLUR_BWD_ROWS")) : 1; return v; }
 static int fir_w64() {
   static const int v = getenv("CAGC_BLUR_W64") ? atoi(getenv("CAGC_BLUR_W64")) : 1;
   return v;
@@ -965,6 +1043,21 @@ extern "C" int cagc_blur_up_bwd(float* gt, const float* gz, const float* fir, in
   const int tx = cdiv(2 * W + 2, FT), ty = cdiv(2 * H + 2, FT);
   const int64_t nb = (int64_t)B * C * tx * ty;
   CAGC_REQUIRE(nb < (1ll << 31), "cagc_blur_up_bwd: too large");
+  {   // row-streaming form: enough threads to fill the chip, one descriptor over the whole gradient
+    const int64_t planes = (int64_t)B * C;
+    const int PWp = (W + 1 + 3) & ~3, ncg = PWp / 4, NY = 2 * (H + 1);
+    int64_t rmax = planes * NY * ncg / (256 * 1024);
+    int R = rmax >= 32 ? 32 : (rmax >= 8 ? (int)rmax : 8);
+    int chunks = cdiv(NY, R);
+    R = cdiv(NY, chunks);
+    chunks = cdiv(NY, R);
+    if (fir_rows_on() && blur_bwd_rows_on() && W % 2 == 0 && 2 * W >= 64 && (((uintptr_t)gt | (uintptr_t)gz) % 16) == 0 &&
+        planes * chunks * ncg >= 64 * 1024 && planes * 4 * (int64_t)H * W * 4 <= 0x7fffffffll && cdiv(planes * chunks * ncg, (int64_t)256) < (1ll << 31)) {
+      hipLaunchKernelGGL(k_blur_up_bwd_rows, dim3((unsigned)cdiv(planes * chunks * ncg, (int64_t)256)), dim3(256), 0, as_stream(stream), gt, gz, fir,
+                         planes, H, W, ncg, chunks, R);
+      return check_launch("cagc_blur_up_bwd");
+    }
+  }
   if (fir_w64() && W % 2 == 0 && 2 * W >= 64 && (((uintptr_t)gt | (uintptr_t)gz) % 16) == 0) {
     const int tx64 = cdiv(2 * W + 2, 64);
     hipLaunchKernelGGL(k_blur_up_bwd_v, dim3((unsigned)((int64_t)B * C * tx64 * ty)), dim3(256), 0, as_stream(stream), gt, gz, fir, H, W,

@@ -46,3 +46,29 @@ def test_blur_up_fwd_vs_float64(case, mode):
               _lib.ptr(nwd) if has_noise else None, _lib.ptr(bd) if styled else None, B, C, H, W, 0.2, 2 ** 0.5)
     err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
     assert err <= 2e-6, (case, mode, err)
+
+
+@pytest.mark.parametrize("case", CASES + [(8, 128, 128, 128)])
+def test_blur_up_bwd_vs_float64(case):
+    """cagc_blur_up_bwd: the adjoint of the blur behind the transposed conv, gz [B,C,2H,2W] -> phase-planar gT [B,C,4,H+1,P]
+    (gT_full[Yt,Xt] = sum_{i,j} fir[i,j] gz[Yt-2+i, Xt-2+j], Yt <= 2H, Xt <= 2W; the planes' extra row / column and the pitch padding are
+    written as zero): round 6's row-streaming kernel and the tiled kernels the smaller cases fall to."""
+    B, C, H, W = case
+    torch.manual_seed(10)
+    P = _lib.query("cagc_phase_pitch", W)
+    gz = torch.randn(B, C, 2 * H, 2 * W)
+    fir = torch.randn(4, 4)
+    full = F.conv2d(F.pad(gz.double().reshape(B * C, 1, 2 * H, 2 * W), (2, 2, 2, 2)), fir.double().view(1, 1, 4, 4))      # [.., 2H+1, 2W+1]
+    tf = torch.zeros(B * C, 2 * H + 2, 2 * W + 2, dtype=torch.float64)
+    tf[:, :2 * H + 1, :2 * W + 1] = full[:, 0]
+    ref = torch.zeros(B * C, 4, H + 1, P, dtype=torch.float64)
+    for ph in range(4):
+        ref[:, ph, :, :W + 1] = tf[:, (ph >> 1)::2, (ph & 1)::2]
+    gt = torch.full((B, C, 4, H + 1, P), float("nan"), device=DEV)
+    gzd, fd = gz.to(DEV), fir.to(DEV)
+    _lib.call("cagc_blur_up_bwd", _lib.ptr(gt), _lib.ptr(gzd), _lib.ptr(fd), B, C, H, W)
+    got = gt.cpu().double().reshape(B * C, 4, H + 1, P)
+    assert torch.isfinite(got).all(), "an entry of the phase planes (incl. padding) was not written"
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-6, (case, err)
+    assert float(got[:, :, :, W + 1:].abs().max()) == 0.0 and float(got[:, 2:, H, :].abs().max()) == 0.0 and float(got[:, 1::2, :, W].abs().max()) == 0.0
