@@ -187,9 +187,9 @@ KERNEL_OF = {"cagc_wino_conv3x3[k_wino<4, false>]": "k_wino<4, false, false", "c
              "cagc_wino_conv3x3[k_wino4<false>]": "k_wino4<false,", "cagc_wino_conv3x3_act_dgrad[k_wino4<true>]": "k_wino4<true,",   # both SCALE variants
              "cagc_modconv_fwd": "k_conv_rd<4, true, true, false>",
              "cagc_modconv_up_fwd": "k_conv_up25<true, 0",
-             "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_act_fwd": "k_conv_s2w<true>", "cagc_conv3x3s2_dgrad": "k_conv_up25<false, 1",
+             "cagc_conv3x3s2_fwd": "k_conv_rd<8, false, false, false>", "cagc_conv3x3s2_act_fwd": "k_conv_s2w<1, 4, false>", "cagc_conv3x3s2_dgrad": "k_conv_up25<false, 1",
              "cagc_modconv_dgrad": "k_conv_rd<5, true, false, true>",
-             "cagc_modconv_up_dgrad": "k_conv_rd<5, true, false, true>", "cagc_modconv_wgrad": "k_wgrad_rd<4, 1, false, 9>",
+             "cagc_modconv_up_dgrad": "k_conv_s2w<2, 5, true>", "cagc_modconv_wgrad": "k_wgrad_rd<4, 1, false, 9>",
              "cagc_modconv_wgrad_demod": "k_wgrad_rd<3, 1, false, 9>"}
 
 
@@ -202,7 +202,7 @@ def pmc_traffic(symbol):
         return None, "the committed PMC passes profile the 256 px workload"
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_{c}.md") for r in ("r05", "r04", "r03")) if os.path.exists(q)), None)
+        path = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_{c}.md") for r in ("r06", "r05", "r04", "r03")) if os.path.exists(q)), None)
         if path is None:
             return None, "no committed PMC summary"
         for line in open(path):
@@ -816,6 +816,8 @@ def main():
                  "median_batch_ms": round(med_b * 1e3, 1), "unit": "images/s", "batches": nb, "batch_size": 64,
                  "shader_clock_mhz": round(float(sw_clk[0] / sw_clk[1])) if float(sw_clk[1]) > 0 else None,
                  "what": "content-aware saliency sweep, full 256px generator fwd+bwd (271 GFLOP/img), on-device mask/noise/score",
+                 "method": "one prune.content_aware_scores call per bs-64 batch, each followed by a device synchronise (per-batch wall times for the "
+                           "median; since round 5 — rounds 1-4 timed ONE call over all batches, so their values are ~1 % higher for the same kernels)",
                  "direct_equivalent_tflops": round(64 * nb / dts * 271e9 / 1e12, 1),
                  "tflops_note": "direct_equivalent = 271 GFLOP/img (every conv as a direct convolution) x images/s: NOT a utilisation figure, it may exceed "
                                 "the 157.3 TFLOP/s fp32-MFMA peak; executed = the MFMA flops the launches of one more (untimed) batch issue, over the median batch time",
